@@ -1,0 +1,135 @@
+/* pffft_hip.h — C ABI of libpffft_hip.so, the MI355X (gfx950) drop-in for the pffft hot path.
+ *
+ * PART 1 declares, with identical names, argument meaning and error behaviour, every symbol the
+ * reference exports for this path (reference headers: include/pffft/pffft.h:124-250,
+ * include/pffft/pffft_double.h:124-246, include/pffft/pffastconv.h:145-180, plus the two
+ * validate_* self-test entries the reference's test programs declare by hand,
+ * tests/test_pffft.c:269-272).  A program compiled against the reference's own headers links
+ * against libpffft_hip.so unchanged; this header exists so that the ABI is written down in this
+ * repository (tests/test_abi.py checks that every name below is exported).
+ *
+ * PART 2 is the additive batched / device-pointer extension the throughput metric is measured on
+ * (the reference API transforms one vector per call, include/pffft/pffft.h:159,168).
+ *
+ * Pointer rule for PART 1: `float*` / `double*` arguments may be ordinary host pointers (staged
+ * through the device: correct, PCIe-bound) or device / managed pointers (used in place).  There is
+ * no CPU arithmetic path in this library: without a usable HIP device every transform entry
+ * reports the failure on stderr and aborts (set PFFFT_HIP_NO_ABORT=1 to get NaN-filled output
+ * instead).  `work` is accepted and ignored (reference: scratch of N / 2N scalars or NULL,
+ * include/pffft/pffft.h:137-142).
+ */
+#ifndef PFFFT_HIP_H
+#define PFFFT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ PART 1: reference ABI ---- */
+
+typedef struct PFFFT_Setup PFFFT_Setup;   /* include/pffft/pffft.h:106        */
+typedef struct PFFFTD_Setup PFFFTD_Setup; /* include/pffft/pffft_double.h:111 */
+typedef struct PFFASTCONV_Setup PFFASTCONV_Setup; /* include/pffft/pffastconv.h:81 */
+
+#ifndef PFFFT_COMMON_ENUMS
+#define PFFFT_COMMON_ENUMS
+typedef enum { PFFFT_FORWARD, PFFFT_BACKWARD } pffft_direction_t; /* pffft.h:112 */
+typedef enum { PFFFT_REAL, PFFFT_COMPLEX } pffft_transform_t;     /* pffft.h:115 */
+#endif
+
+/* float — src/pffft.c:101-129 maps these onto src/pffft_priv_impl.h */
+PFFFT_Setup *pffft_new_setup(int N, pffft_transform_t transform);            /* impl :1062-1112; NULL on invalid N */
+void pffft_destroy_setup(PFFFT_Setup *);                                     /* impl :1115-1120; NULL-safe */
+void pffft_transform(PFFFT_Setup *, const float *in, float *out, float *work, pffft_direction_t);         /* :1816 */
+void pffft_transform_ordered(PFFFT_Setup *, const float *in, float *out, float *work, pffft_direction_t); /* :1820 */
+void pffft_zreorder(PFFFT_Setup *, const float *in, float *out, pffft_direction_t);                       /* :1158 */
+void pffft_zconvolve_accumulate(PFFFT_Setup *, const float *a, const float *b, float *ab, float scaling); /* :1534 */
+void pffft_zconvolve_no_accu(PFFFT_Setup *, const float *a, const float *b, float *ab, float scaling);    /* :1632 */
+int pffft_simd_size(void);                                 /* :76  — always 4: selects the 4-lane internal layout */
+const char *pffft_simd_arch(void);                         /* :116 — "HIP-gfx950" */
+int pffft_min_fft_size(pffft_transform_t transform);       /* :78  */
+int pffft_is_valid_size(int N, pffft_transform_t cplx);    /* :91  */
+int pffft_nearest_transform_size(int N, pffft_transform_t cplx, int higher); /* :100 */
+int pffft_next_power_of_two(int N);                        /* src/pffft_common.c:25 */
+int pffft_is_power_of_two(int N);                          /* src/pffft_common.c:39 */
+void *pffft_aligned_malloc(size_t nb_bytes);               /* src/pffft_common.c:12 — 64-byte aligned */
+void pffft_aligned_free(void *);
+int validate_pffft_simd(void);                             /* impl :2227 — layout self-test, 0 = ok */
+int validate_pffft_simd_ex(void *dbg_file);                /* impl :1889 (FILE* or NULL) */
+
+/* double — src/pffft_double.c:113-142 */
+PFFFTD_Setup *pffftd_new_setup(int N, pffft_transform_t transform);
+void pffftd_destroy_setup(PFFFTD_Setup *);
+void pffftd_transform(PFFFTD_Setup *, const double *in, double *out, double *work, pffft_direction_t);
+void pffftd_transform_ordered(PFFFTD_Setup *, const double *in, double *out, double *work, pffft_direction_t);
+void pffftd_zreorder(PFFFTD_Setup *, const double *in, double *out, pffft_direction_t);
+void pffftd_zconvolve_accumulate(PFFFTD_Setup *, const double *a, const double *b, double *ab, double scaling);
+void pffftd_zconvolve_no_accu(PFFFTD_Setup *, const double *a, const double *b, double *ab, double scaling);
+int pffftd_simd_size(void);
+const char *pffftd_simd_arch(void);
+int pffftd_min_fft_size(pffft_transform_t transform);
+int pffftd_is_valid_size(int N, pffft_transform_t cplx);
+int pffftd_nearest_transform_size(int N, pffft_transform_t cplx, int higher);
+int pffftd_next_power_of_two(int N);
+int pffftd_is_power_of_two(int N);
+void *pffftd_aligned_malloc(size_t nb_bytes);
+void pffftd_aligned_free(void *);
+int validate_pffftd_simd(void);
+int validate_pffftd_simd_ex(void *dbg_file);
+
+/* fast convolution — src/pffastconv.c:58-263; flag values of include/pffft/pffastconv.h:83-134 */
+enum {
+  PFFASTCONV_HIP_CPLX_INP_OUT = 1, PFFASTCONV_HIP_CPLX_FILTER = 2, PFFASTCONV_HIP_DIRECT_INP = 4,
+  PFFASTCONV_HIP_DIRECT_OUT = 8, PFFASTCONV_HIP_CPLX_SINGLE_FFT = 16, PFFASTCONV_HIP_SYMMETRIC = 32,
+  PFFASTCONV_HIP_CORRELATION = 64
+};
+PFFASTCONV_Setup *pffastconv_new_setup(const float *filterCoeffs, int filterLen, int *blockLen, int flags);
+void pffastconv_destroy_setup(PFFASTCONV_Setup *);
+int pffastconv_apply(PFFASTCONV_Setup *, const float *input, int inputLen, float *output, int applyFlush);
+void *pffastconv_malloc(size_t nb_bytes);
+void pffastconv_free(void *);
+int pffastconv_simd_size(void);
+
+/* ------------------------------------------------- PART 2: batched / device extension -------- */
+/* All return 0 on success, otherwise a hipError_t value (pffft_hip_last_error() has the text).
+ * `in`, `out`, `a`, `b`, `ab` are DEVICE pointers to `batch` contiguous vectors (N scalars for a
+ * real setup, 2N for a complex one), 16-byte (float) / 32-byte (double) aligned.  `stream` is a
+ * hipStream_t (NULL = default stream).  Calls are asynchronous with respect to the host.  in == out
+ * is allowed for the transforms (include/pffft/pffft.h:157) and all of a/b/ab may alias for
+ * zconvolve (:194); zreorder needs in != out (:180).
+ *   ordered = 0 -> pffft_transform semantics (spectrum in the internal layout)
+ *   ordered = 1 -> pffft_transform_ordered semantics (canonical interleaved spectrum) */
+int pffft_hip_transform_batch(PFFFT_Setup *, const float *in, float *out, size_t batch,
+                              pffft_direction_t direction, int ordered, void *stream);
+int pffft_hip_zreorder_batch(PFFFT_Setup *, const float *in, float *out, size_t batch,
+                             pffft_direction_t direction, void *stream);
+/* ab[i] (+)= a[i] * b[i or 0] * scaling; b_broadcast != 0 reuses ONE spectrum b for every vector
+ * (the FIR case, src/pffastconv.c:238) */
+int pffft_hip_zconvolve_batch(PFFFT_Setup *, const float *a, const float *b, float *ab, float scaling,
+                              size_t batch, int accumulate, int b_broadcast, void *stream);
+
+int pffftd_hip_transform_batch(PFFFTD_Setup *, const double *in, double *out, size_t batch,
+                               pffft_direction_t direction, int ordered, void *stream);
+int pffftd_hip_zreorder_batch(PFFFTD_Setup *, const double *in, double *out, size_t batch,
+                              pffft_direction_t direction, void *stream);
+int pffftd_hip_zconvolve_batch(PFFFTD_Setup *, const double *a, const double *b, double *ab, double scaling,
+                               size_t batch, int accumulate, int b_broadcast, void *stream);
+
+/* Overlap-save FIR on device-resident signal/output (same block schedule as pffastconv_apply,
+ * src/pffastconv.c:204-261): returns the number of output samples written, or -1 on error. */
+int pffastconv_hip_apply_device(PFFASTCONV_Setup *, const float *d_input, int inputLen, float *d_output,
+                                int applyFlush, void *stream);
+
+/* Name of the kernel family a setup dispatches to ("c1024_f32", "generic", ...): for tests/bench. */
+const char *pffft_hip_kernel_name(const void *setup);
+const char *pffft_hip_last_error(void);
+int pffft_hip_device_count(void);
+/* 0 = default; other values select experimental variants of the headline kernel (bench A/B only) */
+void pffft_hip_set_variant(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFFFT_HIP_H */

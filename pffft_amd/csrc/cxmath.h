@@ -1,0 +1,137 @@
+// Complex arithmetic and small-radix DFT butterflies for the gfx950 FFT kernels.
+//
+// These are the MI355X counterparts of the reference's SIMD macro layer
+// (src/simd/pf_sse1_float.h:45-77, VCPLXMUL/VCPLXMULCONJ in src/simd/pf_float.h:76-81)
+// and of the arithmetic inside passf2/3/4/5_ps (src/pffft_priv_impl.h:122-321).  They are
+// NOT a translation: a butterfly here is a per-lane register DFT of radix 2/3/4/5/8/16 with
+// natural-order output, used by one-wavefront-per-transform kernels; the reference's
+// butterflies operate on 4-lane vectors sweeping main memory.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pf {
+
+constexpr int FWD = 0;  // PFFFT_FORWARD  (include/pffft/pffft.h:112) : exp(-2*pi*i*nk/N)
+constexpr int BWD = 1;  // PFFFT_BACKWARD                            : exp(+2*pi*i*nk/N), unscaled
+
+template <typename T> struct cx { T x, y; };
+
+template <typename T> __device__ __forceinline__ cx<T> mk(T x, T y) { cx<T> r; r.x = x; r.y = y; return r; }
+template <typename T> __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <typename T> __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
+template <typename T> __device__ __forceinline__ cx<T> operator*(cx<T> a, T s) { return mk<T>(a.x * s, a.y * s); }
+template <typename T> __device__ __forceinline__ cx<T> conj(cx<T> a) { return mk<T>(a.x, -a.y); }
+
+// a * w
+template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> w) {
+    return mk<T>(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+// a * conj(w)
+template <typename T> __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> w) {
+    return mk<T>(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+}
+// a * w for the forward transform, a * conj(w) for the backward one (table holds exp(-i*theta))
+template <int DIR, typename T> __device__ __forceinline__ cx<T> twmul(cx<T> a, cx<T> w) {
+    return DIR == FWD ? cmul(a, w) : cmulc(a, w);
+}
+// multiply by -i (forward) / +i (backward): the radix-4 "quarter turn"
+template <int DIR, typename T> __device__ __forceinline__ cx<T> rot(cx<T> a) {
+    return DIR == FWD ? mk<T>(a.y, -a.x) : mk<T>(-a.y, a.x);
+}
+
+template <int DIR, typename T> __device__ __forceinline__ void dft2(cx<T>& a0, cx<T>& a1) {
+    cx<T> t = a0 - a1; a0 = a0 + a1; a1 = t;
+}
+
+template <int DIR, typename T> __device__ __forceinline__ void dft3(cx<T>& a0, cx<T>& a1, cx<T>& a2) {
+    const T s3 = (T)0.86602540378443864676372317075294L;  // sin(2*pi/3)
+    cx<T> t1 = a1 + a2;
+    cx<T> m = mk<T>(a0.x - (T)0.5 * t1.x, a0.y - (T)0.5 * t1.y);
+    cx<T> d = rot<DIR>((a1 - a2) * s3);  // (-/+ i) * sin * (a1 - a2)
+    a0 = a0 + t1; a1 = m + d; a2 = m - d;
+}
+
+template <int DIR, typename T>
+__device__ __forceinline__ void dft4(cx<T>& a0, cx<T>& a1, cx<T>& a2, cx<T>& a3) {
+    cx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<DIR>(a1 - a3);
+    a0 = t0 + t2; a1 = t1 + t3; a2 = t0 - t2; a3 = t1 - t3;
+}
+
+template <int DIR, typename T>
+__device__ __forceinline__ void dft5(cx<T>& a0, cx<T>& a1, cx<T>& a2, cx<T>& a3, cx<T>& a4) {
+    const T c1 = (T)0.30901699437494742410229341718282L;   // cos(2*pi/5)
+    const T c2 = (T)-0.80901699437494742410229341718282L;  // cos(4*pi/5)
+    const T s1 = (T)0.95105651629515357211643933337938L;   // sin(2*pi/5)
+    const T s2 = (T)0.58778525229247312916870595463907L;   // sin(4*pi/5)
+    cx<T> p1 = a1 + a4, m1 = a1 - a4, p2 = a2 + a3, m2 = a2 - a3;
+    cx<T> u1 = mk<T>(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
+    cx<T> u2 = mk<T>(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
+    cx<T> v1 = rot<DIR>(mk<T>(s1 * m1.x + s2 * m2.x, s1 * m1.y + s2 * m2.y));
+    cx<T> v2 = rot<DIR>(mk<T>(s2 * m1.x - s1 * m2.x, s2 * m1.y - s1 * m2.y));
+    a0 = a0 + p1 + p2; a1 = u1 + v1; a4 = u1 - v1; a2 = u2 + v2; a3 = u2 - v2;
+}
+
+// a * exp(-/+ i*pi/4) and a * exp(-/+ 3i*pi/4)
+template <int DIR, typename T> __device__ __forceinline__ cx<T> mulw8_1(cx<T> a) {
+    const T h = (T)0.70710678118654752440084436210485L;
+    return DIR == FWD ? mk<T>((a.x + a.y) * h, (a.y - a.x) * h) : mk<T>((a.x - a.y) * h, (a.x + a.y) * h);
+}
+template <int DIR, typename T> __device__ __forceinline__ cx<T> mulw8_3(cx<T> a) {
+    const T h = (T)0.70710678118654752440084436210485L;
+    return DIR == FWD ? mk<T>((a.y - a.x) * h, -(a.x + a.y) * h) : mk<T>(-(a.x + a.y) * h, (a.x - a.y) * h);
+}
+
+// in-place radix-8, natural-order output (a[d] = sum_q a[q] W8^(q d))
+template <int DIR, typename T> __device__ __forceinline__ void dft8(cx<T> (&a)[8]) {
+    cx<T> b0 = a[0] + a[4], c0 = a[0] - a[4];
+    cx<T> b1 = a[1] + a[5], c1 = mulw8_1<DIR>(a[1] - a[5]);
+    cx<T> b2 = a[2] + a[6], c2 = rot<DIR>(a[2] - a[6]);
+    cx<T> b3 = a[3] + a[7], c3 = mulw8_3<DIR>(a[3] - a[7]);
+    dft4<DIR>(b0, b1, b2, b3);
+    dft4<DIR>(c0, c1, c2, c3);
+    a[0] = b0; a[2] = b1; a[4] = b2; a[6] = b3;
+    a[1] = c0; a[3] = c1; a[5] = c2; a[7] = c3;
+}
+
+// in-place radix-16, natural-order output
+template <int DIR, typename T> __device__ __forceinline__ void dft16(cx<T> (&a)[16]) {
+    const T c1 = (T)0.92387953251128675612818318939679L;  // cos(pi/8)
+    const T s1 = (T)0.38268343236508977172845998403040L;  // sin(pi/8)
+    cx<T> b[8], c[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { b[q] = a[q] + a[q + 8]; c[q] = a[q] - a[q + 8]; }
+    // c[q] *= W16^q (forward: exp(-i*pi*q/8))
+    const cx<T> w1 = mk<T>(c1, -s1), w3 = mk<T>(s1, -c1);
+    c[1] = twmul<DIR>(c[1], w1);
+    c[2] = mulw8_1<DIR>(c[2]);
+    c[3] = twmul<DIR>(c[3], w3);
+    c[4] = rot<DIR>(c[4]);
+    c[5] = twmul<DIR>(c[5], mk<T>(-s1, -c1));
+    c[6] = mulw8_3<DIR>(c[6]);
+    c[7] = twmul<DIR>(c[7], mk<T>(-c1, -s1));
+    dft8<DIR>(b);
+    dft8<DIR>(c);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { a[2 * d] = b[d]; a[2 * d + 1] = c[d]; }
+}
+
+template <int R, int DIR, typename T> __device__ __forceinline__ void dftR(cx<T> (&a)[R]) {
+    if constexpr (R == 2) dft2<DIR>(a[0], a[1]);
+    else if constexpr (R == 3) dft3<DIR>(a[0], a[1], a[2]);
+    else if constexpr (R == 4) dft4<DIR>(a[0], a[1], a[2], a[3]);
+    else if constexpr (R == 5) dft5<DIR>(a[0], a[1], a[2], a[3], a[4]);
+    else if constexpr (R == 8) dft8<DIR>(a);
+    else if constexpr (R == 16) dft16<DIR>(a);
+}
+
+// 16-byte (float) / 32-byte (double) global access unit: 4 scalars
+template <typename T> struct vec4t;
+template <> struct vec4t<float> { typedef __attribute__((ext_vector_type(4))) float type; };
+template <> struct vec4t<double> { typedef __attribute__((ext_vector_type(4))) double type; };
+template <typename T> using vec4 = typename vec4t<T>::type;
+template <typename T> struct vec2t;
+template <> struct vec2t<float> { typedef __attribute__((ext_vector_type(2))) float type; };
+template <> struct vec2t<double> { typedef __attribute__((ext_vector_type(2))) double type; };
+template <typename T> using vec2 = typename vec2t<T>::type;
+
+}  // namespace pf

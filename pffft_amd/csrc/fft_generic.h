@@ -1,0 +1,266 @@
+// Generic LDS-resident batched FFT kernel: any n = 2^a 3^b 5^c that fits in LDS, float or double,
+// real or complex, forward or backward, canonical ("ordered") or pffft-internal ("unordered")
+// spectrum layout.  This is the coverage kernel behind every pffft_* / pffftd_* entry; the
+// size-specialised kernels (fft_c1024.h ...) replace it on the headline shapes.
+//
+// What it replaces in the reference (all in src/pffft_priv_impl.h):
+//   cfftf1_ps :1004-1048 + passf2/3/4/5_ps :122-321   -> stage<R>() in-place DIF passes in LDS
+//   rfftf1_ps/rfftb1_ps :809-901 + radf*/radb* :323-807 -> complex FFT of length N/2 + real_post/real_pre
+//   pffft_cplx_finalize/_preprocess :1195-1270, pffft_real_finalize/_preprocess :1330-1462
+//                                                       -> absorbed: one length-n transform, no 4-lane stitch
+//   pffft_zreorder :1158-1193                           -> bin_of(): the layout is applied on the global
+//                                                          load / store address, never as a separate sweep
+//   pffft_transform_internal :1465-1532                 -> the kernel body (load, passes, store)
+//
+// Structure (one workgroup handles G transforms per pass, grid-stride over the batch):
+//   L  global -> LDS, coalesced 4-scalar loads, scatter to natural order (undoing the internal layout)
+//   P  (real backward) half-complex spectrum -> packed complex spectrum, pairs (k, n-k) in place
+//   C  radix-2/3/4/5 decimation-in-frequency passes, in place, output left digit-reversed in LDS
+//   Q  (real forward) packed complex spectrum -> half-complex spectrum, pairs in place
+//   S  LDS -> global, coalesced 4-scalar stores, gather through digit reversal + layout map
+#pragma once
+#include "cxmath.h"
+
+namespace pf {
+
+constexpr int MAX_STAGES = 28;
+
+struct GenericPlan {
+    int n;        // complex length held in LDS: N (complex) or N/2 (real)
+    int nstages;
+    int is_real;
+    int G;        // transforms per workgroup pass
+    unsigned char radix[MAX_STAGES];
+};
+
+// canonical bin k (natural order) -> LDS position after the DIF passes (mixed-radix digit reversal)
+__device__ __forceinline__ int pos_of(int k, const GenericPlan& p) {
+    int pos = 0, m = p.n;
+    for (int s = 0; s < p.nstages; ++s) {
+        int R = p.radix[s], d;
+        switch (R) {
+            case 2: d = k & 1; k >>= 1; m >>= 1; break;
+            case 4: d = k & 3; k >>= 2; m >>= 2; break;
+            case 3: d = k % 3; k /= 3; m /= 3; break;
+            default: d = k % 5; k /= 5; m /= 5; break;
+        }
+        pos += d * m;
+    }
+    return pos;
+}
+
+// Spectrum bin stored at slot l (0..3) of 4-scalar group v of one vector in the pffft-internal
+// layout (SIMD_SZ == 4).  Closed forms checked against the reference's own pffft_zreorder
+// (src/pffft_priv_impl.h:1158-1193) in tests/test_oracle_layout.py:
+//   complex: internal[32 b + 8 m + 4 p + l] = part p of X[m n/4 + 4 b + l]
+//   real   : internal[32 b + 8 q + 4 p + l] = part p of X[bin(q, t = 4 b + l)] with
+//            bin(0,t)=t, bin(2,t)=n/2+t, bin(1,t)= t ? n/2-t : n/4, bin(3,t)= t ? n-t : 3n/4
+//            (n = N/2 bins; bin 0 carries (DC, Nyquist))
+__device__ __forceinline__ int bin_of(int v, int l, int n, int is_real) {
+    int b = v >> 3, q = (v >> 1) & 3, t = 4 * b + l;
+    if (!is_real) return q * (n >> 2) + t;
+    switch (q) {
+        case 0: return t;
+        case 2: return (n >> 1) + t;
+        case 1: return t ? (n >> 1) - t : (n >> 2);
+        default: return t ? n - t : 3 * (n >> 2);
+    }
+}
+
+template <typename T, int R, int DIR>
+__device__ __forceinline__ void stage(cx<T>* z, int total, int Ls, int tw_stride, const cx<T>* __restrict__ tw) {
+    const int m = Ls / R;
+    const int nb = total / R;
+    for (int id = threadIdx.x; id < nb; id += blockDim.x) {
+        int sub = id / m;
+        int i = id - sub * m;
+        cx<T>* base = z + sub * Ls + i;
+        cx<T> a[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) a[q] = base[q * m];
+        dftR<R, DIR>(a);
+        base[0] = a[0];
+#pragma unroll
+        for (int d = 1; d < R; ++d) base[d * m] = twmul<DIR>(a[d], tw[(i * d) * tw_stride]);
+    }
+}
+
+template <typename T, int DIR>
+__global__ void __launch_bounds__(1024)
+fft_generic_kernel(const T* in, T* out, size_t batch, GenericPlan p, int in_internal, int out_internal,
+                   const cx<T>* __restrict__ tw, const cx<T>* __restrict__ twr) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cx<T>* z = reinterpret_cast<cx<T>*>(smem_raw);
+    T* zs = reinterpret_cast<T*>(smem_raw);
+    const int n = p.n, G = p.G;
+    const int nv = n >> 1;  // 4-scalar groups per vector (2n scalars complex, N = 2n scalars real)
+    const vec4<T>* in4 = reinterpret_cast<const vec4<T>*>(in);
+    vec4<T>* out4 = reinterpret_cast<vec4<T>*>(out);
+
+    for (size_t t0 = (size_t)blockIdx.x * G; t0 < batch; t0 += (size_t)gridDim.x * G) {
+        const int g_here = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);
+        const int totv = g_here * nv;
+        // ---- L: load ----
+        for (int iv = threadIdx.x; iv < totv; iv += blockDim.x) {
+            vec4<T> val = in4[t0 * nv + iv];
+            if (!in_internal) {
+                z[2 * iv] = mk<T>(val.x, val.y);
+                z[2 * iv + 1] = mk<T>(val.z, val.w);
+            } else {
+                int g = iv / nv, v = iv - g * nv, part = v & 1;
+                T* zg = zs + 2 * (size_t)g * n + part;
+                zg[2 * bin_of(v, 0, n, p.is_real)] = val.x;
+                zg[2 * bin_of(v, 1, n, p.is_real)] = val.y;
+                zg[2 * bin_of(v, 2, n, p.is_real)] = val.z;
+                zg[2 * bin_of(v, 3, n, p.is_real)] = val.w;
+            }
+        }
+        __syncthreads();
+        // ---- P: real backward pre-processing: Z'[k] = (A+B) + i w (A-B), Z'[n-k] = conj((A+B) - i w (A-B)),
+        //         A = X[k], B = conj X[n-k], w = exp(+2 pi i k / N)  (gives N*x after the unscaled inverse) ----
+        if (p.is_real && DIR == BWD) {
+            const int half = n >> 1, per = half + 1;
+            for (int id = threadIdx.x; id < g_here * per; id += blockDim.x) {
+                int g = id / per, k = id - g * per;
+                cx<T>* zg = z + (size_t)g * n;
+                if (k == 0) {
+                    cx<T> a = zg[0];
+                    zg[0] = mk<T>(a.x + a.y, a.x - a.y);
+                } else if (k == half) {
+                    cx<T> a = zg[half];
+                    zg[half] = mk<T>((T)2 * a.x, (T)-2 * a.y);
+                } else {
+                    cx<T> A = zg[k], B = conj(zg[n - k]);
+                    cx<T> S = A + B, Dm = cmulc(A - B, twr[k]);  // (A-B) * conj(W_N^k)
+                    cx<T> D = mk<T>(-Dm.y, Dm.x);                // * i
+                    zg[k] = S + D;
+                    zg[n - k] = conj(S - D);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- C: in-place DIF passes ----
+        {
+            int Ls = n;
+            const int total = g_here * n;
+            for (int s = 0; s < p.nstages; ++s) {
+                const int R = p.radix[s];
+                const int tws = n / Ls;
+                switch (R) {
+                    case 2: stage<T, 2, DIR>(z, total, Ls, tws, tw); break;
+                    case 3: stage<T, 3, DIR>(z, total, Ls, tws, tw); break;
+                    case 4: stage<T, 4, DIR>(z, total, Ls, tws, tw); break;
+                    default: stage<T, 5, DIR>(z, total, Ls, tws, tw); break;
+                }
+                Ls /= R;
+                __syncthreads();
+            }
+        }
+        // ---- Q: real forward post-processing: X[k] = S + D, X[n-k] = conj(S - D),
+        //         S = (A+B)/2, D = -(i/2) W_N^k (A-B), A = Z[k], B = conj Z[n-k] ----
+        if (p.is_real && DIR == FWD) {
+            const int half = n >> 1, per = half + 1;
+            for (int id = threadIdx.x; id < g_here * per; id += blockDim.x) {
+                int g = id / per, k = id - g * per;
+                cx<T>* zg = z + (size_t)g * n;
+                if (k == 0) {
+                    cx<T> a = zg[0];
+                    zg[0] = mk<T>(a.x + a.y, a.x - a.y);  // (DC, Nyquist): include/pffft/pffft.h:144-152
+                } else if (k == half) {
+                    int pk = pos_of(half, p);
+                    zg[pk] = conj(zg[pk]);
+                } else {
+                    int pk = pos_of(k, p), pn = pos_of(n - k, p);
+                    cx<T> A = zg[pk], B = conj(zg[pn]);
+                    cx<T> S = (A + B) * (T)0.5, Dm = cmul(A - B, twr[k]) * (T)0.5;
+                    cx<T> D = mk<T>(Dm.y, -Dm.x);  // * (-i)
+                    zg[pk] = S + D;
+                    zg[pn] = conj(S - D);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- S: store ----
+        for (int iv = threadIdx.x; iv < totv; iv += blockDim.x) {
+            int g = iv / nv, v = iv - g * nv;
+            const cx<T>* zg = z + (size_t)g * n;
+            vec4<T> val;
+            if (!out_internal) {
+                cx<T> a = zg[pos_of(2 * v, p)], b = zg[pos_of(2 * v + 1, p)];
+                val.x = a.x; val.y = a.y; val.z = b.x; val.w = b.y;
+            } else {
+                const T* zp = reinterpret_cast<const T*>(zg) + (v & 1);
+                val.x = zp[2 * pos_of(bin_of(v, 0, n, p.is_real), p)];
+                val.y = zp[2 * pos_of(bin_of(v, 1, n, p.is_real), p)];
+                val.z = zp[2 * pos_of(bin_of(v, 2, n, p.is_real), p)];
+                val.w = zp[2 * pos_of(bin_of(v, 3, n, p.is_real), p)];
+            }
+            out4[t0 * nv + iv] = val;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Spectral helpers in the internal layout (batched, elementwise, HBM-bound).
+//   zreorder      : src/pffft_priv_impl.h:1158-1193  (pure permutation internal <-> canonical)
+//   zconvolve_*   : src/pffft_priv_impl.h:1534-1684  (ab (+)= a*b*scaling; for real transforms the
+//                   scalars at internal index 0 (DC) and 4 (Nyquist) multiply as reals, :1626-1629)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void zreorder_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, int n, int is_real,
+                                int to_canonical) {
+    const int nv = n >> 1;
+    const size_t total = batch * (size_t)nv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t t = i / nv;
+        int v = (int)(i - t * nv);
+        const size_t base = t * 2 * (size_t)n;
+        int part = v & 1;
+        if (to_canonical) {  // gather: read one internal group, scatter 4 scalars (write side strided)
+            vec4<T> val = reinterpret_cast<const vec4<T>*>(in)[i];
+            out[base + 2 * (size_t)bin_of(v, 0, n, is_real) + part] = val.x;
+            out[base + 2 * (size_t)bin_of(v, 1, n, is_real) + part] = val.y;
+            out[base + 2 * (size_t)bin_of(v, 2, n, is_real) + part] = val.z;
+            out[base + 2 * (size_t)bin_of(v, 3, n, is_real) + part] = val.w;
+        } else {
+            vec4<T> val;
+            val.x = in[base + 2 * (size_t)bin_of(v, 0, n, is_real) + part];
+            val.y = in[base + 2 * (size_t)bin_of(v, 1, n, is_real) + part];
+            val.z = in[base + 2 * (size_t)bin_of(v, 2, n, is_real) + part];
+            val.w = in[base + 2 * (size_t)bin_of(v, 3, n, is_real) + part];
+            reinterpret_cast<vec4<T>*>(out)[i] = val;
+        }
+    }
+}
+
+// One thread handles a (re-group, im-group) pair = 4 complex products.
+template <typename T, int ACCUMULATE>
+__global__ void zconvolve_kernel(const T* a, const T* b, T* ab, size_t batch, int n, int is_real, T scaling,
+                                 size_t a_stride, size_t b_stride) {
+    const int npairs = n >> 2;  // pairs of 4-scalar groups per vector
+    const size_t total = batch * (size_t)npairs;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t t = i / npairs;
+        int pr = (int)(i - t * npairs);
+        const vec4<T>* a4 = reinterpret_cast<const vec4<T>*>(a + t * a_stride) + 2 * pr;
+        const vec4<T>* b4 = reinterpret_cast<const vec4<T>*>(b + t * b_stride) + 2 * pr;
+        vec4<T>* ab4 = reinterpret_cast<vec4<T>*>(ab + t * 2 * (size_t)n) + 2 * pr;
+        vec4<T> ar = a4[0], ai = a4[1], br = b4[0], bi = b4[1];
+        vec4<T> pr_ = ar * br - ai * bi, pi_ = ar * bi + ai * br;
+        if (is_real && pr == 0) {  // DC and Nyquist are both real: multiply separately
+            pr_.x = ar.x * br.x;
+            pi_.x = ai.x * bi.x;
+        }
+        if (ACCUMULATE) {
+            vec4<T> cr = ab4[0], ci = ab4[1];
+            ab4[0] = cr + pr_ * scaling;
+            ab4[1] = ci + pi_ * scaling;
+        } else {
+            ab4[0] = pr_ * scaling;
+            ab4[1] = pi_ * scaling;
+        }
+    }
+}
+
+}  // namespace pf

@@ -1,0 +1,216 @@
+// pffastconv on the GPU: overlap-save FIR with ALL blocks of a call batched into one pass.
+//
+// Reference: src/pffastconv.c — setup :58-116 (Nfft choice :62-80, flipped / zero-stuffed filter image
+// :99-106, one forward transform into Hf :108), apply :133-263 (block loop :207-261: copy + zero pad,
+// forward rFFT, pffft_zconvolve_no_accu with scale 1/Nfft, backward rFFT, copy numOut samples).
+// The reference walks the blocks one by one on one core; here every block of the call is gathered
+// into a [nblk][Nfft] device image and pushed through the batched kernels in place:
+//   gather -> rFFT fwd (internal layout) -> x Hf * 1/Nfft -> rFFT bwd -> scatter.
+// (included at the end of pffft_hip.hip)
+#pragma once
+
+namespace pf {
+
+struct FastConv {
+    uint32_t magic;
+    PFFFT_Setup* st;
+    int filterLen;  // effective length (2*len-1 for the single-FFT complex mode, src/pffastconv.c:93-94)
+    int Nfft, flags, cplxFactor;
+    float scale;
+    std::vector<float> h_filter_image;  // time-domain image the reference builds in Xt (:99-106)
+    std::mutex mu;
+    float* d_Hf = nullptr;
+    float* d_work = nullptr; size_t work_floats = 0;
+    float* d_x = nullptr; size_t x_floats = 0;
+    float* d_y = nullptr; size_t y_floats = 0;
+};
+constexpr uint32_t FC_MAGIC = 0x46434e56u;
+
+// mode 0: real stream (also the single-FFT complex mode, which is a real stream of 2x length)
+// mode 1: interleaved complex input processed as two real streams (part = block & 1)
+__global__ void fastconv_gather_kernel(const float* __restrict__ x, float* __restrict__ blocks, int nblk, int Nfft,
+                                       int step, int inputLen, int mode) {
+    const size_t total = (size_t)nblk * Nfft;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int b = (int)(i / Nfft), j = (int)(i - (size_t)b * Nfft);
+        float v = 0.f;
+        if (mode == 0) {
+            long src = (long)b * step + j;
+            if (src < inputLen) v = x[src];
+        } else {
+            int part = b & 1;
+            long src = (long)(b >> 1) * step + j;
+            if (src < inputLen) v = x[2 * src + part];
+        }
+        blocks[i] = v;
+    }
+}
+
+__global__ void fastconv_scatter_kernel(const float* __restrict__ blocks, float* __restrict__ y, int nblk, int Nfft,
+                                        int step, int lastOut, int mode) {
+    const int nb_time = mode == 0 ? nblk : nblk >> 1;
+    const size_t total = (size_t)nblk * step;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int b = (int)(i / step), j = (int)(i - (size_t)b * step);
+        int tb = mode == 0 ? b : (b >> 1);
+        int numOut = (tb == nb_time - 1) ? lastOut : step;
+        if (j >= numOut) continue;
+        float v = blocks[(size_t)b * Nfft + j];
+        if (mode == 0) y[(size_t)tb * step + j] = v;
+        else y[2 * ((size_t)tb * step + j) + (b & 1)] = v;
+    }
+}
+
+static int fc_grow(float** p, size_t* have, size_t want) {
+    if (*have >= want) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *have = 0;
+    PF_CHECK(hipMalloc((void**)p, want * sizeof(float)));
+    *have = want;
+    return 0;
+}
+
+static int fc_ensure_device(FastConv* s) {
+    if (s->d_Hf) return 0;
+    PF_CHECK(hipMalloc((void**)&s->d_Hf, sizeof(float) * s->Nfft));
+    PF_CHECK(hipMemcpy(s->d_Hf, s->h_filter_image.data(), sizeof(float) * s->Nfft, hipMemcpyHostToDevice));
+    int rc = transform_batch<float>(s->st, s->d_Hf, s->d_Hf, 1, PFFFT_FORWARD, 0, nullptr);  // :108
+    if (rc) return rc;
+    PF_CHECK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+// Block schedule of src/pffastconv.c:156-166 / :204-210.  Returns the number of time blocks and the
+// number of outputs of the last one; *produced = value returned by pffastconv_apply (in real samples).
+static int fc_schedule(const FastConv* s, int inputLen, int flush, int* lastOut, int* produced) {
+    const int Nfft = s->Nfft, flen = s->filterLen;
+    const int step_full = s->cplxFactor == 2 ? ((Nfft - flen + 1) & ~1) : (Nfft - flen + 1);
+    const long maxOff = flush ? ((long)inputLen - flen + 1) : ((long)inputLen - Nfft + 1);
+    int nblk = 0, last = 0;
+    long off = 0;
+    while (off < maxOff) {
+        long remain = inputLen - off;
+        int procLen = remain >= Nfft ? Nfft : (int)remain;
+        int numOut = procLen - flen + 1;
+        if (s->cplxFactor == 2) { numOut &= ~1; if (!numOut) break; }
+        ++nblk; last = numOut; off += numOut;
+        if (numOut != step_full) break;  // a partial block is always the last one
+    }
+    *lastOut = last;
+    *produced = (int)off;
+    return nblk;
+}
+
+static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, float* d_y, int flush, hipStream_t st,
+                           int* produced_out) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    int rc = fc_ensure_device(s);
+    if (rc) return rc;
+    const int inputLen = s->cplxFactor * cplxInputLen;  // :141
+    const int mode = ((s->flags & PFFASTCONV_HIP_CPLX_INP_OUT) && s->cplxFactor == 1) ? 1 : 0;
+    int lastOut = 0, produced = 0;
+    const int nbt = fc_schedule(s, inputLen, flush, &lastOut, &produced);
+    *produced_out = produced / s->cplxFactor;  // :200 / :261
+    if (nbt == 0) return 0;
+    const int nblk = mode ? 2 * nbt : nbt;
+    const int Nfft = s->Nfft;
+    const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
+    rc = fc_grow(&s->d_work, &s->work_floats, (size_t)nblk * Nfft);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)std::min<size_t>(((size_t)nblk * Nfft + 255) / 256, (size_t)num_cus() * 16);
+    hipLaunchKernelGGL(fastconv_gather_kernel, dim3(grid), dim3(256), 0, st, d_x, s->d_work, nblk, Nfft, step, inputLen,
+                       mode);
+    PF_CHECK(hipGetLastError());
+    rc = transform_batch<float>(s->st, s->d_work, s->d_work, nblk, PFFFT_FORWARD, 0, st);            // :235
+    if (rc) return rc;
+    rc = zconvolve_batch<float>(s->st, s->d_work, s->d_Hf, s->d_work, s->scale, nblk, 0, 1, st);     // :238
+    if (rc) return rc;
+    rc = transform_batch<float>(s->st, s->d_work, s->d_work, nblk, PFFFT_BACKWARD, 0, st);           // :254
+    if (rc) return rc;
+    hipLaunchKernelGGL(fastconv_scatter_kernel, dim3(grid), dim3(256), 0, st, s->d_work, d_y, nblk, Nfft, step, lastOut,
+                       mode);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pf
+
+struct PFFASTCONV_Setup : pf::FastConv {};
+
+PF_EXPORT PFFASTCONV_Setup* pffastconv_new_setup(const float* filterCoeffs, int filterLen, int* blockLen, int flags) {
+    using namespace pf;
+    // src/pffastconv.c:61-82
+    const int cplxFactor = ((flags & PFFASTCONV_HIP_CPLX_INP_OUT) && (flags & PFFASTCONV_HIP_CPLX_SINGLE_FFT)) ? 2 : 1;
+    const int minFftLen = 2 * SIMD * SIMD;
+    if (!filterCoeffs || filterLen <= 0 || !blockLen) return nullptr;
+    int Nfft = 2 * next_pow2(filterLen - 1);
+    if (Nfft < minFftLen) Nfft = minFftLen;
+    if (flags & PFFASTCONV_HIP_CPLX_FILTER) return nullptr;  // :71-72 "not implemented yet"
+    if (*blockLen > Nfft) Nfft = next_pow2(*blockLen);
+    *blockLen = Nfft;
+    Nfft *= cplxFactor;
+    PFFFT_Setup* st = pffft_new_setup(Nfft, PFFFT_REAL);
+    if (!st) return nullptr;
+    PFFASTCONV_Setup* s = new PFFASTCONV_Setup();
+    s->magic = FC_MAGIC;
+    s->st = st;
+    s->filterLen = cplxFactor == 2 ? 2 * filterLen - 1 : filterLen;
+    s->Nfft = Nfft; s->flags = flags; s->cplxFactor = cplxFactor;
+    s->scale = (float)(1.0 / Nfft);
+    s->h_filter_image.assign(Nfft, 0.f);
+    for (int i = 0; i < filterLen; ++i) {  // :100-106
+        float c = (flags & PFFASTCONV_HIP_CORRELATION) ? filterCoeffs[i] : filterCoeffs[filterLen - 1 - i];
+        s->h_filter_image[(Nfft - cplxFactor * i) & (Nfft - 1)] = c;
+    }
+    return s;
+}
+
+PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
+    if (!s) return;
+    pffft_destroy_setup(s->st);
+    for (float* p : {s->d_Hf, s->d_work, s->d_x, s->d_y}) if (p) (void)hipFree(p);
+    s->magic = 0;
+    delete s;
+}
+
+PF_EXPORT int pffastconv_hip_apply_device(PFFASTCONV_Setup* s, const float* d_input, int inputLen, float* d_output,
+                                          int applyFlush, void* stream) {
+    if (!s || s->magic != pf::FC_MAGIC) return -1;
+    int produced = 0;
+    int rc = pf::fc_apply_device(s, d_input, inputLen, d_output, applyFlush, (hipStream_t)stream, &produced);
+    return rc ? -1 : produced;
+}
+
+PF_EXPORT int pffastconv_apply(PFFASTCONV_Setup* s, const float* input, int cplxInputLen, float* output, int applyFlush) {
+    using namespace pf;
+    if (!s || s->magic != FC_MAGIC) { fprintf(stderr, "pffastconv_apply: bad setup\n"); abort(); }
+    const bool in_dev = is_device_ptr(input), out_dev = is_device_ptr(output);
+    const int cpl = (s->flags & PFFASTCONV_HIP_CPLX_INP_OUT) ? 2 : 1;
+    const size_t in_floats = (size_t)cplxInputLen * cpl;
+    const float* d_in = input; float* d_out = output;
+    int rc = 0, produced = 0;
+    do {
+        if (!in_dev) {
+            if ((rc = fc_grow(&s->d_x, &s->x_floats, in_floats ? in_floats : 1))) break;
+            if (in_floats && hipMemcpy(s->d_x, input, in_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = -1; break; }
+            d_in = s->d_x;
+        }
+        if (!out_dev) {
+            if ((rc = fc_grow(&s->d_y, &s->y_floats, in_floats ? in_floats : 1))) break;
+            d_out = s->d_y;
+        }
+        if ((rc = fc_apply_device(s, d_in, cplxInputLen, d_out, applyFlush, nullptr, &produced))) break;
+        if (!out_dev) {
+            if (produced > 0 && hipMemcpy(output, d_out, (size_t)produced * cpl * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = -1; break; }
+        } else if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = -1; break; }
+    } while (0);
+    if (rc) {
+        fprintf(stderr, "pffastconv_apply: HIP path failed (%d): %s\n", rc, g_last_error.c_str());
+        abort();
+    }
+    return produced;
+}
+
+PF_EXPORT void* pffastconv_malloc(size_t nb) { return pf::aligned_malloc64(nb); }
+PF_EXPORT void pffastconv_free(void* p) { pf::aligned_free64(p); }
+PF_EXPORT int pffastconv_simd_size(void) { return pf::SIMD; }

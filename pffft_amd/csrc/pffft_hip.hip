@@ -1,0 +1,513 @@
+// libpffft_hip.so — host side (planner, dispatch, C ABI) of the MI355X pffft drop-in.
+// The ABI is declared in include/pffft_hip.h; each entry cites the reference line it replaces.
+// There is NO CPU arithmetic path here: every transform runs as a HIP kernel on gfx950.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pffft_hip.h"
+#include "fft_c1024.h"
+#include "fft_generic.h"
+
+namespace pf {
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int g_variant = 0;
+
+static int fail(hipError_t e, const char* what) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "pffft_hip: %s failed: %s (%d)", what, hipGetErrorString(e), (int)e);
+    g_last_error = buf;
+    return (int)e;
+}
+#define PF_CHECK(expr)                                   \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return fail(_e, #expr);    \
+    } while (0)
+
+// Legacy void entries have no error channel (include/pffft/pffft.h:159): fail loudly.
+static void legacy_fatal(int code, const char* entry, void* out, size_t out_bytes, bool out_is_host) {
+    fprintf(stderr, "%s: HIP path failed (%d): %s\n", entry, code, g_last_error.c_str());
+    const char* na = getenv("PFFFT_HIP_NO_ABORT");
+    if (na && na[0] == '1') {
+        if (out && out_is_host) memset(out, 0xFF, out_bytes);  // all-ones = NaN pattern
+        return;
+    }
+    abort();
+}
+
+// ------------------------------------------------------------------------------------------------
+// size helpers — semantics of src/pffft_priv_impl.h:76-116 and src/pffft_common.c:25-43
+// ------------------------------------------------------------------------------------------------
+constexpr int SIMD = 4;  // the internal layout is the reference's SIMD_SZ == 4 layout (SURVEY.md finding 2)
+
+static int min_fft_size(int transform) {
+    if (transform == PFFFT_REAL) return 2 * SIMD * SIMD;
+    if (transform == PFFFT_COMPLEX) return SIMD * SIMD;
+    return 1;
+}
+static int is_valid_size(int N, int transform) {
+    const int nmin = min_fft_size(transform);
+    int r = N;
+    while (r >= 5 * nmin && r % 5 == 0) r /= 5;
+    while (r >= 3 * nmin && r % 3 == 0) r /= 3;
+    while (r >= 2 * nmin && r % 2 == 0) r /= 2;
+    return r == nmin;
+}
+static int nearest_size(int N, int transform, int higher) {
+    const int nmin = min_fft_size(transform);
+    if (N < nmin) N = nmin;
+    const int d = higher ? nmin : -nmin;
+    N = higher ? nmin * ((N + nmin - 1) / nmin) : nmin * (N / nmin);
+    for (;; N += d)
+        if (is_valid_size(N, transform)) return N;
+}
+static int next_pow2(int N) {
+    unsigned v = (unsigned)N;
+    v--;
+    v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+    return (int)(v + 1);
+}
+static int is_pow2(int N) { return N && !(N & (N - 1)); }
+
+static void* aligned_malloc64(size_t nb) {  // src/pffft_common.c:12-22: 64-byte aligned, raw pointer kept at p[-1]
+    void* p0 = malloc(nb + 63 + sizeof(void*));
+    if (!p0) return nullptr;
+    uintptr_t p = ((uintptr_t)p0 + 63 + sizeof(void*)) & ~(uintptr_t)63;
+    ((void**)p)[-1] = p0;
+    return (void*)p;
+}
+static void aligned_free64(void* p) {
+    if (p) free(((void**)p)[-1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the plan ("PFFFT_Setup": src/pffft_priv_impl.h:1051-1060)
+// ------------------------------------------------------------------------------------------------
+enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1 };
+constexpr size_t LDS_MAX = 160 * 1024;
+
+struct Setup {
+    uint32_t magic;
+    int N, transform, is_double;
+    int n;           // complex length of the device transform
+    size_t vec_scalars;  // scalars per vector: N (real) / 2N (complex)
+    Kernel kernel;
+    GenericPlan gp;
+    int gthreads;
+    size_t glds;
+    // device state (lazy: creating a setup never touches the GPU)
+    std::mutex mu;        // guards the lazy device initialisation
+    std::mutex stage_mu;  // guards the staging buffers of the legacy host-pointer entries
+    bool dev_ready = false;
+    void* d_tw = nullptr;   // W_n^j, j < n
+    void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
+    void* d_stage[3] = {nullptr, nullptr, nullptr};  // staging for host-pointer legacy calls
+    size_t stage_bytes[3] = {0, 0, 0};
+};
+constexpr uint32_t MAGIC = 0x50464654u;  // "PFFT"
+
+static Setup* new_setup(int N, int transform, int is_double) {
+    // validation: src/pffft_priv_impl.h:1066-1078 and :1105-1109
+    if (N <= 0 || N > (1 << 26)) return nullptr;
+    if (transform != PFFFT_REAL && transform != PFFFT_COMPLEX) return nullptr;
+    const int mult = transform == PFFFT_REAL ? 2 * SIMD * SIMD : SIMD * SIMD;
+    if (N % mult) return nullptr;
+    {   // N / SIMD must factor into 2, 3, 5 (what decompose() + the product check enforce)
+        int r = N / SIMD;
+        for (int f : {2, 3, 5}) while (r % f == 0) r /= f;
+        if (r != 1) return nullptr;
+    }
+    Setup* s = new Setup();
+    s->magic = MAGIC;
+    s->N = N; s->transform = transform; s->is_double = is_double;
+    s->n = transform == PFFFT_REAL ? N / 2 : N;
+    s->vec_scalars = transform == PFFFT_REAL ? (size_t)N : 2 * (size_t)N;
+    // radix schedule for the in-place DIF kernel: 5s, 3s, then 4s, then at most one 2
+    GenericPlan& gp = s->gp;
+    memset(&gp, 0, sizeof gp);
+    gp.n = s->n; gp.is_real = transform == PFFFT_REAL;
+    int r = s->n, ns = 0;
+    while (r % 5 == 0) { gp.radix[ns++] = 5; r /= 5; }
+    while (r % 3 == 0) { gp.radix[ns++] = 3; r /= 3; }
+    while (r % 4 == 0) { gp.radix[ns++] = 4; r /= 4; }
+    if (r % 2 == 0) { gp.radix[ns++] = 2; r /= 2; }
+    gp.nstages = ns;
+    const size_t esz = is_double ? 16 : 8;
+    gp.G = s->n >= 2048 ? 1 : 2048 / s->n;
+    s->glds = (size_t)gp.G * s->n * esz;
+    int th = (int)(((size_t)gp.G * s->n / 8 + 63) / 64 * 64);
+    s->gthreads = th < 64 ? 64 : (th > 1024 ? 1024 : th);
+    s->kernel = K_GENERIC;
+    if (!is_double && transform == PFFFT_COMPLEX && N == 1024) s->kernel = K_C1024_F32;
+    return s;
+}
+
+static void destroy_setup(Setup* s) {
+    if (!s) return;
+    if (s->dev_ready) {
+        if (s->d_tw) (void)hipFree(s->d_tw);
+        if (s->d_twr) (void)hipFree(s->d_twr);
+    }
+    for (void* p : s->d_stage) if (p) (void)hipFree(p);
+    s->magic = 0;
+    delete s;
+}
+
+template <typename T>
+static int ensure_device(Setup* s) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->dev_ready) return 0;
+    if (s->glds > LDS_MAX) {
+        g_last_error = "pffft_hip: N too large for the LDS-resident kernels (multi-pass path not built yet)";
+        return (int)hipErrorInvalidValue;
+    }
+    const int n = s->n;
+    std::vector<cx<T>> tw(n);
+    for (int j = 0; j < n; ++j) {  // tables are generated in extended precision and rounded once
+        long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)n;
+        tw[j].x = (T)cosl(a); tw[j].y = (T)sinl(a);
+    }
+    PF_CHECK(hipMalloc(&s->d_tw, sizeof(cx<T>) * n));
+    PF_CHECK(hipMemcpy(s->d_tw, tw.data(), sizeof(cx<T>) * n, hipMemcpyHostToDevice));
+    if (s->transform == PFFFT_REAL) {
+        const int m = n / 2 + 1;
+        std::vector<cx<T>> twr(m);
+        for (int k = 0; k < m; ++k) {
+            long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)(2 * n);
+            twr[k].x = (T)cosl(a); twr[k].y = (T)sinl(a);
+        }
+        PF_CHECK(hipMalloc(&s->d_twr, sizeof(cx<T>) * m));
+        PF_CHECK(hipMemcpy(s->d_twr, twr.data(), sizeof(cx<T>) * m, hipMemcpyHostToDevice));
+    }
+    s->dev_ready = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <typename K>
+static int allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        PF_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+template <typename T>
+static int launch_generic(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    const GenericPlan& gp = s->gp;
+    const int in_internal = (dir == PFFFT_BACKWARD) && !ordered;
+    const int out_internal = (dir == PFFFT_FORWARD) && !ordered;
+    size_t passes = (batch + gp.G - 1) / gp.G;
+    size_t per_cu = LDS_MAX / (s->glds ? s->glds : 1);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    size_t grid = (size_t)num_cus() * per_cu;
+    if (grid > passes) grid = passes;
+    auto kf = fft_generic_kernel<T, FWD>;
+    auto kb = fft_generic_kernel<T, BWD>;
+    int rc = allow_big_lds(dir == PFFFT_FORWARD ? kf : kb, s->glds);
+    if (rc) return rc;
+    if (dir == PFFFT_FORWARD)
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(s->gthreads), s->glds, st, in, out, batch, gp, in_internal,
+                           out_internal, (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr);
+    else
+        hipLaunchKernelGGL(kb, dim3((unsigned)grid), dim3(s->gthreads), s->glds, st, in, out, batch, gp, in_internal,
+                           out_internal, (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int launch_c1024(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    const unsigned wgs_needed = (unsigned)((batch + C1024_WAVES - 1) / C1024_WAVES);
+    unsigned grid = (unsigned)num_cus() * 2;
+    if (grid > wgs_needed) grid = wgs_needed;
+    const dim3 blk(C1024_WAVES * 64);
+    const size_t lds = C1024_LDS_BYTES;
+    const cx<float>* tw = (const cx<float>*)s->d_tw;
+    const unsigned b = (unsigned)batch;
+#define PF_LAUNCH_C1024(D, I, O)                                                                      \
+    do {                                                                                              \
+        auto k = fft_c1024_f32_kernel<D, I, O>;                                                       \
+        int rc = allow_big_lds(k, lds);                                                               \
+        if (rc) return rc;                                                                            \
+        hipLaunchKernelGGL(k, dim3(grid), blk, lds, st, in, out, b, tw);                              \
+    } while (0)
+    if (dir == PFFFT_FORWARD) {
+        if (ordered) PF_LAUNCH_C1024(FWD, 0, 0); else PF_LAUNCH_C1024(FWD, 0, 1);
+    } else {
+        if (ordered) PF_LAUNCH_C1024(BWD, 0, 0); else PF_LAUNCH_C1024(BWD, 1, 0);
+    }
+#undef PF_LAUNCH_C1024
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    if (!s || s->magic != MAGIC || s->is_double != (sizeof(T) == 8)) {
+        g_last_error = "pffft_hip: bad setup handle";
+        return (int)hipErrorInvalidHandle;
+    }
+    if (batch == 0) return 0;
+    int rc = ensure_device<T>(s);
+    if (rc) return rc;
+    if constexpr (sizeof(T) == 4) {
+        if (s->kernel == K_C1024_F32 && g_variant != 1 && batch < (1ull << 32))
+            return launch_c1024(s, in, out, batch, dir, ordered, st);
+    }
+    return launch_generic<T>(s, in, out, batch, dir, ordered, st);
+}
+
+template <typename T>
+static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, hipStream_t st) {
+    if (!s || s->magic != MAGIC) return (int)hipErrorInvalidHandle;
+    if (batch == 0) return 0;
+    size_t total = batch * (size_t)(s->n / 2);
+    size_t grid = (total + 255) / 256;
+    if (grid > (size_t)num_cus() * 16) grid = (size_t)num_cus() * 16;
+    hipLaunchKernelGGL((zreorder_kernel<T>), dim3((unsigned)grid), dim3(256), 0, st, in, out, batch, s->n,
+                       (int)(s->transform == PFFFT_REAL), (int)(dir == PFFFT_FORWARD));
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, size_t batch, int accumulate,
+                           int b_broadcast, hipStream_t st) {
+    if (!s || s->magic != MAGIC) return (int)hipErrorInvalidHandle;
+    if (batch == 0) return 0;
+    size_t total = batch * (size_t)(s->n / 4);
+    size_t grid = (total + 255) / 256;
+    if (grid > (size_t)num_cus() * 16) grid = (size_t)num_cus() * 16;
+    const size_t vs = s->vec_scalars;
+    const int is_real = s->transform == PFFFT_REAL;
+    if (accumulate)
+        hipLaunchKernelGGL((zconvolve_kernel<T, 1>), dim3((unsigned)grid), dim3(256), 0, st, a, b, ab, batch, s->n,
+                           is_real, scaling, vs, b_broadcast ? (size_t)0 : vs);
+    else
+        hipLaunchKernelGGL((zconvolve_kernel<T, 0>), dim3((unsigned)grid), dim3(256), 0, st, a, b, ab, batch, s->n,
+                           is_real, scaling, vs, b_broadcast ? (size_t)0 : vs);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// legacy single-vector entries: host pointers are staged, device pointers are used in place
+// ------------------------------------------------------------------------------------------------
+static bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+static int stage_buf(Setup* s, int slot, size_t bytes, void** out) {
+    if (s->stage_bytes[slot] < bytes) {
+        if (s->d_stage[slot]) (void)hipFree(s->d_stage[slot]);
+        s->d_stage[slot] = nullptr; s->stage_bytes[slot] = 0;
+        PF_CHECK(hipMalloc(&s->d_stage[slot], bytes));
+        s->stage_bytes[slot] = bytes;
+    }
+    *out = s->d_stage[slot];
+    return 0;
+}
+
+// run `fn(d_in..., d_out)` with up to 3 inputs + 1 output vector of `bytes` bytes each
+template <typename T, typename F>
+static int legacy_run(Setup* s, const T* const* ins, int nin, T* out, bool out_is_inout, F&& fn) {
+    if (!s || s->magic != MAGIC || s->is_double != (sizeof(T) == 8)) {
+        g_last_error = "pffft_hip: bad setup handle";
+        return (int)hipErrorInvalidHandle;
+    }
+    const size_t bytes = s->vec_scalars * sizeof(T);
+    // the staging buffers belong to the setup; the mutex keeps concurrent callers correct
+    // (the reference allows a setup to be shared between threads, include/pffft/pffft.h:102-105)
+    std::lock_guard<std::mutex> lk(s->stage_mu);
+    const T* d_in[3] = {nullptr, nullptr, nullptr};
+    T* d_out = nullptr;
+    const bool out_dev = is_device_ptr(out);
+    int slot = 0;
+    if (out_dev) d_out = out;
+    else {
+        void* p; int rc = stage_buf(s, slot++, bytes, &p); if (rc) return rc;
+        d_out = (T*)p;
+        if (out_is_inout) PF_CHECK(hipMemcpy(d_out, out, bytes, hipMemcpyHostToDevice));
+    }
+    for (int i = 0; i < nin; ++i) {
+        if (ins[i] == out) { d_in[i] = d_out; if (!out_dev && !out_is_inout) PF_CHECK(hipMemcpy(d_out, out, bytes, hipMemcpyHostToDevice)); continue; }
+        bool dup = false;
+        for (int j = 0; j < i; ++j) if (ins[j] == ins[i]) { d_in[i] = d_in[j]; dup = true; break; }
+        if (dup) continue;
+        if (is_device_ptr(ins[i])) d_in[i] = ins[i];
+        else {
+            void* p; int rc = stage_buf(s, slot++, bytes, &p); if (rc) return rc;
+            PF_CHECK(hipMemcpy(p, ins[i], bytes, hipMemcpyHostToDevice));
+            d_in[i] = (const T*)p;
+        }
+    }
+    int rc = fn(d_in, d_out);
+    if (rc) return rc;
+    if (!out_dev) PF_CHECK(hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
+    else PF_CHECK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+template <typename T>
+static void legacy_transform(Setup* s, const T* in, T* out, int dir, int ordered, const char* name) {
+    const T* ins[1] = {in};
+    int rc = legacy_run<T>(s, ins, 1, out, false, [&](const T* const* di, T* dout) {
+        return transform_batch<T>(s, di[0], dout, 1, dir, ordered, nullptr);
+    });
+    if (rc) legacy_fatal(rc, name, out, s ? s->vec_scalars * sizeof(T) : 0, !is_device_ptr(out));
+}
+
+template <typename T>
+static void legacy_zreorder(Setup* s, const T* in, T* out, int dir, const char* name) {
+    const T* ins[1] = {in};
+    int rc = legacy_run<T>(s, ins, 1, out, false, [&](const T* const* di, T* dout) {
+        return zreorder_batch<T>(s, di[0], dout, 1, dir, nullptr);
+    });
+    if (rc) legacy_fatal(rc, name, out, s ? s->vec_scalars * sizeof(T) : 0, !is_device_ptr(out));
+}
+
+template <typename T>
+static void legacy_zconvolve(Setup* s, const T* a, const T* b, T* ab, T scaling, int accumulate, const char* name) {
+    const T* ins[2] = {a, b};
+    int rc = legacy_run<T>(s, ins, 2, ab, accumulate != 0, [&](const T* const* di, T* dout) {
+        return zconvolve_batch<T>(s, di[0], di[1], dout, scaling, 1, accumulate, 0, nullptr);
+    });
+    if (rc) legacy_fatal(rc, name, ab, s ? s->vec_scalars * sizeof(T) : 0, !is_device_ptr(ab));
+}
+
+// Layout self-test standing in for validate_pffft_simd_ex (src/pffft_priv_impl.h:1889-2225, which
+// unit-tests the SIMD macros): checks on the host that the internal-layout map used by the kernels
+// is a permutation with the documented fixed points.  Returns the number of errors.
+static int host_bin_of(int v, int l, int n, int is_real) {
+    int b = v >> 3, q = (v >> 1) & 3, t = 4 * b + l;
+    if (!is_real) return q * (n >> 2) + t;
+    switch (q) {
+        case 0: return t;
+        case 2: return (n >> 1) + t;
+        case 1: return t ? (n >> 1) - t : (n >> 2);
+        default: return t ? n - t : 3 * (n >> 2);
+    }
+}
+static int validate_layout(FILE* dbg) {
+    int errors = 0;
+    for (int is_real = 0; is_real < 2; ++is_real)
+        for (int n : {16, 32, 48, 80, 1024}) {
+            std::vector<int> seen(2 * n, 0);
+            for (int v = 0; v < n / 2; ++v)
+                for (int l = 0; l < 4; ++l) {
+                    int idx = 2 * host_bin_of(v, l, n, is_real) + (v & 1);
+                    if (idx < 0 || idx >= 2 * n || seen[idx]++) ++errors;
+                }
+            if (host_bin_of(0, 0, n, is_real) != 0) ++errors;
+            if (dbg) fprintf(dbg, "pffft_hip layout check n=%d real=%d: errors so far %d\n", n, is_real, errors);
+        }
+    return errors;
+}
+
+}  // namespace pf
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+struct PFFFT_Setup : pf::Setup {};
+struct PFFFTD_Setup : pf::Setup {};
+
+#define PF_EXPORT extern "C" __attribute__((visibility("default")))
+
+#define PF_DEFINE_API(PFX, SETUP, T, ISD, ARCHSTR)                                                                  \
+    PF_EXPORT SETUP* PFX##_new_setup(int N, pffft_transform_t tr) {                                                 \
+        return static_cast<SETUP*>(pf::new_setup(N, (int)tr, ISD));                                                 \
+    }                                                                                                               \
+    PF_EXPORT void PFX##_destroy_setup(SETUP* s) { pf::destroy_setup(s); }                                          \
+    PF_EXPORT void PFX##_transform(SETUP* s, const T* in, T* out, T* work, pffft_direction_t d) {                   \
+        (void)work; pf::legacy_transform<T>(s, in, out, (int)d, 0, #PFX "_transform");                              \
+    }                                                                                                               \
+    PF_EXPORT void PFX##_transform_ordered(SETUP* s, const T* in, T* out, T* work, pffft_direction_t d) {           \
+        (void)work; pf::legacy_transform<T>(s, in, out, (int)d, 1, #PFX "_transform_ordered");                      \
+    }                                                                                                               \
+    PF_EXPORT void PFX##_zreorder(SETUP* s, const T* in, T* out, pffft_direction_t d) {                             \
+        pf::legacy_zreorder<T>(s, in, out, (int)d, #PFX "_zreorder");                                               \
+    }                                                                                                               \
+    PF_EXPORT void PFX##_zconvolve_accumulate(SETUP* s, const T* a, const T* b, T* ab, T sc) {                      \
+        pf::legacy_zconvolve<T>(s, a, b, ab, sc, 1, #PFX "_zconvolve_accumulate");                                  \
+    }                                                                                                               \
+    PF_EXPORT void PFX##_zconvolve_no_accu(SETUP* s, const T* a, const T* b, T* ab, T sc) {                         \
+        pf::legacy_zconvolve<T>(s, a, b, ab, sc, 0, #PFX "_zconvolve_no_accu");                                     \
+    }                                                                                                               \
+    PF_EXPORT int PFX##_simd_size(void) { return pf::SIMD; }                                                        \
+    PF_EXPORT const char* PFX##_simd_arch(void) { return ARCHSTR; }                                                 \
+    PF_EXPORT int PFX##_min_fft_size(pffft_transform_t tr) { return pf::min_fft_size((int)tr); }                    \
+    PF_EXPORT int PFX##_is_valid_size(int N, pffft_transform_t tr) { return pf::is_valid_size(N, (int)tr); }        \
+    PF_EXPORT int PFX##_nearest_transform_size(int N, pffft_transform_t tr, int higher) {                           \
+        return pf::nearest_size(N, (int)tr, higher);                                                                \
+    }                                                                                                               \
+    PF_EXPORT int PFX##_next_power_of_two(int N) { return pf::next_pow2(N); }                                       \
+    PF_EXPORT int PFX##_is_power_of_two(int N) { return pf::is_pow2(N); }                                           \
+    PF_EXPORT void* PFX##_aligned_malloc(size_t nb) { return pf::aligned_malloc64(nb); }                            \
+    PF_EXPORT void PFX##_aligned_free(void* p) { pf::aligned_free64(p); }                                           \
+    PF_EXPORT int validate_##PFX##_simd_ex(void* dbg) { return pf::validate_layout((FILE*)dbg); }                   \
+    PF_EXPORT int validate_##PFX##_simd(void) { return pf::validate_layout(nullptr); }                              \
+    PF_EXPORT int PFX##_hip_transform_batch(SETUP* s, const T* in, T* out, size_t batch, pffft_direction_t d,       \
+                                            int ordered, void* stream) {                                            \
+        return pf::transform_batch<T>(s, in, out, batch, (int)d, ordered, (hipStream_t)stream);                     \
+    }                                                                                                               \
+    PF_EXPORT int PFX##_hip_zreorder_batch(SETUP* s, const T* in, T* out, size_t batch, pffft_direction_t d,        \
+                                           void* stream) {                                                          \
+        return pf::zreorder_batch<T>(s, in, out, batch, (int)d, (hipStream_t)stream);                               \
+    }                                                                                                               \
+    PF_EXPORT int PFX##_hip_zconvolve_batch(SETUP* s, const T* a, const T* b, T* ab, T sc, size_t batch,            \
+                                            int accumulate, int b_broadcast, void* stream) {                        \
+        return pf::zconvolve_batch<T>(s, a, b, ab, sc, batch, accumulate, b_broadcast, (hipStream_t)stream);        \
+    }
+
+PF_DEFINE_API(pffft, PFFFT_Setup, float, 0, "HIP-gfx950")
+PF_DEFINE_API(pffftd, PFFFTD_Setup, double, 1, "HIP-gfx950")
+
+PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
+    const pf::Setup* s = static_cast<const pf::Setup*>(setup);
+    if (!s || s->magic != pf::MAGIC) return "invalid";
+    if (pf::g_variant == 1) return "generic";
+    switch (s->kernel) {
+        case pf::K_C1024_F32: return "c1024_f32";
+        default: return "generic";
+    }
+}
+PF_EXPORT const char* pffft_hip_last_error(void) { return pf::g_last_error.c_str(); }
+PF_EXPORT int pffft_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+PF_EXPORT void pffft_hip_set_variant(int v) { pf::g_variant = v; }
+
+#include "pffastconv_impl.h"
