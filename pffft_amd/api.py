@@ -151,10 +151,10 @@ class Setup:
     (src/pffft_priv_impl.h:1066-1078,1105-1109)."""
 
     def __init__(self, N: int, transform: int, dtype=np.float32):
-        self.N, self.transform, self.dtype = int(N), int(transform), np.dtype(dtype)
+        self.N, self.transform_type, self.dtype = int(N), int(transform), np.dtype(dtype)
         self._pfx = _pfx(dtype)
         self._L = lib()
-        self.handle = getattr(self._L, f"{self._pfx}_new_setup")(self.N, self.transform)
+        self.handle = getattr(self._L, f"{self._pfx}_new_setup")(self.N, self.transform_type)
         if not self.handle:
             raise ValueError(f"pffft_new_setup({N}, {transform}) returned NULL")
         self.vec_scalars = self.N * (2 if transform == COMPLEX else 1)

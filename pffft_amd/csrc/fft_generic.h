@@ -51,7 +51,7 @@ __device__ __forceinline__ int pos_of(int k, const GenericPlan& p) {
 
 // Spectrum bin stored at slot l (0..3) of 4-scalar group v of one vector in the pffft-internal
 // layout (SIMD_SZ == 4).  Closed forms checked against the reference's own pffft_zreorder
-// (src/pffft_priv_impl.h:1158-1193) in tests/test_oracle_layout.py:
+// (src/pffft_priv_impl.h:1158-1193) in tests/test_oracle.py and tests/test_gpu_parity.py:
 //   complex: internal[32 b + 8 m + 4 p + l] = part p of X[m n/4 + 4 b + l]
 //   real   : internal[32 b + 8 q + 4 p + l] = part p of X[bin(q, t = 4 b + l)] with
 //            bin(0,t)=t, bin(2,t)=n/2+t, bin(1,t)= t ? n/2-t : n/4, bin(3,t)= t ? n-t : 3n/4

@@ -1,0 +1,138 @@
+"""CPU tests (-m "not gpu") of the drop-in boundary: the C-ABI library loads without a GPU, exports
+every symbol include/pffft_hip.h declares, and its host-only entries (size helpers, setup
+validation, aligned allocator) behave like the reference's (tests/test_fft_factors.c:36-61,
+tests/test_pffft.c:280-330, src/pffft_common.c:12-43).  No compute entry is called here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import pffft_amd as pa
+from conftest import ROOT
+from oracle import pffft_oracle as po
+
+
+@pytest.fixture(scope="module")
+def L():
+    from pffft_amd import build
+    build.build()
+    return pa.lib()
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "pffft_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b((?:pffftd?_|pffastconv_|validate_pffftd?_)\w+)\s*\(", txt)
+    return sorted(set(names))
+
+
+def test_every_declared_symbol_is_exported(L):
+    names = declared_symbols()
+    assert len(names) >= 53, names
+    out = subprocess.run(["nm", "-D", "--defined-only", pa.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
+    # the reference's exported set must be covered name for name
+    ref_syms = []
+    for pfx in ("pffft", "pffftd"):
+        ref_syms += [f"{pfx}_{s}" for s in (
+            "new_setup destroy_setup transform transform_ordered zreorder zconvolve_accumulate zconvolve_no_accu "
+            "simd_size simd_arch min_fft_size is_valid_size nearest_transform_size next_power_of_two "
+            "is_power_of_two aligned_malloc aligned_free").split()]
+        ref_syms += [f"validate_{pfx}_simd", f"validate_{pfx}_simd_ex"]
+    ref_syms += ["pffastconv_new_setup", "pffastconv_apply", "pffastconv_destroy_setup", "pffastconv_malloc",
+                 "pffastconv_free", "pffastconv_simd_size"]
+    assert not [s for s in ref_syms if s not in exported]
+    # internal helpers of the reference that are hidden there must not leak here either
+    assert "pffft_cplx_finalize" not in exported and "pffft_transform_internal" not in exported
+
+
+def test_introspection(L):
+    assert pa.simd_size() == 4 and pa.simd_size(np.float64) == 4  # selects the 4-lane internal layout
+    assert pa.simd_arch() == "HIP-gfx950"
+    assert L.pffastconv_simd_size() == 4
+    assert pa.min_fft_size(pa.REAL) == 32 and pa.min_fft_size(pa.COMPLEX) == 16
+    assert L.validate_pffft_simd() == 0 and L.validate_pffftd_simd() == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_accepted_sizes_match_reference_rules(L, dtype):
+    # tests/test_fft_factors.c:36-61: is_valid_size(N) <=> local 2/3/5 factorisation <=> new_setup(N) != NULL
+    for tr in (pa.REAL, pa.COMPLEX):
+        nmin = pa.min_fft_size(tr, dtype)
+        for N in range(nmin // 2, 12 * nmin + 1, nmin // 2):
+            assert pa.is_valid_size(N, tr, dtype) == po.is_valid_size(N, tr), (N, tr)
+            try:
+                s = pa.Setup(N, tr, dtype)
+                ok = True
+                s.close()
+            except ValueError:
+                ok = False
+            assert ok == po.new_setup_ok(N, tr), (N, tr)
+        for N in (1, 17, 100, 1000, 5000, 100000):
+            for higher in (False, True):
+                assert pa.nearest_transform_size(N, tr, higher, dtype) == po.nearest_transform_size(N, tr, higher)
+    for bad in (-1, 0, (1 << 26) + 32, 100, 33):
+        with pytest.raises(ValueError):
+            pa.Setup(bad, pa.COMPLEX, dtype)
+
+
+def test_power_of_two_helpers(L):
+    for pfx in ("pffft", "pffftd"):
+        npo2, ipo2 = getattr(L, pfx + "_next_power_of_two"), getattr(L, pfx + "_is_power_of_two")
+        for N in list(range(0, 70)) + [255, 256, 257, 1 << 20, (1 << 20) + 1]:
+            assert npo2(N) == po.next_power_of_two(N), N
+            assert bool(ipo2(N)) == po.is_power_of_two(N), N
+
+
+def test_aligned_allocator(L):
+    for pfx in ("pffft", "pffftd"):
+        m, f = getattr(L, pfx + "_aligned_malloc"), getattr(L, pfx + "_aligned_free")
+        ps = [m(n) for n in (1, 17, 4096, 1 << 20)]
+        assert all(p and p % 64 == 0 for p in ps)  # src/pffft_common.c:8: 64-byte alignment
+        for p in ps:
+            C.memset(p, 0xAB, 1)
+            f(p)
+        f(None)  # NULL-safe
+    L.pffastconv_malloc.restype = C.c_void_p
+    L.pffastconv_malloc.argtypes = [C.c_size_t]
+    L.pffastconv_free.argtypes = [C.c_void_p]
+    p = L.pffastconv_malloc(100)
+    assert p % 64 == 0
+    L.pffastconv_free(p)
+
+
+def test_fastconv_setup_rules(L):
+    # src/pffastconv.c:62-80: Nfft = max(2*next_pow2(filterLen-1), 2*simd^2, next_pow2(blockLen)); CPLX_FILTER -> NULL
+    h = np.ones(4096, np.float32)
+    fc = pa.FastConv(h, 0, 0)
+    assert fc.block_len == 8192
+    fc.close()
+    fc = pa.FastConv(np.ones(5, np.float32), 0, 0)
+    assert fc.block_len == 32
+    fc.close()
+    fc = pa.FastConv(np.ones(100, np.float32), 1000, 0)
+    assert fc.block_len == 1024
+    fc.close()
+    with pytest.raises(ValueError):
+        pa.FastConv(h, 0, 2)
+    for taps, blk, flags in ((129, 0, 0), (64, 512, 0), (33, 0, 17)):
+        s = po.fastconv_setup(np.ones(taps, np.float32), blk, flags)
+        fc = pa.FastConv(np.ones(taps, np.float32), blk, flags)
+        assert fc.block_len == s["blockLen"]
+        fc.close()
+
+
+def test_no_oracle_in_product():
+    """The shipped package must not import or link the oracle."""
+    for root, _, files in os.walk(os.path.join(ROOT, "pffft_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r"(from|import)\s+oracle|#include\s+\"[^\"]*oracle|libpffft_ref|dlopen", txt), f
+    out = subprocess.run(["ldd", pa.lib_path()], capture_output=True, text=True).stdout
+    assert "pffft_ref" not in out and "fftpack" not in out

@@ -1,0 +1,307 @@
+"""GPU parity tests (-m gpu): the HIP path, reached through the C ABI (libpffft_hip.so), against
+  * the real reference compiled from its own sources (oracle/_ref, shipped prebuilt to the GPU box),
+  * the committed golden fixtures generated from it (tests/golden),
+  * the numpy restatement (oracle/pffft_oracle.py),
+on seeded inputs at small sizes, and through size-independent properties at BASELINE's full sizes.
+Bars (BASELINE.json north_star): 1e-5 relative float, 1e-12 double (see conftest.tol_for for the one
+documented exception where the reference's own double build is only ~1e-8 accurate)."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, gkey, relerr, tol_for
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import pffft_amd as pa  # noqa: E402
+from oracle import pffft_oracle as po  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available() or pa.device_count() < 1:
+        pytest.fail("GPU tests need a HIP device: the product has no CPU fallback")  # fail loudly, never skip silently
+    torch.cuda.set_device(0)
+
+
+def _dt(dt):
+    return np.float32 if dt == "f32" else np.float64
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("dt,tr,N", GOLDEN_CASES)
+def test_against_golden(golden, dt, tr, N):
+    k, dtype, tol = gkey(dt, tr, N), _dt(dt), tol_for(dt, N)
+    s = pa.Setup(N, tr, dtype)
+    x = golden[k + "_x"]
+    for ordered, name in ((True, "ordered"), (False, "unordered")):
+        fwd = s.transform_batch(_dev(x[None]), None, pa.FORWARD, ordered).cpu().numpy()[0]
+        assert relerr(fwd, golden[k + "_fwd_" + name]) <= tol, (name, "fwd")
+        bwd = s.transform_batch(_dev(golden[k + "_fwd_" + name][None]), None, pa.BACKWARD, ordered).cpu().numpy()[0]
+        assert relerr(bwd, golden[k + "_bwd_" + name]) <= tol, (name, "bwd")
+    if N <= 1024:
+        fu = golden[k + "_fwd_unordered"]
+        zr = s.zreorder_batch(_dev(fu[None]), None, pa.FORWARD).cpu().numpy()[0]
+        assert np.array_equal(zr, fu[golden[k + "_perm"]])  # pure permutation: bit exact
+        back = s.zreorder_batch(_dev(zr[None]), None, pa.BACKWARD).cpu().numpy()[0]
+        assert np.array_equal(back, fu)
+        for acc, nm in ((True, "_zc_accumulate"), (False, "_zc_no_accu")):
+            ab = _dev(golden[k + "_zc_acc0"][None].copy())
+            s.zconvolve_batch(_dev(fu[None]), _dev(golden[k + "_zc_b"][None]), ab, 0.25, acc)
+            assert relerr(ab.cpu().numpy()[0], golden[k + nm]) <= (1e-6 if dt == "f32" else 1e-14)
+    s.close()
+
+
+# ------------------------------------------------------------------ the real reference, more sizes, batches
+SIZES_C = [16, 32, 48, 64, 80, 96, 128, 160, 192, 240, 256, 288, 384, 480, 512, 576, 640, 800, 864, 1024, 2048,
+           2592, 4000, 4096, 12000, 16384]
+SIZES_R = [32, 64, 96, 128, 160, 192, 256, 288, 384, 480, 512, 576, 640, 800, 864, 1024, 2048, 4000, 4096, 8192,
+           12000, 16384, 36864]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("tr", [0, 1])
+def test_against_reference_all_sizes(ref, dt, tr):
+    dtype = _dt(dt)
+    rng = np.random.default_rng(11 + tr)
+    sizes = SIZES_C if tr == 1 else SIZES_R
+    if dt == "f64":
+        sizes = [n for n in sizes if n * (2 if tr == 1 else 1) * 8 <= 160 * 1024]  # LDS-resident limit
+    for N in sizes:
+        rs = ref.setup(N, tr, dtype)
+        s = pa.Setup(N, tr, dtype)
+        batch = 5  # odd, not a multiple of the per-workgroup transform count
+        x = rng.uniform(-1, 1, (batch, s.vec_scalars)).astype(dtype)
+        tol = tol_for(dt, N)
+        for ordered in (False, True):
+            want = rs.batch(x, 0, ordered)
+            got = s.transform_batch(_dev(x), None, pa.FORWARD, ordered).cpu().numpy()
+            assert relerr(got, want) <= tol, (dt, tr, N, ordered, "fwd")
+            wb = rs.batch(want, 1, ordered)
+            gb = s.transform_batch(_dev(want), None, pa.BACKWARD, ordered).cpu().numpy()
+            assert relerr(gb, wb) <= tol, (dt, tr, N, ordered, "bwd")
+        # in-place == out-of-place bit-exactly (benchmarks/bench_pffft.c:343-349)
+        buf = _dev(x)
+        oop = s.transform_batch(buf, None, pa.FORWARD, False).cpu().numpy()
+        s.transform_batch(buf, buf, pa.FORWARD, False)
+        assert np.array_equal(buf.cpu().numpy(), oop)
+        s.close(); rs.close()
+
+
+@pytest.mark.parametrize("dt,tr,N", [("f64", 1, 96), ("f64", 1, 4000), ("f64", 0, 96), ("f64", 0, 4000),
+                                     ("f64", 1, 1024), ("f32", 1, 1024), ("f32", 0, 16384)])
+def test_against_float64_dft(dt, tr, N):
+    """Independent truth: numpy float64 FFT.  This is where the 1e-12 double bar holds for radix-3/5 sizes."""
+    dtype = _dt(dt)
+    rng = np.random.default_rng(5)
+    s = pa.Setup(N, tr, dtype)
+    x = rng.uniform(-1, 1, (2, s.vec_scalars)).astype(dtype)
+    got = s.transform_batch(_dev(x), None, pa.FORWARD, True).cpu().numpy().astype(np.float64)
+    for i in range(2):
+        if tr == 1:
+            want = np.fft.fft(x[i, 0::2].astype(np.float64) + 1j * x[i, 1::2])
+            g = got[i, 0::2] + 1j * got[i, 1::2]
+        else:
+            full = np.fft.rfft(x[i].astype(np.float64))
+            want = full[:-1].copy(); want[0] = full[0].real + 1j * full[-1].real
+            g = got[i, 0::2] + 1j * got[i, 1::2]
+        assert np.abs(g - want).max() / np.abs(want).max() <= (1e-12 if dt == "f64" else 1e-5 / 4)
+    s.close()
+
+
+def test_numpy_restatement_agrees():
+    rng = np.random.default_rng(3)
+    for N, tr in ((1024, 1), (64, 0), (480, 0), (2592, 1)):
+        s = pa.Setup(N, tr)
+        x = rng.uniform(-1, 1, s.vec_scalars).astype(np.float32)
+        got = s.transform_batch(_dev(x[None]), None, pa.FORWARD, False).cpu().numpy()[0]
+        assert relerr(got, po.transform(x, N, tr, po.FORWARD, False)) <= 1e-5
+        s.close()
+
+
+# ------------------------------------------------------------------ legacy single-vector entries (host pointers)
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_legacy_host_pointer_api(ref, dt):
+    dtype = _dt(dt)
+    rng = np.random.default_rng(21)
+    for N, tr in ((64, 0), (1024, 1), (96, 1), (1024, 0)):
+        rs, s = ref.setup(N, tr, dtype), pa.Setup(N, tr, dtype)
+        tol = tol_for(dt, N)
+        x = rng.uniform(-1, 1, s.vec_scalars).astype(dtype)
+        fu = s.transform(x, pa.FORWARD)
+        fo = s.transform_ordered(x, pa.FORWARD)
+        assert relerr(fu, rs.transform_unordered(x, 0)) <= tol
+        assert relerr(fo, rs.transform_ordered(x, 0)) <= tol
+        assert np.array_equal(s.zreorder(fu, pa.FORWARD), fo)       # transform_ordered == transform + zreorder
+        assert relerr(s.transform(fu, pa.BACKWARD) / N, x) <= 20 * tol
+        # aliasing: input == output (include/pffft/pffft.h:157)
+        buf = pa.api._aligned_empty(s.vec_scalars, dtype); buf[:] = x
+        s.transform_inplace(buf, pa.FORWARD, ordered=False)
+        assert np.array_equal(buf, fu)
+        # zconvolve with all three operands aliased (include/pffft/pffft.h:194)
+        ab = s.zconvolve(fu, fu, np.zeros_like(fu), 0.5, accumulate=True)
+        assert relerr(ab, rs.zconvolve(fu, fu, np.zeros_like(fu), 0.5, True)) <= 10 * tol
+        s.close(); rs.close()
+
+
+# ------------------------------------------------------------------ reference's own generative checks on the HIP path
+@pytest.mark.parametrize("N", [32, 64, 1024, 4096, 16384])
+@pytest.mark.parametrize("cplx", [0, 1])
+def test_single_tone(N, cplx):
+    """tests/test_pffft.c:109-247 — dynamic range >= 140 dB, magnitude error <= 1e-6*N-ish, round trip."""
+    if cplx == 0 and N < 32:
+        return
+    s = pa.Setup(N, pa.COMPLEX if cplx else pa.REAL)
+    n = np.arange(N)
+    for kk in (0, N // 16, 5 * N // 16):
+        amp, phi0 = 1.1, np.pi / 8
+        if cplx:
+            z = amp * np.exp(1j * (2 * np.pi * kk * n / N + phi0))
+            x = np.empty(2 * N, np.float32); x[0::2], x[1::2] = z.real, z.imag
+            expected = amp * N
+        else:
+            x = (amp * np.cos(2 * np.pi * kk * n / N + phi0)).astype(np.float32)
+            expected = amp * np.cos(phi0) * N if kk == 0 else amp * N / 2
+        X = s.transform_batch(_dev(x[None]), None, pa.FORWARD, True).cpu().numpy()[0].astype(np.float64)
+        P = X[0::2] ** 2 + X[1::2] ** 2
+        if not cplx and kk == 0:
+            P[0] = X[0] ** 2
+        others = np.delete(P, kk)
+        assert 10 * np.log10(P[kk] / max(others.max(), 1e-300)) >= 140.0   # tests/test_pffft.c:57-61
+        assert abs(np.sqrt(P[kk]) / abs(expected) - 1) <= 1e-6 * 4          # :67,207-213
+        back = s.transform_batch(_dev(X.astype(np.float32)[None]), None, pa.BACKWARD, True).cpu().numpy()[0]
+        assert np.sum((back / N - x) ** 2) <= N * 1e-7                     # :229-243
+    s.close()
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs)
+def _hash_uniform(shape, seed, device):
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    return torch.rand(shape, device=device, generator=g) * 2 - 1
+
+
+def test_c2_full_batch_properties(ref):
+    """BASELINE configs[1]: N=1024 complex float, batch 2^20 (8 GiB in / 8 GiB out)."""
+    N, B = 1024, 1 << 20
+    s = pa.Setup(N, pa.COMPLEX)
+    assert pa.kernel_name(s) == "c1024_f32"
+    x = _hash_uniform((B, 2 * N), 2, "cuda")
+    y = s.transform_batch(x, None, pa.FORWARD, False)
+    # (1) sampled transforms against the reference
+    idx = torch.tensor([0, 1, 7, 8, 63, 64, 4095, 4096, B // 2, B - 2, B - 1] + list(range(1000, 300000, 9973)))
+    rs = ref.setup(N, 1)
+    assert relerr(y[idx.cuda()].cpu().numpy(), rs.batch(x[idx.cuda()].cpu().numpy(), 0, False)) <= 1e-5
+    # (2) Parseval per transform (layout independent): sum |X|^2 = N sum |x|^2
+    ex = (x.double() ** 2).sum(dim=1); ey = (y.double() ** 2).sum(dim=1)
+    assert float(((ey - N * ex).abs() / (N * ex)).max()) <= 1e-5
+    # (3) X[0] (internal index 0 / 4) = sum of the inputs
+    assert float((y[:, 0].double() - x[:, 0::2].double().sum(1)).abs().max()) <= 1e-3
+    assert float((y[:, 4].double() - x[:, 1::2].double().sum(1)).abs().max()) <= 1e-3
+    # (4) round trip through the inverse, in place
+    s.transform_batch(y, y, pa.BACKWARD, False)
+    assert float((y / N - x).abs().max()) <= 2e-6
+    # (5) ordered == zreorder(unordered), bit exact, on a slice
+    sl = x[: 1 << 14]
+    yo = s.transform_batch(sl, None, pa.FORWARD, True)
+    yu = s.transform_batch(sl, None, pa.FORWARD, False)
+    assert torch.equal(s.zreorder_batch(yu, None, pa.FORWARD), yo)
+    del x, y
+    torch.cuda.empty_cache()
+    s.close(); rs.close()
+
+
+def test_c3_full_batch_properties(ref):
+    """BASELINE configs[2]: N=16384 real float forward, batch 2^16 (4 GiB)."""
+    N, B = 16384, 1 << 16
+    s = pa.Setup(N, pa.REAL)
+    x = _hash_uniform((B, N), 3, "cuda")
+    y = s.transform_batch(x, None, pa.FORWARD, False)
+    idx = torch.tensor([0, 1, B // 3, B - 1]).cuda()
+    rs = ref.setup(N, 0)
+    assert relerr(y[idx].cpu().numpy(), rs.batch(x[idx].cpu().numpy(), 0, False)) <= 1e-5
+    # Parseval for the half spectrum: 2*sum|X_k|^2 - DC^2 - Nyq^2 = N sum x^2 (DC at internal 0, Nyquist at 4)
+    ex = (x.double() ** 2).sum(1)
+    ey = 2 * (y.double() ** 2).sum(1) - y[:, 0].double() ** 2 - y[:, 4].double() ** 2
+    assert float(((ey - N * ex).abs() / (N * ex)).max()) <= 1e-5
+    s.transform_batch(y, y, pa.BACKWARD, False)
+    assert float((y / N - x).abs().max()) <= 5e-6
+    del x, y
+    torch.cuda.empty_cache()
+    s.close(); rs.close()
+
+
+def test_c5_double_properties(ref):
+    """BASELINE configs[4] per-GPU shape, reduced batch for the test: N=1024 complex double."""
+    N, B = 1024, 1 << 16
+    s = pa.Setup(N, pa.COMPLEX, np.float64)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    x = torch.rand((B, 2 * N), device="cuda", generator=g, dtype=torch.float64) * 2 - 1
+    y = s.transform_batch(x, None, pa.FORWARD, False)
+    idx = torch.tensor([0, 1, B // 2, B - 1]).cuda()
+    rs = ref.setup(N, 1, np.float64)
+    assert relerr(y[idx].cpu().numpy(), rs.batch(x[idx].cpu().numpy(), 0, False)) <= 1e-12
+    s.transform_batch(y, y, pa.BACKWARD, False)
+    assert float((y / N - x).abs().max()) <= 1e-13
+    s.close(); rs.close()
+
+
+def test_linearity_and_edge_batches():
+    N = 1024
+    s = pa.Setup(N, pa.COMPLEX)
+    a = _hash_uniform((37, 2 * N), 7, "cuda"); b = _hash_uniform((37, 2 * N), 8, "cuda")
+    fa, fb = s.transform_batch(a, None, 0, False), s.transform_batch(b, None, 0, False)
+    fab = s.transform_batch(2 * a - 3 * b, None, 0, False)
+    assert float((fab - (2 * fa - 3 * fb)).abs().max() / fab.abs().max()) <= 1e-5
+    # batch sizes around the waves-per-workgroup / grid boundaries, and the empty batch
+    for B in (0, 1, 7, 8, 9, 4095, 4097):
+        x = _hash_uniform((B, 2 * N), 9, "cuda")
+        y = s.transform_batch(x, None, 0, False)
+        if B:
+            assert torch.equal(y[-1:], s.transform_batch(x[-1:].contiguous(), None, 0, False))
+    s.close()
+
+
+# ------------------------------------------------------------------ fast convolution
+@pytest.mark.parametrize("name", ["ramp", "rand", "cplx2", "cplx1", "corr"])
+@pytest.mark.parametrize("flush", [0, 1])
+def test_fastconv_golden(golden, name, flush):
+    k = f"fc_{name}_flush{flush}"
+    L, taps, blk, flags, fl, n, bl = [int(v) for v in golden[k + "_meta"]]
+    fc = pa.FastConv(golden[k + "_h"], blk, flags)
+    assert fc.block_len == bl
+    y, produced = fc.apply(golden[k + "_x"], bool(flush))
+    assert produced == n
+    want = golden[k + "_y"]
+    if want.size:
+        lim = (want.max() - want.min()) / 1e5   # the reference test's own limit, tests/test_pffastconv.c:685
+        assert np.abs(y - want).max() <= lim
+    yd, nd = fc.apply(_dev(golden[k + "_x"]), bool(flush))
+    assert nd == n and (not want.size or np.abs(yd.cpu().numpy() - want).max() <= lim)
+    fc.close()
+
+
+def test_c4_fir_config(ref):
+    """BASELINE configs[3]: signal 2^20, 4096 taps, overlap-save with Nfft 8192 (255 blocks)."""
+    L, taps = 1 << 20, 4096
+    rng = np.random.default_rng(4)
+    h = rng.uniform(-1, 1, taps).astype(np.float32)
+    for name, x in (("uniform", rng.uniform(-1, 1, L).astype(np.float32)),
+                    ("ramp", (np.arange(L) % 4093).astype(np.float32))):   # tests/test_pffastconv.c:539
+        if name == "ramp":
+            h = np.array([(-1.0, 1.0, 0.5)[j % 3] for j in range(taps)], dtype=np.float32)
+        yw, nw, bl = ref.fastconv(x, h, 0, 0, 1)
+        fc = pa.FastConv(h, 0, 0)
+        assert fc.block_len == bl == 8192
+        y, n = fc.apply(_dev(x), True)
+        assert n == nw == L - taps + 1
+        lim = (yw.max() - yw.min()) / 1e5
+        assert np.abs(y.cpu().numpy() - yw).max() <= lim
+        # and the naive FIR truth on a window (tests/test_pffastconv.c:175-213)
+        w = slice(12345, 12345 + 3000)
+        naive = np.convolve(x[w.start: w.stop + taps - 1].astype(np.float64), h.astype(np.float64), mode="valid")
+        assert np.abs(y.cpu().numpy()[w] - naive).max() <= lim
+        fc.close()
