@@ -38,6 +38,14 @@ def lib():
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing — build it with `python -m pffft_amd.build` "
                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7 and hands us its streams
+    # and device pointers, so when torch is installed it must be loaded FIRST — the dynamic loader then
+    # binds libpffft_hip.so's NEEDED libamdhip64.so.7 to that same instance (matching SONAME).  Loading
+    # in the other order gives two runtimes in one process; the second one finds no device.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(p, mode=getattr(os, "RTLD_LOCAL", 0))
     for pfx, ct in (("pffft", C.c_float), ("pffftd", C.c_double)):
         g = lambda n: getattr(L, f"{pfx}_{n}")

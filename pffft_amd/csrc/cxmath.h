@@ -22,13 +22,21 @@ template <typename T> __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> 
 template <typename T> __device__ __forceinline__ cx<T> operator*(cx<T> a, T s) { return mk<T>(a.x * s, a.y * s); }
 template <typename T> __device__ __forceinline__ cx<T> conj(cx<T> a) { return mk<T>(a.x, -a.y); }
 
+// The library is compiled with -ffp-contract=off and every fused multiply-add is written out, so
+// that the arithmetic of a butterfly is fixed by the source: all template instantiations of a kernel
+// (ordered / unordered, in place / out of place) then produce bit-identical spectra, which is what
+// pffft guarantees between pffft_transform_ordered and pffft_transform + pffft_zreorder
+// (same arithmetic, src/pffft_priv_impl.h:1497-1498) and what benchmarks/bench_pffft.c:343-349 asserts.
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // a * w
 template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> w) {
-    return mk<T>(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+    return mk<T>(fma_(a.x, w.x, -(a.y * w.y)), fma_(a.x, w.y, a.y * w.x));
 }
 // a * conj(w)
 template <typename T> __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> w) {
-    return mk<T>(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+    return mk<T>(fma_(a.x, w.x, a.y * w.y), fma_(a.y, w.x, -(a.x * w.y)));
 }
 // a * w for the forward transform, a * conj(w) for the backward one (table holds exp(-i*theta))
 template <int DIR, typename T> __device__ __forceinline__ cx<T> twmul(cx<T> a, cx<T> w) {
@@ -46,7 +54,7 @@ template <int DIR, typename T> __device__ __forceinline__ void dft2(cx<T>& a0, c
 template <int DIR, typename T> __device__ __forceinline__ void dft3(cx<T>& a0, cx<T>& a1, cx<T>& a2) {
     const T s3 = (T)0.86602540378443864676372317075294L;  // sin(2*pi/3)
     cx<T> t1 = a1 + a2;
-    cx<T> m = mk<T>(a0.x - (T)0.5 * t1.x, a0.y - (T)0.5 * t1.y);
+    cx<T> m = mk<T>(fma_((T)-0.5, t1.x, a0.x), fma_((T)-0.5, t1.y, a0.y));
     cx<T> d = rot<DIR>((a1 - a2) * s3);  // (-/+ i) * sin * (a1 - a2)
     a0 = a0 + t1; a1 = m + d; a2 = m - d;
 }
@@ -64,10 +72,10 @@ __device__ __forceinline__ void dft5(cx<T>& a0, cx<T>& a1, cx<T>& a2, cx<T>& a3,
     const T s1 = (T)0.95105651629515357211643933337938L;   // sin(2*pi/5)
     const T s2 = (T)0.58778525229247312916870595463907L;   // sin(4*pi/5)
     cx<T> p1 = a1 + a4, m1 = a1 - a4, p2 = a2 + a3, m2 = a2 - a3;
-    cx<T> u1 = mk<T>(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
-    cx<T> u2 = mk<T>(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
-    cx<T> v1 = rot<DIR>(mk<T>(s1 * m1.x + s2 * m2.x, s1 * m1.y + s2 * m2.y));
-    cx<T> v2 = rot<DIR>(mk<T>(s2 * m1.x - s1 * m2.x, s2 * m1.y - s1 * m2.y));
+    cx<T> u1 = mk<T>(fma_(c2, p2.x, fma_(c1, p1.x, a0.x)), fma_(c2, p2.y, fma_(c1, p1.y, a0.y)));
+    cx<T> u2 = mk<T>(fma_(c1, p2.x, fma_(c2, p1.x, a0.x)), fma_(c1, p2.y, fma_(c2, p1.y, a0.y)));
+    cx<T> v1 = rot<DIR>(mk<T>(fma_(s2, m2.x, s1 * m1.x), fma_(s2, m2.y, s1 * m1.y)));
+    cx<T> v2 = rot<DIR>(mk<T>(fma_(-s1, m2.x, s2 * m1.x), fma_(-s1, m2.y, s2 * m1.y)));
     a0 = a0 + p1 + p2; a1 = u1 + v1; a4 = u1 - v1; a2 = u2 + v2; a3 = u2 - v2;
 }
 
