@@ -30,7 +30,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-ffp-contract=off", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-fvisibility=hidden", "-ffp-contract=off", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -14,7 +14,7 @@ namespace pf {
 constexpr int FWD = 0;  // PFFFT_FORWARD  (include/pffft/pffft.h:112) : exp(-2*pi*i*nk/N)
 constexpr int BWD = 1;  // PFFFT_BACKWARD                            : exp(+2*pi*i*nk/N), unscaled
 
-template <typename T> struct cx { T x, y; };
+template <typename T> struct alignas(2 * sizeof(T)) cx { T x, y; };
 
 template <typename T> __device__ __forceinline__ cx<T> mk(T x, T y) { cx<T> r; r.x = x; r.y = y; return r; }
 template <typename T> __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }

@@ -14,12 +14,19 @@
 //   S3     2 radix-8 butterflies over c  -> X[2L + e + 128 kc], kc = 0..7
 //   store  canonical: float4 (X[2L+128kc], X[2L+1+128kc]) at 1 KiB stride   (1 KiB / wave-instr)
 //          internal : X3 exchange through split re/im planes so that lane L, step s stores the
-//                     4-scalar group v = 64 s + L of the pffft layout (cxmath/bin_of) — again 1 KiB / instr.
+//                     4-scalar group v = 64 s + L of the pffft layout (fft_generic.h bin_of) — again 1 KiB / instr.
 // Backward = conjugated twiddles and the mirror-image X0 exchange when the input is in internal layout.
 //
-// LDS: 8 KiB twiddle table W1024^j per workgroup + 8960 B per wave.  Row strides (136 complex) and
+// Work distribution (the part that decides the HBM rate, tools/membench.hip): persistent workgroups of
+// 8 waves pull the next group of 8 consecutive transforms from an atomic counter, so the whole chip
+// sweeps the batch IN ORDER through a window of a few MiB (DRAM-page friendly; a copy with this
+// pattern reaches 6.9 TB/s where a static grid-stride assignment of the same chunks reaches 5.3),
+// and every wave issues the loads of its NEXT transform before it finishes the current one.
+//
+// LDS: 8960 B per wave (exchange images only; twiddles live in registers).  Row strides (136 complex) and
 // the X2 pair swizzle / X3 plane paddings come from tools/lds_sim.py searches (bank-conflict free
-// except the X2 b128 read, 2x).  No barriers in the loop: a wave only talks to itself.
+// except the X2 b128 read, 2x).  A wave only talks to itself through LDS; the one __syncthreads per
+// iteration only publishes the next work index.
 #pragma once
 #include "cxmath.h"
 
@@ -29,7 +36,7 @@ constexpr int C1024_WAVES = 8;                 // waves per workgroup
 constexpr int C1024_S1 = 136;                  // complex row stride of the X1/X2 images
 constexpr int C1024_PLANE = 1120;              // floats per re/im plane of the X0/X3 image
 constexpr int C1024_WAVE_BYTES = 2 * C1024_PLANE * 4;  // 8960 >= 8*136*8 = 8704
-constexpr int C1024_LDS_BYTES = 8192 + C1024_WAVES * C1024_WAVE_BYTES;
+constexpr int C1024_LDS_BYTES = C1024_WAVES * C1024_WAVE_BYTES + 16;
 
 __device__ __forceinline__ int c1024_plane_addr(int part, int k) {  // float index inside the wave image
     return part * C1024_PLANE + k + 16 * (k >> 8);
@@ -40,142 +47,224 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int DIR, int IN_INTERNAL, int OUT_INTERNAL>
-__global__ void __launch_bounds__(C1024_WAVES * 64, 4)
-fft_c1024_f32_kernel(const float* in, float* out, unsigned batch, const cx<float>* __restrict__ twg) {
+typedef vec4<float> C1024V4;
+
+__device__ __forceinline__ void c1024_load(C1024V4 (&raw)[8], const float* in, size_t t, int L) {
+    const C1024V4* src = reinterpret_cast<const C1024V4*>(in) + t * 512 + L;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j] = __builtin_nontemporal_load(src + 64 * j);
+}
+
+// part A: consume the 8 loaded float4, S1, write the X1 image.  After it `raw` is dead.
+template <int DIR, int IN_INTERNAL>
+__device__ __forceinline__ void c1024_part_a(const C1024V4 (&raw)[8], cx<float>* wl, float* wf,
+                                             const cx<float> (&w1)[7][2], int L) {
     typedef cx<float> C;
-    typedef vec4<float> V4;
+    typedef C1024V4 V4;
+    C a[8][2];
+    if (!IN_INTERNAL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[j][0] = mk<float>(raw[j].x, raw[j].y);
+            a[j][1] = mk<float>(raw[j].z, raw[j].w);
+        }
+    } else {
+        // X0: the internal layout arrives in linear order; scatter into re/im planes, read back canonical
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            int k0 = 256 * ((L >> 1) & 3) + 4 * (8 * s + (L >> 3));
+            *reinterpret_cast<V4*>(wf + c1024_plane_addr(L & 1, k0)) = raw[s];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int k = 128 * j + 2 * L;
+            vec2<float> re = *reinterpret_cast<const vec2<float>*>(wf + c1024_plane_addr(0, k));
+            vec2<float> im = *reinterpret_cast<const vec2<float>*>(wf + c1024_plane_addr(1, k));
+            a[j][0] = mk<float>(re.x, im.x);
+            a[j][1] = mk<float>(re.y, im.y);
+        }
+        wave_lds_fence();
+    }
+    // ---- S1: radix-8 over j, twiddle W1024^(k1 * r) ----
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        C b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = a[j][e];
+        dft8<DIR>(b);
+        a[0][e] = b[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) a[k1][e] = twmul<DIR>(b[k1], w1[k1 - 1][e]);
+    }
+    // ---- X1 write ----
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+        V4 v; v.x = a[k1][0].x; v.y = a[k1][0].y; v.z = a[k1][1].x; v.w = a[k1][1].y;
+        *reinterpret_cast<V4*>(wl + k1 * C1024_S1 + 2 * L) = v;
+    }
+    wave_lds_fence();
+}
+
+// part B: X1 read, S2, X2, S3, store
+template <int DIR, int OUT_INTERNAL>
+__device__ __forceinline__ void c1024_part_b(float* out, size_t t, cx<float>* wl, float* wf,
+                                             const cx<float> (&w2)[15], int L) {
+    typedef cx<float> C;
+    typedef C1024V4 V4;
+    V4* dst = reinterpret_cast<V4*>(out) + t * 512 + L;
+    C m[16];
+    {
+        const C* rd = wl + (L >> 3) * C1024_S1 + (L & 7);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) m[q] = rd[8 * q];
+    }
+    wave_lds_fence();
+    // ---- S2: radix-16 over a, twiddle W128^(c * ka) = W1024^(8 c ka) ----
+    dft16<DIR>(m);
+#pragma unroll
+    for (int ka = 1; ka < 16; ++ka) m[ka] = twmul<DIR>(m[ka], w2[ka - 1]);
+    // ---- X2: image (k1, ka, c) at k1*S1 + 8 ka + 2*((c>>1) ^ (ka&3)) + (c&1) ----
+    {
+        const int k1 = L >> 3, c = L & 7;
+#pragma unroll
+        for (int ka = 0; ka < 16; ++ka)
+            wl[k1 * C1024_S1 + 8 * ka + 2 * ((c >> 1) ^ (ka & 3)) + (c & 1)] = m[ka];
+    }
+    wave_lds_fence();
+    C a[8][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int k1 = 2 * (L & 3) + e, ka = L >> 2;
+        const C* rd = wl + k1 * C1024_S1 + 8 * ka;
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+            V4 v = *reinterpret_cast<const V4*>(rd + 2 * (cp ^ (ka & 3)));
+            a[2 * cp][e] = mk<float>(v.x, v.y);
+            a[2 * cp + 1][e] = mk<float>(v.z, v.w);
+        }
+    }
+    // ---- S3: radix-8 over c -> X[2L + e + 128 kc] ----
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        C b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b[q] = a[q][e];
+        dft8<DIR>(b);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q][e] = b[q];
+    }
+    if (!OUT_INTERNAL) {
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            V4 v; v.x = a[kc][0].x; v.y = a[kc][0].y; v.z = a[kc][1].x; v.w = a[kc][1].y;
+            __builtin_nontemporal_store(v, dst + 64 * kc);
+        }
+    } else {
+        wave_lds_fence();
+        // ---- X3: canonical -> internal layout through split planes ----
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            int k = 2 * L + 128 * kc;
+            vec2<float> re, im;
+            re.x = a[kc][0].x; re.y = a[kc][1].x; im.x = a[kc][0].y; im.y = a[kc][1].y;
+            *reinterpret_cast<vec2<float>*>(wf + c1024_plane_addr(0, k)) = re;
+            *reinterpret_cast<vec2<float>*>(wf + c1024_plane_addr(1, k)) = im;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            int k0 = 256 * ((L >> 1) & 3) + 4 * (8 * s + (L >> 3));
+            V4 v = *reinterpret_cast<const V4*>(wf + c1024_plane_addr(L & 1, k0));
+            __builtin_nontemporal_store(v, dst + 64 * s);
+        }
+    }
+    wave_lds_fence();
+}
+
+// The 29 twiddles a lane needs depend only on its lane id: W1024^(k1 (2L+e)) for S1 and
+// W1024^(8 (L&7) ka) for S2.  They are fetched once per wave and live in registers (58 VGPRs) for
+// the whole persistent loop: no twiddle table in LDS, no LDS latency in the butterflies.
+__device__ __forceinline__ void c1024_load_twiddles(const cx<float>* __restrict__ twg, int L, cx<float> (&w1)[7][2],
+                                                    cx<float> (&w2)[15]) {
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) {
+        w1[k1 - 1][0] = twg[k1 * (2 * L)];
+        w1[k1 - 1][1] = twg[k1 * (2 * L + 1)];
+    }
+#pragma unroll
+    for (int ka = 1; ka < 16; ++ka) w2[ka - 1] = twg[8 * (L & 7) * ka];
+}
+
+// ---- dynamic in-order distribution + prefetch (default) ----
+// ctr[0] = next group of 8 transforms, ctr[1] = workgroups finished (the last one re-arms both)
+template <int DIR, int IN_INTERNAL, int OUT_INTERNAL>
+__global__ void __launch_bounds__(C1024_WAVES * 64, 2)
+fft_c1024_f32_dyn_kernel(const float* in, float* out, unsigned batch, const cx<float>* __restrict__ twg,
+                         unsigned* ctr) {
+    typedef cx<float> C;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    C* tw = reinterpret_cast<C*>(smem_raw);
     const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
-    char* wbase = smem_raw + 8192 + wave * C1024_WAVE_BYTES;
+    char* wbase = smem_raw + wave * C1024_WAVE_BYTES;
     C* wl = reinterpret_cast<C*>(wbase);
     float* wf = reinterpret_cast<float*>(wbase);
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + C1024_WAVES * C1024_WAVE_BYTES);
 
-    for (int i = threadIdx.x; i < 1024; i += C1024_WAVES * 64) tw[i] = twg[i];
+    C w1[7][2], w2[15];
+    c1024_load_twiddles(twg, L, w1, w2);
+    unsigned pend = 0;
+    if (threadIdx.x == 0) {
+        s_next[0] = atomicAdd(&ctr[0], 1u);
+        pend = atomicAdd(&ctr[0], 1u);
+    }
     __syncthreads();
+    unsigned g = s_next[0];
+    const size_t last = (size_t)batch - 1;
+    C1024V4 raw[8];
+    {   // clamped: always a valid address, so the loads are unconditional (no phi copies, no early waits)
+        size_t t0 = (size_t)g * C1024_WAVES + wave;
+        c1024_load(raw, in, t0 < last ? t0 : last, L);
+    }
+    for (unsigned it = 0; (size_t)g * C1024_WAVES < batch; ++it) {
+        if (threadIdx.x == 0) {  // publish the index of iteration it+1, grab the one of it+2
+            s_next[(it + 1) & 1] = pend;
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        const size_t t = (size_t)g * C1024_WAVES + wave;
+        const bool active = t < batch;  // wave-uniform
+        c1024_part_a<DIR, IN_INTERNAL>(raw, wl, wf, w1, L);
+        __syncthreads();
+        const unsigned gn = s_next[(it + 1) & 1];
+        const size_t tn = (size_t)gn * C1024_WAVES + wave;
+        c1024_load(raw, in, tn < last ? tn : last, L);  // in flight while this transform finishes
+        if (active) c1024_part_b<DIR, OUT_INTERNAL>(out, t, wl, wf, w2, L);
+        g = gn;
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();  // my last (unused) grab has landed before I report done
+        unsigned d = atomicAdd(&ctr[1], 1u);
+        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+}
 
+// ---- static persistent assignment (variant 2, kept for A/B measurements) ----
+template <int DIR, int IN_INTERNAL, int OUT_INTERNAL>
+__global__ void __launch_bounds__(C1024_WAVES * 64, 2)
+fft_c1024_f32_kernel(const float* in, float* out, unsigned batch, const cx<float>* __restrict__ twg) {
+    typedef cx<float> C;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
+    char* wbase = smem_raw + wave * C1024_WAVE_BYTES;
+    C* wl = reinterpret_cast<C*>(wbase);
+    float* wf = reinterpret_cast<float*>(wbase);
+    C w1[7][2], w2[15];
+    c1024_load_twiddles(twg, L, w1, w2);
     const unsigned nwaves = gridDim.x * C1024_WAVES;
     for (unsigned t = blockIdx.x * C1024_WAVES + wave; t < batch; t += nwaves) {
-        const V4* src = reinterpret_cast<const V4*>(in) + (size_t)t * 512;
-        V4* dst = reinterpret_cast<V4*>(out) + (size_t)t * 512;
-        C a[8][2];
-        if (!IN_INTERNAL) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                V4 v = __builtin_nontemporal_load(src + 64 * j + L);
-                a[j][0] = mk<float>(v.x, v.y);
-                a[j][1] = mk<float>(v.z, v.w);
-            }
-        } else {
-            // X0: linear load of the internal layout, scatter into re/im planes, read back canonical
-            V4 v[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) v[s] = __builtin_nontemporal_load(src + 64 * s + L);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                int k0 = 256 * ((L >> 1) & 3) + 4 * (8 * s + (L >> 3));
-                *reinterpret_cast<V4*>(wf + c1024_plane_addr(L & 1, k0)) = v[s];
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int k = 128 * j + 2 * L;
-                vec2<float> re = *reinterpret_cast<const vec2<float>*>(wf + c1024_plane_addr(0, k));
-                vec2<float> im = *reinterpret_cast<const vec2<float>*>(wf + c1024_plane_addr(1, k));
-                a[j][0] = mk<float>(re.x, im.x);
-                a[j][1] = mk<float>(re.y, im.y);
-            }
-            wave_lds_fence();
-        }
-        // ---- S1: radix-8 over j, twiddle W1024^(k1 * r) ----
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            C b[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = a[j][e];
-            dft8<DIR>(b);
-            const int r = 2 * L + e;
-            a[0][e] = b[0];
-#pragma unroll
-            for (int k1 = 1; k1 < 8; ++k1) a[k1][e] = twmul<DIR>(b[k1], tw[k1 * r]);
-        }
-        // ---- X1 ----
-#pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) {
-            V4 v; v.x = a[k1][0].x; v.y = a[k1][0].y; v.z = a[k1][1].x; v.w = a[k1][1].y;
-            *reinterpret_cast<V4*>(wl + k1 * C1024_S1 + 2 * L) = v;
-        }
-        wave_lds_fence();
-        C m[16];
-        {
-            const C* rd = wl + (L >> 3) * C1024_S1 + (L & 7);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) m[q] = rd[8 * q];
-        }
-        wave_lds_fence();
-        // ---- S2: radix-16 over a, twiddle W128^(c * ka) = W1024^(8 c ka) ----
-        dft16<DIR>(m);
-        {
-            const int c8 = 8 * (L & 7);
-#pragma unroll
-            for (int ka = 1; ka < 16; ++ka) m[ka] = twmul<DIR>(m[ka], tw[c8 * ka]);
-        }
-        // ---- X2: image (k1, ka, c) at k1*S1 + 8 ka + 2*((c>>1) ^ (ka&3)) + (c&1) ----
-        {
-            const int k1 = L >> 3, c = L & 7;
-#pragma unroll
-            for (int ka = 0; ka < 16; ++ka)
-                wl[k1 * C1024_S1 + 8 * ka + 2 * ((c >> 1) ^ (ka & 3)) + (c & 1)] = m[ka];
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int k1 = 2 * (L & 3) + e, ka = L >> 2;
-            const C* rd = wl + k1 * C1024_S1 + 8 * ka;
-#pragma unroll
-            for (int cp = 0; cp < 4; ++cp) {
-                V4 v = *reinterpret_cast<const V4*>(rd + 2 * (cp ^ (ka & 3)));
-                a[2 * cp][e] = mk<float>(v.x, v.y);
-                a[2 * cp + 1][e] = mk<float>(v.z, v.w);
-            }
-        }
-        // ---- S3: radix-8 over c -> X[2L + e + 128 kc] ----
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            C b[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) b[q] = a[q][e];
-            dft8<DIR>(b);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) a[q][e] = b[q];
-        }
-        if (!OUT_INTERNAL) {
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                V4 v; v.x = a[kc][0].x; v.y = a[kc][0].y; v.z = a[kc][1].x; v.w = a[kc][1].y;
-                __builtin_nontemporal_store(v, dst + 64 * kc + L);
-            }
-        } else {
-            wave_lds_fence();
-            // ---- X3: canonical -> internal layout through split planes ----
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                int k = 2 * L + 128 * kc;
-                vec2<float> re, im;
-                re.x = a[kc][0].x; re.y = a[kc][1].x; im.x = a[kc][0].y; im.y = a[kc][1].y;
-                *reinterpret_cast<vec2<float>*>(wf + c1024_plane_addr(0, k)) = re;
-                *reinterpret_cast<vec2<float>*>(wf + c1024_plane_addr(1, k)) = im;
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                int k0 = 256 * ((L >> 1) & 3) + 4 * (8 * s + (L >> 3));
-                V4 v = *reinterpret_cast<const V4*>(wf + c1024_plane_addr(L & 1, k0));
-                __builtin_nontemporal_store(v, dst + 64 * s + L);
-            }
-        }
-        wave_lds_fence();
+        C1024V4 raw[8];
+        c1024_load(raw, in, t, L);
+        c1024_part_a<DIR, IN_INTERNAL>(raw, wl, wf, w1, L);
+        c1024_part_b<DIR, OUT_INTERNAL>(out, t, wl, wf, w2, L);
     }
 }
 

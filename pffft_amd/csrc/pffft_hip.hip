@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -97,6 +98,7 @@ static void aligned_free64(void* p) {
 // ------------------------------------------------------------------------------------------------
 enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1 };
 constexpr size_t LDS_MAX = 160 * 1024;
+constexpr unsigned CTR_RING = 4096;
 
 struct Setup {
     uint32_t magic;
@@ -113,6 +115,8 @@ struct Setup {
     bool dev_ready = false;
     void* d_tw = nullptr;   // W_n^j, j < n
     void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
+    unsigned* d_ctr = nullptr;             // ring of {next, done} work counters for the dynamic kernels
+    std::atomic<unsigned> ctr_slot{0};
     void* d_stage[3] = {nullptr, nullptr, nullptr};  // staging for host-pointer legacy calls
     size_t stage_bytes[3] = {0, 0, 0};
 };
@@ -159,6 +163,7 @@ static void destroy_setup(Setup* s) {
     if (s->dev_ready) {
         if (s->d_tw) (void)hipFree(s->d_tw);
         if (s->d_twr) (void)hipFree(s->d_twr);
+        if (s->d_ctr) (void)hipFree(s->d_ctr);
     }
     for (void* p : s->d_stage) if (p) (void)hipFree(p);
     s->magic = 0;
@@ -190,6 +195,13 @@ static int ensure_device(Setup* s) {
         }
         PF_CHECK(hipMalloc(&s->d_twr, sizeof(cx<T>) * m));
         PF_CHECK(hipMemcpy(s->d_twr, twr.data(), sizeof(cx<T>) * m, hipMemcpyHostToDevice));
+    }
+    if (s->kernel == K_C1024_F32) {
+        // Each launch of a dynamic kernel takes its own {next, done} counter pair from this ring; the
+        // kernel re-arms the pair when its last workgroup retires.  A pair is reused only CTR_RING
+        // launches later, i.e. at most CTR_RING launches of one setup may be in flight at once.
+        PF_CHECK(hipMalloc((void**)&s->d_ctr, sizeof(unsigned) * 2 * CTR_RING));
+        PF_CHECK(hipMemset(s->d_ctr, 0, sizeof(unsigned) * 2 * CTR_RING));
     }
     s->dev_ready = true;
     return 0;
@@ -245,18 +257,29 @@ static int launch_generic(Setup* s, const T* in, T* out, size_t batch, int dir, 
 
 static int launch_c1024(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st) {
     const unsigned wgs_needed = (unsigned)((batch + C1024_WAVES - 1) / C1024_WAVES);
-    unsigned grid = (unsigned)num_cus() * 2;
+    // variants (bench A/B only): 0 = dynamic in-order, 1 WG/CU (default); 3 = dynamic, 2 WG/CU;
+    // 2 = static persistent assignment, 2 WG/CU
+    const bool dyn = g_variant != 2;
+    unsigned grid = (unsigned)num_cus() * ((g_variant == 2 || g_variant == 3) ? 2 : 1);
     if (grid > wgs_needed) grid = wgs_needed;
     const dim3 blk(C1024_WAVES * 64);
     const size_t lds = C1024_LDS_BYTES;
     const cx<float>* tw = (const cx<float>*)s->d_tw;
     const unsigned b = (unsigned)batch;
+    unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
 #define PF_LAUNCH_C1024(D, I, O)                                                                      \
     do {                                                                                              \
-        auto k = fft_c1024_f32_kernel<D, I, O>;                                                       \
-        int rc = allow_big_lds(k, lds);                                                               \
-        if (rc) return rc;                                                                            \
-        hipLaunchKernelGGL(k, dim3(grid), blk, lds, st, in, out, b, tw);                              \
+        if (dyn) {                                                                                    \
+            auto k = fft_c1024_f32_dyn_kernel<D, I, O>;                                               \
+            int rc = allow_big_lds(k, lds);                                                           \
+            if (rc) return rc;                                                                        \
+            hipLaunchKernelGGL(k, dim3(grid), blk, lds, st, in, out, b, tw, ctr);                     \
+        } else {                                                                                      \
+            auto k = fft_c1024_f32_kernel<D, I, O>;                                                   \
+            int rc = allow_big_lds(k, lds);                                                           \
+            if (rc) return rc;                                                                        \
+            hipLaunchKernelGGL(k, dim3(grid), blk, lds, st, in, out, b, tw);                          \
+        }                                                                                             \
     } while (0)
     if (dir == PFFFT_FORWARD) {
         if (ordered) PF_LAUNCH_C1024(FWD, 0, 0); else PF_LAUNCH_C1024(FWD, 0, 1);
