@@ -141,33 +141,23 @@ def main():
     except Exception as e:  # the checker is optional here; tests/ are the parity gate
         parity = f"unchecked: {e}"
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    # W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize on both sides
+    # (pffft_amd/sharding.py); HIP events on the launch stream give the kernel's own average duration.
+    from pffft_amd.sharding import combine, timed_steps
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_s = e0.elapsed_time(e1) * 1e-3 / args.steps   # HIP events on the launch stream
-    barrier()
+    count = [0]
 
-    total = float(batch)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([total], device=dev, dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total = float(c.item())
+    def timed_step():
+        if count[0] == args.warmup:
+            e0.record()
+        step()
+        count[0] += 1
+        if count[0] == args.warmup + args.steps:
+            e1.record()
+
+    elapsed = timed_steps(timed_step, args.steps, args.warmup, dist, torch.cuda.synchronize)
+    kernel_s = e0.elapsed_time(e1) * 1e-3 / args.steps
+    elapsed, total = combine(elapsed, float(batch), dist, dev)
 
     extras = {}
     if not args.no_extras and rank == 0:

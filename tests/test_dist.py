@@ -1,0 +1,63 @@
+"""CPU test of the N>1 path (-m "not gpu"): world_size 2 over gloo, 127.0.0.1 rendezvous.
+The data path has no collective (batch shards); what is distributed is the measurement
+bracket of bench.py (pffft_amd/sharding.py): barrier, MAX of elapsed, SUM of units — exercised here with a
+host-side stand-in step, since the transform itself has no CPU implementation in the product."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from pffft_amd.sharding import combine, shard_range, timed_steps
+
+
+def test_shard_range_partitions_the_batch():
+    for total in (0, 1, 7, 8, 1 << 20, (1 << 23) + 5):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def _worker(rank, world, port, total, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    start, count = shard_range(total, rank, world)
+    x = np.random.default_rng(rank).standard_normal((count, 64))
+    done = [0]
+
+    def step():  # stand-in for one pass over this rank's shard
+        np.fft.fft(x, axis=1)
+        done[0] += 1
+
+    elapsed = timed_steps(step, steps=3, warmup=1, dist=dist, sync=None)
+    mx, tot = combine(elapsed, float(count), dist, torch.device("cpu"))
+    q.put((rank, start, count, elapsed, mx, tot, done[0]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bracket():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    total = 1001
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, c0, e0, m0, t0, d0), (r1, s1, c1, e1, m1, t1, d1) = res
+    assert (s0, c0, s1, c1) == (0, 501, 501, 500)
+    assert t0 == t1 == total                      # SUM over ranks of the units
+    assert m0 == m1 == pytest.approx(max(e0, e1))  # MAX over ranks of the elapsed time
+    assert d0 == d1 == 4                          # 1 warm-up + exactly 3 timed steps
