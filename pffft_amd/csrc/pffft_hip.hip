@@ -16,6 +16,7 @@
 #include "../../include/pffft_hip.h"
 #include "fft_c1024.h"
 #include "fft_generic.h"
+#include "fft_tiled.h"
 
 namespace pf {
 
@@ -96,7 +97,7 @@ static void aligned_free64(void* p) {
 // ------------------------------------------------------------------------------------------------
 // the plan ("PFFFT_Setup": src/pffft_priv_impl.h:1051-1060)
 // ------------------------------------------------------------------------------------------------
-enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1 };
+enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1, K_TILED = 2 };
 constexpr size_t LDS_MAX = 160 * 1024;
 constexpr unsigned CTR_RING = 4096;
 
@@ -155,6 +156,9 @@ static Setup* new_setup(int N, int transform, int is_double) {
     s->gthreads = th < 64 ? 64 : (th > 1024 ? 1024 : th);
     s->kernel = K_GENERIC;
     if (!is_double && transform == PFFFT_COMPLEX && N == 1024) s->kernel = K_C1024_F32;
+    else if ((s->n & (s->n - 1)) == 0 && s->n >= 512 && s->n <= 16384 &&
+             (size_t)s->n * esz <= 128 * 1024)
+        s->kernel = K_TILED;  // power-of-two sizes: register-tiled kernels (fft_tiled.h)
     return s;
 }
 
@@ -196,7 +200,7 @@ static int ensure_device(Setup* s) {
         PF_CHECK(hipMalloc(&s->d_twr, sizeof(cx<T>) * m));
         PF_CHECK(hipMemcpy(s->d_twr, twr.data(), sizeof(cx<T>) * m, hipMemcpyHostToDevice));
     }
-    if (s->kernel == K_C1024_F32) {
+    {
         // Each launch of a dynamic kernel takes its own {next, done} counter pair from this ring; the
         // kernel re-arms the pair when its last workgroup retires.  A pair is reused only CTR_RING
         // launches later, i.e. at most CTR_RING launches of one setup may be in flight at once.
@@ -292,6 +296,56 @@ static int launch_c1024(Setup* s, const float* in, float* out, size_t batch, int
 }
 
 template <typename T>
+struct TiledEntry {
+    void (*fn)(const T*, T*, unsigned, int, const cx<T>*, const cx<T>*, unsigned*);
+    size_t lds;
+    int wg, t_per_wg;
+};
+template <typename T, template <typename> class CfgT>
+static TiledEntry<T> tiled_entry(int dir, int real) {
+    typedef CfgT<T> C;
+    TiledEntry<T> e;
+    e.lds = C::LDS_BYTES; e.wg = C::WG_THREADS; e.t_per_wg = C::T_PER_WG;
+    if (dir == PFFFT_FORWARD) e.fn = real ? fft_tiled_kernel<C, FWD, 1> : fft_tiled_kernel<C, FWD, 0>;
+    else e.fn = real ? fft_tiled_kernel<C, BWD, 1> : fft_tiled_kernel<C, BWD, 0>;
+    return e;
+}
+template <typename T>
+static bool tiled_lookup(int n, int dir, int real, TiledEntry<T>* e) {
+    switch (n) {
+        case 512: *e = tiled_entry<T, Tiled512>(dir, real); return true;
+        case 1024: *e = tiled_entry<T, Tiled1024>(dir, real); return true;
+        case 2048: *e = tiled_entry<T, Tiled2048>(dir, real); return true;
+        case 4096: *e = tiled_entry<T, Tiled4096>(dir, real); return true;
+        case 8192: *e = tiled_entry<T, Tiled8192>(dir, real); return true;
+        case 16384: *e = tiled_entry<T, Tiled16384>(dir, real); return true;
+    }
+    return false;
+}
+
+template <typename T>
+static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    TiledEntry<T> e;
+    const int real = s->transform == PFFFT_REAL;
+    if (!tiled_lookup<T>(s->n, dir, real, &e)) return -1;
+    int rc = allow_big_lds(e.fn, e.lds);
+    if (rc) return rc;
+    int per_cu = 0;
+    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(e.fn), e.wg, e.lds));
+    if (per_cu < 1) per_cu = 1;
+    if (g_variant >= 10 && g_variant < 20 && per_cu > g_variant - 10 && g_variant > 10) per_cu = g_variant - 10;  // A/B: cap WGs per CU
+    size_t groups = (batch + e.t_per_wg - 1) / e.t_per_wg;
+    size_t grid = (size_t)num_cus() * per_cu;
+    if (grid > groups) grid = groups;
+    const int flags = (((dir == PFFFT_BACKWARD) && !ordered) ? 1 : 0) | (((dir == PFFFT_FORWARD) && !ordered) ? 2 : 0);
+    unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    hipLaunchKernelGGL(e.fn, dim3((unsigned)grid), dim3(e.wg), e.lds, st, in, out, (unsigned)batch, flags,
+                       (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
 static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     if (!s || s->magic != MAGIC || s->is_double != (sizeof(T) == 8)) {
         g_last_error = "pffft_hip: bad setup handle";
@@ -304,6 +358,8 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         if (s->kernel == K_C1024_F32 && g_variant != 1 && batch < (1ull << 32))
             return launch_c1024(s, in, out, batch, dir, ordered, st);
     }
+    if (s->kernel == K_TILED && g_variant != 1 && batch < (1ull << 32))
+        return launch_tiled<T>(s, in, out, batch, dir, ordered, st);
     return launch_generic<T>(s, in, out, batch, dir, ordered, st);
 }
 
@@ -522,6 +578,7 @@ PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
     if (pf::g_variant == 1) return "generic";
     switch (s->kernel) {
         case pf::K_C1024_F32: return "c1024_f32";
+        case pf::K_TILED: return "tiled";
         default: return "generic";
     }
 }
