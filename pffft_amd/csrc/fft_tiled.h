@@ -11,103 +11,169 @@
 //     in  q : x[j + q n/R] * W_{Ns R}^(q (j mod Ns))          out d : y[(j div Ns) Ns R + (j mod Ns) + d Ns]
 // so the first stage reads the vector straight from HBM with 16-byte coalesced loads, the last stage
 // writes the canonical spectrum straight back the same way, and only the exchanges between stages go
-// through LDS (one image of n points, reused in place; TPT <= 64: wave-local fences, TPT > 64: one
-// workgroup per transform and __syncthreads).  Layout / real-transform work is done by adapters around
-// that core, also through the LDS image:
-//   complex, internal layout : split re/im planes <-> linear 4-scalar groups (bin_of, fft_generic.h)
-//   real forward             : Z = FFT_n(x[2j] + i x[2j+1]);  X[k] = (Z[k]+conj Z[n-k])/2 - i/2 W_N^k (Z[k]-conj Z[n-k])
-//   real backward            : Z'[k] = (X[k]+conj X[n-k]) + i conj(W_N^k) (X[k]-conj X[n-k]);  x = IFFT_n(Z')  (= N x)
-// Workgroups are persistent and pull transforms in order from an atomic counter (see fft_c1024.h for why).
+// through LDS (one image of n points per transform, reused in place).  Layout / real-transform work is
+// done by adapters around that core, also through the LDS image:
+//   complex, internal layout : natural-order image <-> linear 16-byte chunks of the pffft layout (bin_of)
+//   real forward             : Z = FFT_n(x[2j] + i x[2j+1]); pairs (k, n-k) in place:
+//                              X[k] = S + D, X[n-k] = conj(S - D), S = (A+B)/2, D = -(i/2) W_N^k (A-B),
+//                              A = Z[k], B = conj Z[n-k]
+//   real backward            : pairs in place: Z'[k] = S + D, Z'[n-k] = conj(S - D), S = A+B,
+//                              D = i conj(W_N^k) (A-B), A = X[k], B = conj X[n-k];  x = IFFT_n(Z') (= N x)
+// The recipe that makes it HBM-bound is the one measured on fft_c1024.h: persistent 512-thread workgroups
+// (one per CU) that pull transforms IN ORDER from an atomic counter, every twiddle a thread ever needs
+// resident in its registers (they depend on the thread id only), and the 16-byte loads of the NEXT
+// transform issued as soon as the current one has left its input registers.
 #pragma once
 #include "cxmath.h"
 #include "fft_generic.h"  // bin_of
 
 namespace pf {
 
-template <typename T, int LOGN_, int TPT_, int NS_, int R0_, int R1_, int R2_, int R3_, int PAD0_ = 0, int PADN_ = 0>
+// TWMODE: 0 = every twiddle in registers, 1 = W_n^j table in LDS, 2 = global table (L2),
+//         3 = one base twiddle per butterfly in registers, its powers w^2..w^(R-1) recomputed (<= 4 products deep)
+template <typename T, int LOGN_, int TPT_, int NS_, int R0_, int R1_, int R2_, int R3_, int PAD0_, int PADN_,
+          int TWMODE_, int PREFETCH_, int WGT_ = 512>
 struct TiledCfg {
     typedef T real_t;
     static constexpr int LOGN = LOGN_, n = 1 << LOGN_, TPT = TPT_, E = n / TPT_, NS = NS_;
     static constexpr int VEC = 16 / (2 * (int)sizeof(T));  // complex points per 16 bytes: 2 float, 1 double
-    static constexpr int PAD0 = PAD0_;  // row padding (points) of the transposed image after stage 0
-    static constexpr int PADN = PADN_;  // padding (points) per 64 points of the natural images
+    static constexpr int CH = 16 / (int)sizeof(T);         // scalars per 16-byte chunk: 4 float, 2 double
+    static constexpr int NCH = E * 2 / CH;                  // 16-byte chunks per thread
+    static constexpr int PAD0 = PAD0_, PADN = PADN_, TWMODE = TWMODE_, PREFETCH = PREFETCH_;
     __host__ __device__ static constexpr int rad(int s) { return s == 0 ? R0_ : s == 1 ? R1_ : s == 2 ? R2_ : R3_; }
-    __host__ __device__ static constexpr int ns(int s) {  // product of the radices before stage s
+    __host__ __device__ static constexpr int ns(int s) {
         int p = 1;
         for (int i = 0; i < s; ++i) p *= rad(i);
         return p;
     }
-    // LDS image of one transform, in points (complex<T>): natural layout padded per 64, or the transposed
-    // image after stage 0 (R0 rows of n/R0 + PAD0), whichever is larger
-    static constexpr int IMG_NAT = n + PADN * (n / 64);
-    static constexpr int IMG_TRN = R0_ * (n / R0_ + PAD0);
-    static constexpr int IMG = (IMG_NAT > IMG_TRN ? IMG_NAT : IMG_TRN) + 8;
-    // transforms per workgroup: one when a transform spans several waves, else as many as fit 512
-    // threads and ~80 KiB of LDS (two workgroups per CU)
-    __host__ __device__ static constexpr int t_per_wg() {
-        if (TPT > 64) return 1;
-        int m = 512 / TPT;
-        while (m > 1 && (size_t)m * IMG * 2 * sizeof(T) > 80 * 1024) m /= 2;
-        return m;
+    // register twiddles: stage s >= 1 holds (E / R_s) * (R_s - 1) of them
+    __host__ __device__ static constexpr int tw_off(int s) {
+        int o = 0;
+        for (int i = 1; i < s; ++i) o += (E / rad(i)) * (TWMODE_ == 3 ? 1 : rad(i) - 1);
+        return o;
     }
-    static constexpr int T_PER_WG = t_per_wg();
-    static constexpr int WG_THREADS = TPT > 64 ? TPT : (T_PER_WG * TPT < 64 ? 64 : T_PER_WG * TPT);
-    static constexpr size_t LDS_BYTES = (size_t)T_PER_WG * IMG * 2 * sizeof(T) + 16;
-};
-
-// 16-byte global access = VEC complex points
-template <typename T> struct unit16;
-template <> struct unit16<float> {
-    typedef vec4<float> type;
-    static __device__ __forceinline__ void unpack(type v, cx<float>& a, cx<float>& b) { a = mk<float>(v.x, v.y); b = mk<float>(v.z, v.w); }
-    static __device__ __forceinline__ type pack(cx<float> a, cx<float> b) { type v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; return v; }
-};
-template <> struct unit16<double> {
-    typedef vec2<double> type;
+    static constexpr int TW_COUNT = tw_off(NS_);
+    static constexpr int IMG_NAT = n + PADN_ * (n / 64);
+    static constexpr int IMG_TRN = R0_ * (n / R0_ + PAD0_);
+    static constexpr int IMG = (IMG_NAT > IMG_TRN ? IMG_NAT : IMG_TRN) + 8;
+    static constexpr int WG_THREADS = TPT > WGT_ ? TPT : WGT_;
+    static constexpr int T_PER_WG = WG_THREADS / TPT;
+    static constexpr size_t TABLE_BYTES = TWMODE_ == 1 ? (size_t)n * 2 * sizeof(T) : 0;
+    static constexpr size_t LDS_BYTES = TABLE_BYTES + (size_t)T_PER_WG * IMG * 2 * sizeof(T) + 16;
 };
 
 template <class C, int S> struct StageInfo {
     static constexpr int R = C::rad(S), Ns = C::ns(S), B = C::E / R;
     static constexpr bool PAIR = (C::VEC == 2) && (B % 2 == 0);
-    // butterfly index of thread t, slot u
     static __device__ __forceinline__ int j(int t, int u) {
         if (PAIR) return 2 * t + (u & 1) + 2 * C::TPT * (u >> 1);
         return t + C::TPT * u;
     }
 };
 
-// physical LDS index (points) of logical position P
 template <class C> __device__ __forceinline__ int phys_nat(int P) { return P + C::PADN * (P >> 6); }
 template <class C> __device__ __forceinline__ int phys_trn(int P) {  // image after stage 0: P = j*R0 + d -> row d, column j
     constexpr int R0 = C::rad(0);
     return (P & (R0 - 1)) * (C::n / R0 + C::PAD0) + (P / R0);
 }
 
-template <class C, int DIR>
-struct TiledCore {
+typedef vec4<float> chunk16;  // a 16-byte register quantum, reinterpreted per precision
+
+template <typename T> struct ChunkOps;
+template <> struct ChunkOps<float> {
+    static __device__ __forceinline__ float get(const chunk16& c, int i) { return c[i]; }
+    static __device__ __forceinline__ void set(chunk16& c, int i, float v) { c[i] = v; }
+};
+template <> struct ChunkOps<double> {
+    static __device__ __forceinline__ double get(const chunk16& c, int i) {
+        return __builtin_bit_cast(vec2<double>, c)[i];
+    }
+    static __device__ __forceinline__ void set(chunk16& c, int i, double v) {
+        vec2<double> d = __builtin_bit_cast(vec2<double>, c);
+        d[i] = v;
+        c = __builtin_bit_cast(chunk16, d);
+    }
+};
+
+template <class C, int DIR, int REAL>
+struct Tiled {
     typedef typename C::real_t T;
     typedef cx<T> CX;
+    typedef ChunkOps<T> CO;
+    typedef StageInfo<C, 0> S0;
+    typedef StageInfo<C, C::NS - 1> SL;
+    static constexpr int n = C::n, E = C::E, TPT = C::TPT, VEC = C::VEC, CH = C::CH, NCH = C::NCH;
+    static constexpr int R0 = S0::R, RL = SL::R;
+    static constexpr bool REGTW = C::TWMODE == 0 || C::TWMODE == 3;
+    static constexpr int NPT = (REAL && REGTW) ? E / 2 : 1;  // pair-pass twiddles per thread
 
-    template <int TPT> static __device__ __forceinline__ void xsync() {
+    struct Tw {
+        CX r[C::TW_COUNT > 0 ? C::TW_COUNT : 1];
+        CX p[NPT];
+    };
+
+    static __device__ __forceinline__ void xsync() {
         if (TPT > 64) __syncthreads();
         else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     }
 
-    // butterflies of stage S on v (inputs v[u*R+q] -> outputs v[u*R+d]); twiddles on inputs for S > 0
-    template <int S>
-    static __device__ __forceinline__ void butterflies(CX (&v)[C::E], int t, const CX* __restrict__ tw) {
-        typedef StageInfo<C, S> SI;
-        constexpr int R = SI::R, Ns = SI::Ns, B = SI::B;
+    template <int S> static __device__ __forceinline__ void load_tw_stage(Tw& w, int t, const CX* __restrict__ twg) {
+        if constexpr (S < C::NS) {
+            typedef StageInfo<C, S> SI;
+            constexpr int R = SI::R, Ns = SI::Ns, step = n / (Ns * R), off = C::tw_off(S);
 #pragma unroll
-        for (int u = 0; u < B; ++u) {
+            for (int u = 0; u < SI::B; ++u) {
+                const int k = SI::j(t, u) & (Ns - 1);
+                if constexpr (C::TWMODE == 3) w.r[off + u] = twg[k * step];
+                else {
+#pragma unroll
+                    for (int q = 1; q < R; ++q) w.r[off + u * (R - 1) + (q - 1)] = twg[(q * k) * step];
+                }
+            }
+            load_tw_stage<S + 1>(w, t, twg);
+        }
+    }
+    static __device__ __forceinline__ void load_tw(Tw& w, int t, const CX* __restrict__ twg, const CX* __restrict__ twrg) {
+        if constexpr (REGTW) {
+            load_tw_stage<1>(w, t, twg);
+            if constexpr (REAL) {
+#pragma unroll
+                for (int i = 0; i < E / 2; ++i) w.p[i] = twrg[t + TPT * i];
+            }
+        }
+    }
+    template <int S> static __device__ __forceinline__ CX stage_tw(const Tw& w, int t, int u, int q, const CX* tab) {
+        typedef StageInfo<C, S> SI;
+        if constexpr (C::TWMODE == 0) return w.r[C::tw_off(S) + u * (SI::R - 1) + (q - 1)];
+        else {
+            const int k = SI::j(t, u) & (SI::Ns - 1);
+            return tab[(q * k) * (n / (SI::Ns * SI::R))];
+        }
+    }
+
+    template <int S>
+    static __device__ __forceinline__ void butterflies(CX (&v)[E], int t, const Tw& w, const CX* tab) {
+        typedef StageInfo<C, S> SI;
+        constexpr int R = SI::R;
+#pragma unroll
+        for (int u = 0; u < SI::B; ++u) {
             CX a[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) a[q] = v[u * R + q];
-            if (S > 0) {
-                const int k = SI::j(t, u) & (Ns - 1);
-                constexpr int step = C::n / (Ns * R);
+            if constexpr (S > 0 && C::TWMODE == 3) {
+                CX p[R];  // p[q] = w^q, every power at most 4 products away from the table value
+                p[1] = w.r[C::tw_off(S) + u];
+                if constexpr (R > 2) { p[2] = cmul(p[1], p[1]); p[3] = cmul(p[2], p[1]); }
+                if constexpr (R > 4) { p[4] = cmul(p[2], p[2]); p[5] = cmul(p[4], p[1]); p[6] = cmul(p[3], p[3]); p[7] = cmul(p[4], p[3]); }
+                if constexpr (R > 8) {
+                    p[8] = cmul(p[4], p[4]); p[9] = cmul(p[8], p[1]); p[10] = cmul(p[5], p[5]); p[11] = cmul(p[8], p[3]);
+                    p[12] = cmul(p[6], p[6]); p[13] = cmul(p[8], p[5]); p[14] = cmul(p[7], p[7]); p[15] = cmul(p[8], p[7]);
+                }
 #pragma unroll
-                for (int q = 1; q < R; ++q) a[q] = twmul<DIR>(a[q], tw[(q * k) * step]);
+                for (int q = 1; q < R; ++q) a[q] = twmul<DIR>(a[q], p[q]);
+            } else if constexpr (S > 0) {
+#pragma unroll
+                for (int q = 1; q < R; ++q) a[q] = twmul<DIR>(a[q], stage_tw<S>(w, t, u, q, tab));
             }
             dftR<R, DIR>(a);
 #pragma unroll
@@ -115,74 +181,142 @@ struct TiledCore {
         }
     }
 
-    // exchange between stage S and S+1 through the LDS image `img`
-    template <int S>
-    static __device__ __forceinline__ void exchange(CX (&v)[C::E], int t, CX* img) {
+    // The LDS addresses below are written as (one base per butterfly) + (compile-time offset per
+    // operand), so that every access is a ds_read/ds_write with an immediate offset and the persistent
+    // loop keeps a handful of address registers instead of one per access.  The split is exact:
+    //   natural image : phys(P) = P + PADN*(P>>6); for P = H + a + c with H a multiple of min(Ns R, 64)...
+    //                    floor((H+a+c)/64) = floor(H/64) + floor(c/64) for the operand
+    //                   strides c used here (multiples of Ns, resp. of n/R >= 64)
+    //   transposed    : phys(P) = (P mod R0)*ROW + P div R0
+    static __device__ __forceinline__ constexpr int nat_off(int c) { return c + C::PADN * (c >> 6); }
+    template <int S> static __device__ __forceinline__ void xwrite(const CX (&v)[E], int t, CX* img) {
         typedef StageInfo<C, S> SW;
-        typedef StageInfo<C, S + 1> SR;
-        constexpr int R = SW::R, Ns = SW::Ns;
-        constexpr bool TRN = (S == 0);
-        // write: y[(j div Ns) Ns R + (j mod Ns) + d Ns]
+        constexpr int R = SW::R, Ns = SW::Ns, ROW = n / R0 + C::PAD0;
 #pragma unroll
         for (int u = 0; u < SW::B; ++u) {
             const int j = SW::j(t, u);
-            const int base = (j / Ns) * (Ns * R) + (j & (Ns - 1));
+            if constexpr (S == 0) {  // P = j*R0 + d -> row d, column j
+                CX* p = img + j;
 #pragma unroll
-            for (int d = 0; d < R; ++d) {
-                const int P = base + d * Ns;
-                img[TRN ? phys_trn<C>(P) : phys_nat<C>(P)] = v[u * R + d];
+                for (int d = 0; d < R; ++d) p[d * ROW] = v[u * R + d];
+            } else {
+                const int Ha = (j / Ns) * (Ns * R) + (j & (Ns - 1));
+                CX* p = img + Ha + C::PADN * (Ha >> 6);
+#pragma unroll
+                for (int d = 0; d < R; ++d) p[nat_off(d * Ns)] = v[u * R + d];
             }
         }
-        xsync<C::TPT>();
-        // read: x[j' + q n/R']
-        constexpr int R2 = SR::R;
+    }
+    template <int S> static __device__ __forceinline__ void xread(CX (&v)[E], int t, const CX* img) {
+        typedef StageInfo<C, S + 1> SR;
+        constexpr int R2 = SR::R, ROW = n / R0 + C::PAD0;
+        static_assert((n / R2) % 64 == 0 || C::PADN == 0, "operand stride must be a multiple of the padding period");
+        static_assert((n / R2) % R0 == 0, "operand stride must be a multiple of R0");
 #pragma unroll
         for (int u = 0; u < SR::B; ++u) {
             const int j = SR::j(t, u);
+            if constexpr (S == 0) {  // P = j + q n/R2 -> row P mod R0 = j mod R0, column j div R0 + q n/(R2 R0)
+                const CX* p = img + (j & (R0 - 1)) * ROW + (j / R0);
 #pragma unroll
-            for (int q = 0; q < R2; ++q) {
-                const int P = j + q * (C::n / R2);
-                v[u * R2 + q] = img[TRN ? phys_trn<C>(P) : phys_nat<C>(P)];
+                for (int q = 0; q < R2; ++q) v[u * R2 + q] = p[q * (n / (R2 * R0))];
+            } else {
+                const CX* p = img + j + C::PADN * (j >> 6);
+#pragma unroll
+                for (int q = 0; q < R2; ++q) v[u * R2 + q] = p[nat_off(q * (n / R2))];
             }
         }
-        xsync<C::TPT>();
     }
 
-    // the whole transform on registers: in  v[u*R0+q] = x[j0(t,u) + q n/R0],  out v[u*RL+d] = X[jL(t,u) + d n/RL]
-    static __device__ __forceinline__ void run(CX (&v)[C::E], int t, CX* img, const CX* __restrict__ tw) {
-        butterflies<0>(v, t, tw);
-        if constexpr (C::NS > 1) { exchange<0>(v, t, img); butterflies<1>(v, t, tw); }
-        if constexpr (C::NS > 2) { exchange<1>(v, t, img); butterflies<2>(v, t, tw); }
-        if constexpr (C::NS > 3) { exchange<2>(v, t, img); butterflies<3>(v, t, tw); }
+    // chunk index (16-byte units inside one vector) of raw slot i for the two load patterns
+    static __device__ __forceinline__ int plain_chunk(int t, int i) {  // first-stage operand order
+        if constexpr (VEC == 2) {  // slot i = (pair index ii, input q): ii * R0 + q
+            const int ii = i / R0, q = i % R0;
+            return t + TPT * ii + q * (n / (2 * R0));
+        } else {
+            const int u = i / R0, q = i % R0;
+            return t + TPT * u + q * (n / R0);
+        }
+    }
+    static __device__ __forceinline__ void load_raw(chunk16 (&raw)[NCH], const T* src, int t, bool plain) {
+        const chunk16* s = reinterpret_cast<const chunk16*>(src);
+        if (plain) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) raw[i] = __builtin_nontemporal_load(s + plain_chunk(t, i));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) raw[i] = __builtin_nontemporal_load(s + t + TPT * i);
+        }
+    }
+
+    // in-place pair pass on the natural-order image (real transforms)
+    static __device__ __forceinline__ void pair_pass(CX* img, int t, const Tw& w, const CX* __restrict__ twrg) {
+        // k = t + TPT i and n - k: two base pointers + compile-time offsets (TPT i is a multiple of 64)
+        CX* const pk = img + t + C::PADN * (t >> 6);
+        CX* const pn = img + (n - t) + C::PADN * ((n - t) >> 6);
+        constexpr bool AFF = (TPT % 64 == 0);
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            const int k = t + TPT * i;
+            CX* const qk = AFF ? pk + nat_off(TPT * i) : img + phys_nat<C>(k);
+            CX* const qn = AFF ? pn - nat_off(TPT * i) : img + phys_nat<C>(n - k);
+            if (k == 0) {
+                CX a = img[phys_nat<C>(0)];
+                img[phys_nat<C>(0)] = mk<T>(a.x + a.y, a.x - a.y);  // (DC, Nyquist) <-> Z[0], both directions
+                CX h = img[phys_nat<C>(n / 2)];
+                img[phys_nat<C>(n / 2)] = DIR == FWD ? conj(h) : mk<T>((T)2 * h.x, (T)-2 * h.y);
+            } else {
+                CX wk;
+                if constexpr (REGTW) wk = w.p[i]; else wk = twrg[k];
+                CX A = *qk, Bc = conj(*qn);
+                CX S, D;
+                if (DIR == FWD) {
+                    S = (A + Bc) * (T)0.5;
+                    CX m = cmul((A - Bc) * (T)0.5, wk);
+                    D = mk<T>(m.y, -m.x);  // * (-i)
+                } else {
+                    S = A + Bc;
+                    CX m = cmulc(A - Bc, wk);
+                    D = mk<T>(-m.y, m.x);  // * (+i)
+                }
+                *qk = S + D;
+                *qn = conj(S - D);
+            }
+        }
     }
 };
 
-// ---------------------------------------------------------------------------------------------
-// kernel
-// ---------------------------------------------------------------------------------------------
 // flags: bit0 = input in internal layout, bit1 = output in internal layout
 template <class C, int DIR, int REAL>
-__global__ void __launch_bounds__(C::WG_THREADS)
+__global__ void __launch_bounds__(C::WG_THREADS, C::WG_THREADS >= 1024 ? 4 : 2)
 fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned batch, int flags,
-                 const cx<typename C::real_t>* __restrict__ tw, const cx<typename C::real_t>* __restrict__ twr,
+                 const cx<typename C::real_t>* __restrict__ twg, const cx<typename C::real_t>* __restrict__ twrg,
                  unsigned* ctr) {
     typedef typename C::real_t T;
     typedef cx<T> CX;
-    typedef TiledCore<C, DIR> Core;
-    typedef StageInfo<C, 0> S0;
-    typedef StageInfo<C, C::NS - 1> SL;
-    constexpr int n = C::n, E = C::E, TPT = C::TPT, VEC = C::VEC;
-    constexpr int R0 = S0::R, RL = SL::R;
-    static_assert(VEC == 1 || (S0::PAIR && SL::PAIR), "float configs need an even number of butterflies in the first and last stage");
+    typedef Tiled<C, DIR, REAL> K;
+    typedef typename K::S0 S0;
+    typedef typename K::SL SL;
+    typedef ChunkOps<T> CO;
+    constexpr int n = C::n, E = C::E, TPT = C::TPT, VEC = C::VEC, CH = C::CH, NCH = C::NCH;
+    constexpr int R0 = K::R0, RL = K::RL;
+    static_assert(VEC == 1 || (S0::PAIR && SL::PAIR), "float configs need an even butterfly count in the first/last stage");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int slot = threadIdx.x / TPT, t = threadIdx.x % TPT;
-    CX* img = reinterpret_cast<CX*>(smem_raw) + (size_t)slot * C::IMG;
+    CX* tab = reinterpret_cast<CX*>(smem_raw);  // W_n^j table (TWMODE 1), else unused
+    CX* img = reinterpret_cast<CX*>(smem_raw + C::TABLE_BYTES) + (size_t)slot * C::IMG;
     T* imgs = reinterpret_cast<T*>(img);
-    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + (size_t)C::T_PER_WG * C::IMG * sizeof(CX));
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + C::TABLE_BYTES + (size_t)C::T_PER_WG * C::IMG * sizeof(CX));
     const bool in_int = flags & 1, out_int = flags & 2;
-    constexpr int GROUPS = (2 * n / 4) / TPT;  // 4-scalar groups per thread (E/2)
-    typedef vec4<T> G4;
+    const bool plain_in = REAL ? (DIR == FWD) : !in_int;   // operand order of stage 0 straight from HBM
+    const bool plain_out = REAL ? (DIR == BWD) : !out_int;
 
+    typename K::Tw w;
+    K::load_tw(w, t, twg, twrg);
+    const CX* twt = twg;
+    if constexpr (C::TWMODE == 1) {
+        for (int i = threadIdx.x; i < n; i += C::WG_THREADS) tab[i] = twg[i];
+        twt = tab;
+    }
     unsigned pend = 0;
     if (threadIdx.x == 0) {
         s_next[0] = atomicAdd(&ctr[0], 1u);
@@ -190,158 +324,150 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
     }
     __syncthreads();
     unsigned g = s_next[0];
+    const size_t last = (size_t)batch - 1;
+    chunk16 raw[NCH];
+    {
+        size_t t0 = (size_t)g * C::T_PER_WG + slot;
+        K::load_raw(raw, in + (t0 < last ? t0 : last) * 2 * (size_t)n, t, plain_in);
+    }
     for (unsigned it = 0; (size_t)g * C::T_PER_WG < batch; ++it) {
         if (threadIdx.x == 0) {
             s_next[(it + 1) & 1] = pend;
             pend = atomicAdd(&ctr[0], 1u);
         }
         const size_t tr = (size_t)g * C::T_PER_WG + slot;
-        const bool active = tr < batch;
-        const size_t trc = active ? tr : (size_t)batch - 1;  // inactive slots recompute the last vector, never store
-        const T* src = in + trc * 2 * (size_t)n;
-        T* dst = out + trc * 2 * (size_t)n;
+        const bool active = tr < batch;  // inactive slots recompute the last vector and never store
+        T* dst = out + (active ? tr : last) * 2 * (size_t)n;
         CX v[E];
+        // The irregular layout maps (bin_of) are recomputed per iteration from an opaque copy of the thread
+        // index: hoisted out of the persistent loop they would pin one address register per scalar.
+        int tl = t;
+        asm volatile("" : "+v"(tl));
 
-        // ------------------------------------------------------------------ input adapters
-        const bool plain_in = REAL ? (DIR == FWD) : !in_int;  // time-domain input or canonical complex spectrum
+        // ------------------------------------------------------------------ input
         if (plain_in) {
             if constexpr (VEC == 2) {
-                const vec4<float>* s4 = reinterpret_cast<const vec4<float>*>(src);
 #pragma unroll
-                for (int i = 0; i < S0::B / 2; ++i)
+                for (int ii = 0; ii < S0::B / 2; ++ii)
 #pragma unroll
                     for (int q = 0; q < R0; ++q) {
-                        vec4<float> x = __builtin_nontemporal_load(s4 + t + TPT * i + q * (n / (2 * R0)));
-                        v[(2 * i) * R0 + q] = mk<T>(x.x, x.y);
-                        v[(2 * i + 1) * R0 + q] = mk<T>(x.z, x.w);
+                        const chunk16 c = raw[ii * R0 + q];
+                        v[(2 * ii) * R0 + q] = mk<T>(c.x, c.y);
+                        v[(2 * ii + 1) * R0 + q] = mk<T>(c.z, c.w);
                     }
             } else {
-                const vec2<double>* s2 = reinterpret_cast<const vec2<double>*>(src);
 #pragma unroll
-                for (int u = 0; u < S0::B; ++u)
-#pragma unroll
-                    for (int q = 0; q < R0; ++q) {
-                        vec2<double> x = __builtin_nontemporal_load(s2 + t + TPT * u + q * (n / R0));
-                        v[u * R0 + q] = mk<T>(x.x, x.y);
-                    }
+                for (int i = 0; i < NCH; ++i) v[i] = mk<T>(CO::get(raw[i], 0), CO::get(raw[i], 1));
             }
         } else {
-            // spectrum input that needs the LDS image first: linear 4-scalar groups -> natural-order bins
-            const G4* s4 = reinterpret_cast<const G4*>(src);
-            G4 gv[GROUPS];
+            // spectrum input: linear chunks -> natural-order image
 #pragma unroll
-            for (int i = 0; i < GROUPS; ++i) gv[i] = __builtin_nontemporal_load(s4 + t + TPT * i);
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tl + TPT * i;
+                if (in_int) {  // chunk c = scalars [c*CH, c*CH+CH) of the internal layout
+                    const int gi = (c * CH) >> 2, l0 = (c * CH) & 3, part = gi & 1;
 #pragma unroll
-            for (int i = 0; i < GROUPS; ++i) {
-                const int gi = t + TPT * i;
-                if (in_int) {
-                    const int part = gi & 1;
-                    imgs[2 * phys_nat<C>(bin_of(gi, 0, n, REAL)) + part] = gv[i].x;
-                    imgs[2 * phys_nat<C>(bin_of(gi, 1, n, REAL)) + part] = gv[i].y;
-                    imgs[2 * phys_nat<C>(bin_of(gi, 2, n, REAL)) + part] = gv[i].z;
-                    imgs[2 * phys_nat<C>(bin_of(gi, 3, n, REAL)) + part] = gv[i].w;
-                } else {
-                    img[phys_nat<C>(2 * gi)] = mk<T>(gv[i].x, gv[i].y);
-                    img[phys_nat<C>(2 * gi + 1)] = mk<T>(gv[i].z, gv[i].w);
+                    for (int s = 0; s < CH; ++s) imgs[2 * phys_nat<C>(bin_of(gi, l0 + s, n, REAL)) + part] = CO::get(raw[i], s);
+                } else {       // canonical: CH/2 consecutive bins
+                    if constexpr (VEC == 2) {
+                        img[phys_nat<C>(2 * c)] = mk<T>(raw[i].x, raw[i].y);
+                        img[phys_nat<C>(2 * c + 1)] = mk<T>(raw[i].z, raw[i].w);
+                    } else {
+                        img[phys_nat<C>(c)] = mk<T>(CO::get(raw[i], 0), CO::get(raw[i], 1));
+                    }
                 }
             }
-            Core::template xsync<TPT>();
+            K::xsync();
+            if constexpr (REAL) {
+                K::pair_pass(img, t, w, twrg);
+                K::xsync();
+            }
 #pragma unroll
             for (int u = 0; u < S0::B; ++u)
 #pragma unroll
                 for (int q = 0; q < R0; ++q) {
-                    const int k = S0::j(t, u) + q * (n / R0);
-                    if (!REAL) {
-                        v[u * R0 + q] = img[phys_nat<C>(k)];
-                    } else {  // real backward: Z'[k] = (A+B) + i conj(W_N^k) (A-B), A = X[k], B = conj X[n-k]
-                        CX A = img[phys_nat<C>(k)];
-                        if (k == 0) {
-                            v[u * R0 + q] = mk<T>(A.x + A.y, A.x - A.y);
-                        } else {
-                            CX Bc = conj(img[phys_nat<C>(n - k)]);
-                            CX S = A + Bc, Dm = A - Bc;
-                            // conj(W_N^k): k <= n/2 -> conj(twr[k]);  k > n/2 -> -twr[n-k]
-                            CX m = (k <= n / 2) ? cmulc(Dm, twr[k]) : cmul(Dm, twr[n - k]) * (T)-1;
-                            v[u * R0 + q] = mk<T>(S.x - m.y, S.y + m.x);  // S + i*m
-                        }
-                    }
+                    const int j = S0::j(t, u);
+                    v[u * R0 + q] = (img + j + C::PADN * (j >> 6))[K::nat_off(q * (n / R0))];
                 }
-            Core::template xsync<TPT>();
+            K::xsync();
         }
 
-        // ------------------------------------------------------------------ the transform
-        Core::run(v, t, img, tw);
-
-        __syncthreads();  // publishes s_next (and is a workgroup barrier for TPT > 64 images)
+        // ------------------------------------------------------------------ transform
+        K::template butterflies<0>(v, t, w, twt);
+        if constexpr (C::NS > 1) K::template xwrite<0>(v, t, img);
+        __syncthreads();  // publishes s_next; first half of exchange 0
         const unsigned gn = s_next[(it + 1) & 1];
+        if constexpr (C::PREFETCH) {  // the loads of the next transform fly while this one is finished
+            const size_t tn = (size_t)gn * C::T_PER_WG + slot;
+            K::load_raw(raw, in + (tn < last ? tn : last) * 2 * (size_t)n, t, plain_in);
+        }
+        if constexpr (C::NS > 1) { K::template xread<0>(v, t, img); K::xsync(); K::template butterflies<1>(v, t, w, twt); }
+        if constexpr (C::NS > 2) { K::template xwrite<1>(v, t, img); K::xsync(); K::template xread<1>(v, t, img); K::xsync(); K::template butterflies<2>(v, t, w, twt); }
+        if constexpr (C::NS > 3) { K::template xwrite<2>(v, t, img); K::xsync(); K::template xread<2>(v, t, img); K::xsync(); K::template butterflies<3>(v, t, w, twt); }
 
-        // ------------------------------------------------------------------ output adapters
-        const bool plain_out = REAL ? (DIR == BWD) : !out_int;
+        // ------------------------------------------------------------------ output
         if (plain_out) {
             if (active) {
+                chunk16* d16 = reinterpret_cast<chunk16*>(dst);
                 if constexpr (VEC == 2) {
-                    vec4<float>* d4 = reinterpret_cast<vec4<float>*>(dst);
 #pragma unroll
-                    for (int i = 0; i < SL::B / 2; ++i)
+                    for (int ii = 0; ii < SL::B / 2; ++ii)
 #pragma unroll
                         for (int d = 0; d < RL; ++d) {
-                            CX a = v[(2 * i) * RL + d], b = v[(2 * i + 1) * RL + d];
-                            vec4<float> x; x.x = a.x; x.y = a.y; x.z = b.x; x.w = b.y;
-                            __builtin_nontemporal_store(x, d4 + t + TPT * i + d * (n / (2 * RL)));
+                            const CX a = v[(2 * ii) * RL + d], b = v[(2 * ii + 1) * RL + d];
+                            chunk16 x; x.x = a.x; x.y = a.y; x.z = b.x; x.w = b.y;
+                            __builtin_nontemporal_store(x, d16 + t + TPT * ii + d * (n / (2 * RL)));
                         }
                 } else {
-                    vec2<double>* d2 = reinterpret_cast<vec2<double>*>(dst);
 #pragma unroll
                     for (int u = 0; u < SL::B; ++u)
 #pragma unroll
                         for (int d = 0; d < RL; ++d) {
-                            vec2<double> x; x.x = v[u * RL + d].x; x.y = v[u * RL + d].y;
-                            __builtin_nontemporal_store(x, d2 + t + TPT * u + d * (n / RL));
+                            chunk16 x;
+                            CO::set(x, 0, v[u * RL + d].x); CO::set(x, 1, v[u * RL + d].y);
+                            __builtin_nontemporal_store(x, d16 + t + TPT * u + d * (n / RL));
                         }
                 }
             }
         } else {
-            // canonical spectrum -> LDS image (natural order), then 4-scalar groups in output order
+            // canonical spectrum -> natural-order image -> (pair pass) -> linear chunks of the output layout
 #pragma unroll
             for (int u = 0; u < SL::B; ++u)
 #pragma unroll
-                for (int d = 0; d < RL; ++d) img[phys_nat<C>(SL::j(t, u) + d * (n / RL))] = v[u * RL + d];
-            Core::template xsync<TPT>();
-            G4* d4 = reinterpret_cast<G4*>(dst);
-#pragma unroll
-            for (int i = 0; i < GROUPS; ++i) {
-                const int gi = t + TPT * i;
-                G4 o;
-                if (!REAL) {  // complex, internal layout: part p of 4 consecutive bins
-                    const int part = gi & 1;
-                    o.x = imgs[2 * phys_nat<C>(bin_of(gi, 0, n, 0)) + part];
-                    o.y = imgs[2 * phys_nat<C>(bin_of(gi, 1, n, 0)) + part];
-                    o.z = imgs[2 * phys_nat<C>(bin_of(gi, 2, n, 0)) + part];
-                    o.w = imgs[2 * phys_nat<C>(bin_of(gi, 3, n, 0)) + part];
-                } else {      // real forward: X[k] = S + D, S = (A+B)/2, D = -(i/2) W_N^k (A-B)
-                    T r[4];
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) {
-                        const int k = out_int ? bin_of(gi, l, n, 1) : (2 * gi + (l >> 1));
-                        const int part = out_int ? (gi & 1) : (l & 1);
-                        CX A = img[phys_nat<C>(k)];
-                        CX X;
-                        if (k == 0) {
-                            X = mk<T>(A.x + A.y, A.x - A.y);
-                        } else {
-                            CX Bc = conj(img[phys_nat<C>(n - k)]);
-                            CX S = (A + Bc) * (T)0.5, Dm = (A - Bc) * (T)0.5;
-                            // W_N^k: k <= n/2 -> twr[k];  k > n/2 -> -conj(twr[n-k])
-                            CX m = (k <= n / 2) ? cmul(Dm, twr[k]) : cmulc(Dm, twr[n - k]) * (T)-1;
-                            X = mk<T>(S.x + m.y, S.y - m.x);  // S - i*m
-                        }
-                        r[l] = part ? X.y : X.x;
-                    }
-                    o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+                for (int d = 0; d < RL; ++d) {
+                    const int j = SL::j(t, u);
+                    (img + j + C::PADN * (j >> 6))[K::nat_off(d * (n / RL))] = v[u * RL + d];
                 }
-                if (active) __builtin_nontemporal_store(o, d4 + t + TPT * i);
+            K::xsync();
+            if constexpr (REAL) {
+                K::pair_pass(img, t, w, twrg);
+                K::xsync();
             }
-            Core::template xsync<TPT>();
+            chunk16* d16 = reinterpret_cast<chunk16*>(dst);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tl + TPT * i;
+                chunk16 o;
+                if (out_int) {
+                    const int gi = (c * CH) >> 2, l0 = (c * CH) & 3, part = gi & 1;
+#pragma unroll
+                    for (int s = 0; s < CH; ++s) CO::set(o, s, imgs[2 * phys_nat<C>(bin_of(gi, l0 + s, n, REAL)) + part]);
+                } else {
+                    if constexpr (VEC == 2) {
+                        const CX a = img[phys_nat<C>(2 * c)], b = img[phys_nat<C>(2 * c + 1)];
+                        o.x = a.x; o.y = a.y; o.z = b.x; o.w = b.y;
+                    } else {
+                        const CX a = img[phys_nat<C>(c)];
+                        CO::set(o, 0, a.x); CO::set(o, 1, a.y);
+                    }
+                }
+                if (active) __builtin_nontemporal_store(o, d16 + c);
+            }
+            K::xsync();
+        }
+        if constexpr (!C::PREFETCH) {
+            const size_t tn = (size_t)gn * C::T_PER_WG + slot;
+            K::load_raw(raw, in + (tn < last ? tn : last) * 2 * (size_t)n, t, plain_in);
         }
         g = gn;
     }
@@ -352,12 +478,23 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
     }
 }
 
-// ---- configurations: <T, log2 n, threads/transform, stages, radices...> ----
-template <typename T> using Tiled512 = TiledCfg<T, 9, 32, 3, 8, 8, 8, 1>;      // E = 16, two transforms per wave
-template <typename T> using Tiled1024 = TiledCfg<T, 10, 64, 3, 8, 16, 8, 1>;   // E = 16
-template <typename T> using Tiled2048 = TiledCfg<T, 11, 128, 4, 8, 4, 8, 8>;   // E = 16
-template <typename T> using Tiled4096 = TiledCfg<T, 12, 128, 3, 16, 16, 16, 1>;   // E = 32
-template <typename T> using Tiled8192 = TiledCfg<T, 13, 512, 4, 8, 8, 16, 8>;     // E = 16
-template <typename T> using Tiled16384 = TiledCfg<T, 14, 512, 4, 16, 8, 8, 16>;  // E = 32
+// ---- configurations: <T, log2 n, threads/transform, stages, R0..R3, PAD0, PADN, TWMODE, PREFETCH> ----
+template <typename T> struct TiledPick;
+template <> struct TiledPick<float> {
+    typedef TiledCfg<float, 9, 32, 3, 8, 8, 8, 1, 4, 4, 3, 1> C512;
+    typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 1> C1024;
+    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 1, 3, 1> C2048;
+    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 1, 3, 1> C4096;
+    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 1, 3, 1> C8192;
+    typedef TiledCfg<float, 14, 1024, 4, 8, 16, 16, 8, 4, 1, 3, 0> C16384;
+};
+template <> struct TiledPick<double> {
+    typedef TiledCfg<double, 9, 32, 3, 8, 8, 8, 1, 4, 0, 1, 0> C512;
+    typedef TiledCfg<double, 10, 64, 3, 8, 16, 8, 1, 4, 0, 1, 0> C1024;
+    typedef TiledCfg<double, 11, 128, 4, 8, 4, 8, 8, 4, 0, 1, 0, 256> C2048;
+    typedef TiledCfg<double, 12, 256, 4, 8, 8, 8, 8, 4, 0, 1, 0, 256> C4096;
+    typedef TiledCfg<double, 13, 512, 4, 8, 8, 16, 8, 4, 0, 3, 0> C8192;
+    typedef TiledCfg<double, 14, 1024, 4, 8, 16, 16, 8, 4, 0, 2, 0> C16384;  // (LDS too small: never dispatched)
+};
 
 }  // namespace pf

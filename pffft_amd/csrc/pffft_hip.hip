@@ -301,9 +301,8 @@ struct TiledEntry {
     size_t lds;
     int wg, t_per_wg;
 };
-template <typename T, template <typename> class CfgT>
+template <typename T, class C>
 static TiledEntry<T> tiled_entry(int dir, int real) {
-    typedef CfgT<T> C;
     TiledEntry<T> e;
     e.lds = C::LDS_BYTES; e.wg = C::WG_THREADS; e.t_per_wg = C::T_PER_WG;
     if (dir == PFFFT_FORWARD) e.fn = real ? fft_tiled_kernel<C, FWD, 1> : fft_tiled_kernel<C, FWD, 0>;
@@ -313,12 +312,12 @@ static TiledEntry<T> tiled_entry(int dir, int real) {
 template <typename T>
 static bool tiled_lookup(int n, int dir, int real, TiledEntry<T>* e) {
     switch (n) {
-        case 512: *e = tiled_entry<T, Tiled512>(dir, real); return true;
-        case 1024: *e = tiled_entry<T, Tiled1024>(dir, real); return true;
-        case 2048: *e = tiled_entry<T, Tiled2048>(dir, real); return true;
-        case 4096: *e = tiled_entry<T, Tiled4096>(dir, real); return true;
-        case 8192: *e = tiled_entry<T, Tiled8192>(dir, real); return true;
-        case 16384: *e = tiled_entry<T, Tiled16384>(dir, real); return true;
+        case 512: *e = tiled_entry<T, typename TiledPick<T>::C512>(dir, real); return true;
+        case 1024: *e = tiled_entry<T, typename TiledPick<T>::C1024>(dir, real); return true;
+        case 2048: *e = tiled_entry<T, typename TiledPick<T>::C2048>(dir, real); return true;
+        case 4096: *e = tiled_entry<T, typename TiledPick<T>::C4096>(dir, real); return true;
+        case 8192: *e = tiled_entry<T, typename TiledPick<T>::C8192>(dir, real); return true;
+        case 16384: *e = tiled_entry<T, typename TiledPick<T>::C16384>(dir, real); return true;
     }
     return false;
 }
