@@ -32,14 +32,14 @@ namespace pf {
 // TWMODE: 0 = every twiddle in registers, 1 = W_n^j table in LDS, 2 = global table (L2),
 //         3 = one base twiddle per butterfly in registers, its powers w^2..w^(R-1) recomputed (<= 4 products deep)
 template <typename T, int LOGN_, int TPT_, int NS_, int R0_, int R1_, int R2_, int R3_, int PAD0_, int PADN_,
-          int TWMODE_, int PREFETCH_, int WGT_ = 512>
+          int TWMODE_, int PREFETCH_, int WGT_ = 512, int OCC_ = 2>
 struct TiledCfg {
     typedef T real_t;
     static constexpr int LOGN = LOGN_, n = 1 << LOGN_, TPT = TPT_, E = n / TPT_, NS = NS_;
     static constexpr int VEC = 16 / (2 * (int)sizeof(T));  // complex points per 16 bytes: 2 float, 1 double
     static constexpr int CH = 16 / (int)sizeof(T);         // scalars per 16-byte chunk: 4 float, 2 double
     static constexpr int NCH = E * 2 / CH;                  // 16-byte chunks per thread
-    static constexpr int PAD0 = PAD0_, PADN = PADN_, TWMODE = TWMODE_, PREFETCH = PREFETCH_;
+    static constexpr int PAD0 = PAD0_, PADN = PADN_, TWMODE = TWMODE_, PREFETCH = PREFETCH_, OCC = OCC_;
     __host__ __device__ static constexpr int rad(int s) { return s == 0 ? R0_ : s == 1 ? R1_ : s == 2 ? R2_ : R3_; }
     __host__ __device__ static constexpr int ns(int s) {
         int p = 1;
@@ -163,6 +163,9 @@ struct Tiled {
             if constexpr (S > 0 && C::TWMODE == 3) {
                 CX p[R];  // p[q] = w^q, every power at most 4 products away from the table value
                 p[1] = w.r[C::tw_off(S) + u];
+                // opaque per iteration: otherwise the powers are hoisted out of the persistent loop and
+                // pinned in registers again (which is TWMODE 0 and spills)
+                asm volatile("" : "+v"(p[1].x), "+v"(p[1].y));
                 if constexpr (R > 2) { p[2] = cmul(p[1], p[1]); p[3] = cmul(p[2], p[1]); }
                 if constexpr (R > 4) { p[4] = cmul(p[2], p[2]); p[5] = cmul(p[4], p[1]); p[6] = cmul(p[3], p[3]); p[7] = cmul(p[4], p[3]); }
                 if constexpr (R > 8) {
@@ -287,7 +290,7 @@ struct Tiled {
 
 // flags: bit0 = input in internal layout, bit1 = output in internal layout
 template <class C, int DIR, int REAL>
-__global__ void __launch_bounds__(C::WG_THREADS, C::WG_THREADS >= 1024 ? 4 : 2)
+__global__ void __launch_bounds__(C::WG_THREADS, C::WG_THREADS >= 1024 ? 4 : C::OCC)
 fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned batch, int flags,
                  const cx<typename C::real_t>* __restrict__ twg, const cx<typename C::real_t>* __restrict__ twrg,
                  unsigned* ctr) {
@@ -487,6 +490,14 @@ template <> struct TiledPick<float> {
     typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 1, 3, 1> C4096;
     typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 1, 3, 1> C8192;
     typedef TiledCfg<float, 14, 1024, 4, 8, 16, 16, 8, 4, 1, 3, 0> C16384;
+};
+// experimental alternatives (pffft_hip_set_variant(20)): no register prefetch, 128-VGPR budget, two
+// workgroups per CU so that independent transforms overlap each other's barrier phases
+struct TiledAltF32 {
+    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 1, 3, 0, 256, 4> C2048;
+    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 1, 3, 0, 256, 4> C4096;
+    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 1, 3, 0, 512, 4> C8192;
+    typedef TiledCfg<float, 13, 256, 4, 8, 8, 8, 16, 4, 1, 3, 0, 256, 2> C8192b;  // E = 32
 };
 template <> struct TiledPick<double> {
     typedef TiledCfg<double, 9, 32, 3, 8, 8, 8, 1, 4, 0, 1, 0> C512;
