@@ -77,6 +77,17 @@ template <class C> __device__ __forceinline__ int phys_trn(int P) {  // image af
     return (P & (R0 - 1)) * (C::n / R0 + C::PAD0) + (P / R0);
 }
 
+// LDS accesses of one complex point as ONE typed vector access (struct copies of cx<T> through memory
+// left type-punned private allocas behind = scratch traffic in the hot loop)
+template <typename T> __device__ __forceinline__ void lds_st(cx<T>* p, cx<T> v) {
+    vec2<T> x; x.x = v.x; x.y = v.y;
+    *reinterpret_cast<vec2<T>*>(p) = x;
+}
+template <typename T> __device__ __forceinline__ cx<T> lds_ld(const cx<T>* p) {
+    const vec2<T> x = *reinterpret_cast<const vec2<T>*>(p);
+    return mk<T>(x.x, x.y);
+}
+
 typedef vec4<float> chunk16;  // a 16-byte register quantum, reinterpreted per precision
 
 template <typename T> struct ChunkOps;
@@ -105,7 +116,22 @@ struct Tiled {
     static constexpr int n = C::n, E = C::E, TPT = C::TPT, VEC = C::VEC, CH = C::CH, NCH = C::NCH;
     static constexpr int R0 = S0::R, RL = SL::R;
     static constexpr bool REGTW = C::TWMODE == 0 || C::TWMODE == 3;
-    static constexpr int NPT = (REAL && REGTW) ? E / 2 : 1;  // pair-pass twiddles per thread
+    // Real transforms: the stage next to the half-complex spectrum (last stage forward, first stage
+    // backward) uses the SYMMETRIC butterfly assignment  thread t -> butterflies { t, n/R - t }  (thread 0:
+    // { 0, n/(2R) }).  Bin k = j + d n/R and its mirror n - k = (n/R - j) + (R-1-d) n/R then live in the same
+    // thread, so the pair pass  X[k], X[n-k] <-> Z[k], Z[n-k]  runs in registers, with no LDS round trip.
+    static constexpr int RS = (DIR == FWD) ? RL : R0;                 // radix of that stage
+    static constexpr int SYM_STAGE = REAL ? ((DIR == FWD) ? C::NS - 1 : 0) : -1;
+    static_assert(!REAL || E / RS == 2, "real transforms need exactly two butterflies per thread in the spectrum-side stage");
+    static constexpr int NPT = REAL ? RS : 1;  // pair-pass twiddles per thread
+    template <int S> static __device__ __forceinline__ int jm(int t, int u) {
+        if constexpr (S == SYM_STAGE) {
+            constexpr int nb = n / C::rad(S);
+            return u == 0 ? t : (t == 0 ? nb / 2 : nb - t);
+        } else {
+            return StageInfo<C, S>::j(t, u);
+        }
+    }
 
     struct Tw {
         CX r[C::TW_COUNT > 0 ? C::TW_COUNT : 1];
@@ -123,7 +149,7 @@ struct Tiled {
             constexpr int R = SI::R, Ns = SI::Ns, step = n / (Ns * R), off = C::tw_off(S);
 #pragma unroll
             for (int u = 0; u < SI::B; ++u) {
-                const int k = SI::j(t, u) & (Ns - 1);
+                const int k = jm<S>(t, u) & (Ns - 1);
                 if constexpr (C::TWMODE == 3) w.r[off + u] = twg[k * step];
                 else {
 #pragma unroll
@@ -136,9 +162,16 @@ struct Tiled {
     static __device__ __forceinline__ void load_tw(Tw& w, int t, const CX* __restrict__ twg, const CX* __restrict__ twrg) {
         if constexpr (REGTW) {
             load_tw_stage<1>(w, t, twg);
-            if constexpr (REAL) {
+        }
+        if constexpr (REAL) {
+            // W_N^k of the RS mirror pairs this thread owns (pair_regs): t != 0: k = t + d n/RS;
+            // thread 0: butterfly 0 pairs d = 1..RS/2-1 at k = d n/RS, butterfly 1 pairs d = 0..RS/2-1 at
+            // k = (2d+1) n/(2 RS).  The table holds k <= n/2; W_N^k = -conj(W_N^(n-k)) beyond.
 #pragma unroll
-                for (int i = 0; i < E / 2; ++i) w.p[i] = twrg[t + TPT * i];
+            for (int d = 0; d < RS; ++d) {
+                int k = t + d * (n / RS);
+                if (t == 0) k = d < RS / 2 ? d * (n / RS) : (2 * (d - RS / 2) + 1) * (n / (2 * RS));
+                w.p[d] = k <= n / 2 ? twrg[k] : conj(twrg[n - k]) * (T)-1;
             }
         }
     }
@@ -146,7 +179,7 @@ struct Tiled {
         typedef StageInfo<C, S> SI;
         if constexpr (C::TWMODE == 0) return w.r[C::tw_off(S) + u * (SI::R - 1) + (q - 1)];
         else {
-            const int k = SI::j(t, u) & (SI::Ns - 1);
+            const int k = jm<S>(t, u) & (SI::Ns - 1);
             return tab[(q * k) * (n / (SI::Ns * SI::R))];
         }
     }
@@ -197,16 +230,16 @@ struct Tiled {
         constexpr int R = SW::R, Ns = SW::Ns, ROW = n / R0 + C::PAD0;
 #pragma unroll
         for (int u = 0; u < SW::B; ++u) {
-            const int j = SW::j(t, u);
+            const int j = jm<S>(t, u);
             if constexpr (S == 0) {  // P = j*R0 + d -> row d, column j
                 CX* p = img + j;
 #pragma unroll
-                for (int d = 0; d < R; ++d) p[d * ROW] = v[u * R + d];
+                for (int d = 0; d < R; ++d) lds_st(p + d * ROW, v[u * R + d]);
             } else {
                 const int Ha = (j / Ns) * (Ns * R) + (j & (Ns - 1));
                 CX* p = img + Ha + C::PADN * (Ha >> 6);
 #pragma unroll
-                for (int d = 0; d < R; ++d) p[nat_off(d * Ns)] = v[u * R + d];
+                for (int d = 0; d < R; ++d) lds_st(p + nat_off(d * Ns), v[u * R + d]);
             }
         }
     }
@@ -217,15 +250,15 @@ struct Tiled {
         static_assert((n / R2) % R0 == 0, "operand stride must be a multiple of R0");
 #pragma unroll
         for (int u = 0; u < SR::B; ++u) {
-            const int j = SR::j(t, u);
+            const int j = jm<S + 1>(t, u);
             if constexpr (S == 0) {  // P = j + q n/R2 -> row P mod R0 = j mod R0, column j div R0 + q n/(R2 R0)
                 const CX* p = img + (j & (R0 - 1)) * ROW + (j / R0);
 #pragma unroll
-                for (int q = 0; q < R2; ++q) v[u * R2 + q] = p[q * (n / (R2 * R0))];
+                for (int q = 0; q < R2; ++q) v[u * R2 + q] = lds_ld(p + q * (n / (R2 * R0)));
             } else {
                 const CX* p = img + j + C::PADN * (j >> 6);
 #pragma unroll
-                for (int q = 0; q < R2; ++q) v[u * R2 + q] = p[nat_off(q * (n / R2))];
+                for (int q = 0; q < R2; ++q) v[u * R2 + q] = lds_ld(p + nat_off(q * (n / R2)));
             }
         }
     }
@@ -251,40 +284,51 @@ struct Tiled {
         }
     }
 
-    // in-place pair pass on the natural-order image (real transforms)
-    static __device__ __forceinline__ void pair_pass(CX* img, int t, const Tw& w, const CX* __restrict__ twrg) {
-        // k = t + TPT i and n - k: two base pointers + compile-time offsets (TPT i is a multiple of 64)
-        CX* const pk = img + t + C::PADN * (t >> 6);
-        CX* const pn = img + (n - t) + C::PADN * ((n - t) >> 6);
-        constexpr bool AFF = (TPT % 64 == 0);
-#pragma unroll
-        for (int i = 0; i < E / 2; ++i) {
-            const int k = t + TPT * i;
-            CX* const qk = AFF ? pk + nat_off(TPT * i) : img + phys_nat<C>(k);
-            CX* const qn = AFF ? pn - nat_off(TPT * i) : img + phys_nat<C>(n - k);
-            if (k == 0) {
-                CX a = img[phys_nat<C>(0)];
-                img[phys_nat<C>(0)] = mk<T>(a.x + a.y, a.x - a.y);  // (DC, Nyquist) <-> Z[0], both directions
-                CX h = img[phys_nat<C>(n / 2)];
-                img[phys_nat<C>(n / 2)] = DIR == FWD ? conj(h) : mk<T>((T)2 * h.x, (T)-2 * h.y);
-            } else {
-                CX wk;
-                if constexpr (REGTW) wk = w.p[i]; else wk = twrg[k];
-                CX A = *qk, Bc = conj(*qn);
-                CX S, D;
-                if (DIR == FWD) {
-                    S = (A + Bc) * (T)0.5;
-                    CX m = cmul((A - Bc) * (T)0.5, wk);
-                    D = mk<T>(m.y, -m.x);  // * (-i)
-                } else {
-                    S = A + Bc;
-                    CX m = cmulc(A - Bc, wk);
-                    D = mk<T>(-m.y, m.x);  // * (+i)
-                }
-                *qk = S + D;
-                *qn = conj(S - D);
-            }
+    // one mirror pair: a holds the bin k, b the bin n-k (spectrum X forward-out / backward-in, packed Z on the other side)
+    struct Pair { CX a, b; };
+    static __device__ __forceinline__ Pair pair1(CX A, CX Bin, CX wk) {
+        const CX Bc = conj(Bin);
+        CX S, D;
+        if (DIR == FWD) {  // X[k] = S + D, S = (A+B)/2, D = -(i/2) W_N^k (A-B)
+            S = (A + Bc) * (T)0.5;
+            const CX m = cmul((A - Bc) * (T)0.5, wk);
+            D = mk<T>(m.y, -m.x);
+        } else {           // Z'[k] = S + D, S = A+B, D = i conj(W_N^k) (A-B)
+            S = A + Bc;
+            const CX m = cmulc(A - Bc, wk);
+            D = mk<T>(-m.y, m.x);
         }
+        Pair r;
+        r.a = S + D;
+        r.b = conj(S - D);
+        return r;
+    }
+    // in-register pair pass on the symmetric stage's operands: v[u*RS + d] = bin jm(t,u) + d n/RS.
+    // Branch-free: every thread evaluates the regular pairing (bin of butterfly 0 with its mirror in
+    // butterfly 1) and the pairing of thread 0 (both of its butterflies are self-mirrored), then selects.
+    static __device__ __forceinline__ CX sel(bool c, CX a, CX b) { return mk<T>(c ? a.x : b.x, c ? a.y : b.y); }
+    static __device__ __forceinline__ void pair_regs(CX (&v)[E], int t, const Tw& w) {
+        CX r0[2 * RS], r1[2 * RS];
+#pragma unroll
+        for (int d = 0; d < RS; ++d) {
+            const Pair r = pair1(v[d], v[RS + (RS - 1 - d)], w.p[d]);
+            r0[d] = r.a; r0[RS + (RS - 1 - d)] = r.b;
+        }
+        r1[0] = mk<T>(v[0].x + v[0].y, v[0].x - v[0].y);  // bin 0 <-> (DC, Nyquist), the same map in both directions
+#pragma unroll
+        for (int d = 1; d < RS / 2; ++d) {
+            const Pair r = pair1(v[d], v[RS - d], w.p[d]);
+            r1[d] = r.a; r1[RS - d] = r.b;
+        }
+        r1[RS / 2] = DIR == FWD ? conj(v[RS / 2]) : mk<T>((T)2 * v[RS / 2].x, (T)-2 * v[RS / 2].y);  // k = n/2
+#pragma unroll
+        for (int d = 0; d < RS / 2; ++d) {
+            const Pair r = pair1(v[RS + d], v[RS + (RS - 1 - d)], w.p[RS / 2 + d]);
+            r1[RS + d] = r.a; r1[RS + (RS - 1 - d)] = r.b;
+        }
+        const bool first = (t == 0);
+#pragma unroll
+        for (int i = 0; i < 2 * RS; ++i) v[i] = sel(first, r1[i], r0[i]);
     }
 };
 
@@ -303,6 +347,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
     constexpr int n = C::n, E = C::E, TPT = C::TPT, VEC = C::VEC, CH = C::CH, NCH = C::NCH;
     constexpr int R0 = K::R0, RL = K::RL;
     static_assert(VEC == 1 || (S0::PAIR && SL::PAIR), "float configs need an even butterfly count in the first/last stage");
+    static_assert(!REAL || ((n / RL) % 64 == 0 && (n / R0) % 64 == 0) || C::PADN == 0, "pad period vs operand stride");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int slot = threadIdx.x / TPT, t = threadIdx.x % TPT;
     CX* tab = reinterpret_cast<CX*>(smem_raw);  // W_n^j table (TWMODE 1), else unused
@@ -373,26 +418,23 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
                     for (int s = 0; s < CH; ++s) imgs[2 * phys_nat<C>(bin_of(gi, l0 + s, n, REAL)) + part] = CO::get(raw[i], s);
                 } else {       // canonical: CH/2 consecutive bins
                     if constexpr (VEC == 2) {
-                        img[phys_nat<C>(2 * c)] = mk<T>(raw[i].x, raw[i].y);
-                        img[phys_nat<C>(2 * c + 1)] = mk<T>(raw[i].z, raw[i].w);
+                        lds_st(img + phys_nat<C>(2 * c), mk<T>(raw[i].x, raw[i].y));
+                        lds_st(img + phys_nat<C>(2 * c + 1), mk<T>(raw[i].z, raw[i].w));
                     } else {
-                        img[phys_nat<C>(c)] = mk<T>(CO::get(raw[i], 0), CO::get(raw[i], 1));
+                        lds_st(img + phys_nat<C>(c), mk<T>(CO::get(raw[i], 0), CO::get(raw[i], 1)));
                     }
                 }
             }
             K::xsync();
-            if constexpr (REAL) {
-                K::pair_pass(img, t, w, twrg);
-                K::xsync();
-            }
 #pragma unroll
             for (int u = 0; u < S0::B; ++u)
 #pragma unroll
                 for (int q = 0; q < R0; ++q) {
-                    const int j = S0::j(t, u);
-                    v[u * R0 + q] = (img + j + C::PADN * (j >> 6))[K::nat_off(q * (n / R0))];
+                    const int j = K::template jm<0>(t, u);
+                    v[u * R0 + q] = lds_ld(img + j + C::PADN * (j >> 6) + K::nat_off(q * (n / R0)));
                 }
             K::xsync();
+            if constexpr (REAL) K::pair_regs(v, t, w);  // half-complex spectrum -> packed spectrum, in registers
         }
 
         // ------------------------------------------------------------------ transform
@@ -433,19 +475,16 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
                 }
             }
         } else {
-            // canonical spectrum -> natural-order image -> (pair pass) -> linear chunks of the output layout
+            // (real: pair pass in registers) canonical spectrum -> natural-order image -> linear chunks of the output layout
+            if constexpr (REAL) K::pair_regs(v, t, w);
 #pragma unroll
             for (int u = 0; u < SL::B; ++u)
 #pragma unroll
                 for (int d = 0; d < RL; ++d) {
-                    const int j = SL::j(t, u);
-                    (img + j + C::PADN * (j >> 6))[K::nat_off(d * (n / RL))] = v[u * RL + d];
+                    const int j = K::template jm<C::NS - 1>(t, u);
+                    lds_st(img + j + C::PADN * (j >> 6) + K::nat_off(d * (n / RL)), v[u * RL + d]);
                 }
             K::xsync();
-            if constexpr (REAL) {
-                K::pair_pass(img, t, w, twrg);
-                K::xsync();
-            }
             chunk16* d16 = reinterpret_cast<chunk16*>(dst);
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
@@ -457,10 +496,10 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
                     for (int s = 0; s < CH; ++s) CO::set(o, s, imgs[2 * phys_nat<C>(bin_of(gi, l0 + s, n, REAL)) + part]);
                 } else {
                     if constexpr (VEC == 2) {
-                        const CX a = img[phys_nat<C>(2 * c)], b = img[phys_nat<C>(2 * c + 1)];
+                        const CX a = lds_ld(img + phys_nat<C>(2 * c)), b = lds_ld(img + phys_nat<C>(2 * c + 1));
                         o.x = a.x; o.y = a.y; o.z = b.x; o.w = b.y;
                     } else {
-                        const CX a = img[phys_nat<C>(c)];
+                        const CX a = lds_ld(img + phys_nat<C>(c));
                         CO::set(o, 0, a.x); CO::set(o, 1, a.y);
                     }
                 }
@@ -497,7 +536,6 @@ struct TiledAltF32 {
     typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 1, 3, 0, 256, 4> C2048;
     typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 1, 3, 0, 256, 4> C4096;
     typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 1, 3, 0, 512, 4> C8192;
-    typedef TiledCfg<float, 13, 256, 4, 8, 8, 8, 16, 4, 1, 3, 0, 256, 2> C8192b;  // E = 32
 };
 template <> struct TiledPick<double> {
     typedef TiledCfg<double, 9, 32, 3, 8, 8, 8, 1, 4, 0, 1, 0> C512;

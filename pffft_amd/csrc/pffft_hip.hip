@@ -312,14 +312,15 @@ static TiledEntry<T> tiled_entry(int dir, int real) {
 template <typename T>
 static bool tiled_lookup(int n, int dir, int real, TiledEntry<T>* e) {
     if constexpr (sizeof(T) == 4) {
-        if (g_variant == 20) {
+        // real transforms of n >= 2048 points: the no-prefetch / two-workgroups-per-CU variants measure
+        // 10-30 % faster (gpurun_out/tiled3.log); complex ones keep the prefetching variants
+        if ((real && g_variant != 22) || g_variant == 20) {
             switch (n) {
                 case 2048: *e = tiled_entry<T, TiledAltF32::C2048>(dir, real); return true;
                 case 4096: *e = tiled_entry<T, TiledAltF32::C4096>(dir, real); return true;
                 case 8192: *e = tiled_entry<T, TiledAltF32::C8192>(dir, real); return true;
             }
         }
-        if (g_variant == 21 && n == 8192) { *e = tiled_entry<T, TiledAltF32::C8192b>(dir, real); return true; }
     }
     switch (n) {
         case 512: *e = tiled_entry<T, typename TiledPick<T>::C512>(dir, real); return true;
