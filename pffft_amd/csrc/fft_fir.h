@@ -1,0 +1,182 @@
+// Fused overlap-save FIR block kernel (pffastconv): for every block of the signal
+//     gather (zero padded) -> real FFT -> x Hf * 1/Nfft -> inverse real FFT -> scatter of the valid samples
+// in ONE kernel, one HBM read of the block and one write of its valid outputs.
+//
+// Reference: the block loop of pffastconv_apply, src/pffastconv.c:207-261 (copy + zero pad :231-233,
+// pffft_transform forward :235, pffft_zconvolve_no_accu :238, pffft_transform backward :254, copy of numOut
+// samples :255), which walks the blocks one at a time through three separate sweeps over Nfft floats.
+//
+// Built from the register-tiled transform (fft_tiled.h) with n = Nfft/2 complex points.  Because the
+// spectrum-side stage of BOTH directions uses the symmetric butterfly assignment, a thread that finishes
+// the forward transform holds exactly the bins (k and n-k pairs) whose products the first backward
+// butterflies need: forward pair pass, multiplication with the filter spectrum and backward pair pass all
+// happen in registers — no layout, no LDS exchange between the two transforms.  The filter spectrum
+// (canonical order, pre-scaled by 1/Nfft) sits in registers for the whole persistent loop.
+#pragma once
+#include "fft_tiled.h"
+
+namespace pf {
+
+#ifdef PF_FIR_DEBUG
+__device__ long long pf_dbg[64];
+#define PF_STAMP(i) do { if (blockIdx.x == 7 && threadIdx.x == 0) pf_dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PF_STAMP(i) do { } while (0)
+#endif
+
+struct __attribute__((packed, aligned(4))) F4u { float a, b, c, d; };  // block offsets are multiples of 4 bytes only
+
+template <class C>
+__global__ void __launch_bounds__(C::WG_THREADS, 2)
+fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const cx<float>* __restrict__ Hc,
+                      int nblk, int step, int inputLen, int lastOut,
+                      const cx<float>* __restrict__ twg, const cx<float>* __restrict__ twrg, unsigned* ctr) {
+    typedef float T;
+    typedef cx<T> CX;
+    typedef Tiled<C, FWD, 1> KF;
+    typedef Tiled<C, BWD, 1> KB;
+    constexpr int n = C::n, E = C::E, TPT = C::TPT, NS = C::NS;
+    constexpr int R0 = C::rad(0), RL = C::rad(NS - 1);
+    static_assert(R0 == RL && E / R0 == 2 && C::VEC == 2, "fused FIR needs R0 == RL, two butterflies per thread, float");
+    constexpr int Nfft = 2 * n;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int slot = threadIdx.x / TPT, t = threadIdx.x % TPT;
+    CX* img = reinterpret_cast<CX*>(smem_raw + C::TABLE_BYTES) + (size_t)slot * C::IMG;
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + C::TABLE_BYTES + (size_t)C::T_PER_WG * C::IMG * sizeof(CX));
+
+    PF_STAMP(0);
+    typename KF::Tw wf;
+    typename KB::Tw wb;
+    KF::load_tw(wf, t, twg, twrg);
+    KB::load_tw(wb, t, twg, twrg);
+    // filter spectrum of the bins this thread owns after the forward transform: k = jm(t,u) + d n/R
+    CX h[E];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int d = 0; d < RL; ++d) h[u * RL + d] = Hc[KF::template jm<NS - 1>(t, u) + d * (n / RL)];
+
+    // ctr == nullptr: static assignment (grid covers every block group once) — no atomics on the latency path
+    const bool dyn = ctr != nullptr;
+    unsigned pend = 0;
+    unsigned g = blockIdx.x;
+    if (dyn) {
+        if (threadIdx.x == 0) {
+            s_next[0] = atomicAdd(&ctr[0], 1u);
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        __syncthreads();
+        g = s_next[0];
+    }
+    for (unsigned it = 0; (int)(g * C::T_PER_WG) < nblk; ++it) {
+        if (dyn && threadIdx.x == 0) {
+            s_next[(it + 1) & 1] = pend;
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        const int blk = (int)(g * C::T_PER_WG) + slot;
+        const bool active = blk < nblk;
+        const long off = (long)(active ? blk : nblk - 1) * step;  // first input / output sample of the block
+        const int numOut = (active && blk == nblk - 1) ? lastOut : step;
+        CX v[E];
+        PF_STAMP(1);
+        // ---- gather: stage-0 operand order, zero beyond the end of the signal (src/pffastconv.c:231-233) ----
+        {
+            const float* src = x + off;
+            const long avail = (long)inputLen - off;  // samples of this block that exist
+#pragma unroll
+            for (int ii = 0; ii < 1; ++ii)
+#pragma unroll
+                for (int q = 0; q < R0; ++q) {
+                    const int e0 = 4 * (t + TPT * ii + q * (n / (2 * R0)));  // first of 4 consecutive samples
+                    float f0, f1, f2, f3;
+                    if (e0 + 3 < avail) {
+                        const F4u q4 = *reinterpret_cast<const F4u*>(src + e0);  // 16 bytes, 4-byte aligned
+                        f0 = q4.a; f1 = q4.b; f2 = q4.c; f3 = q4.d;
+                    } else {
+                        f0 = e0 < avail ? src[e0] : 0.f; f1 = e0 + 1 < avail ? src[e0 + 1] : 0.f;
+                        f2 = e0 + 2 < avail ? src[e0 + 2] : 0.f; f3 = e0 + 3 < avail ? src[e0 + 3] : 0.f;
+                    }
+                    v[(2 * ii) * R0 + q] = mk<T>(f0, f1);
+                    v[(2 * ii + 1) * R0 + q] = mk<T>(f2, f3);
+                }
+        }
+        // ---- forward transform ----
+        KF::template butterflies<0>(v, t, wf, twg);
+        PF_STAMP(2);
+        KF::template xwrite<0>(v, t, img);
+        __syncthreads();
+        PF_STAMP(3);
+        const unsigned gn = dyn ? s_next[(it + 1) & 1] : g + gridDim.x;
+        KF::template xread<0>(v, t, img); KF::xsync(); KF::template butterflies<1>(v, t, wf, twg);
+        if constexpr (NS > 2) { KF::template xwrite<1>(v, t, img); KF::xsync(); KF::template xread<1>(v, t, img); KF::xsync(); KF::template butterflies<2>(v, t, wf, twg); }
+        if constexpr (NS > 3) { KF::template xwrite<2>(v, t, img); KF::xsync(); KF::template xread<2>(v, t, img); KF::xsync(); KF::template butterflies<3>(v, t, wf, twg); }
+        PF_STAMP(4);
+        KF::pair_regs(v, t, wf);                       // packed spectrum -> half-complex spectrum X[k]
+        // ---- X[k] * H[k] (already scaled by 1/Nfft, src/pffastconv.c:97,238); bin 0 carries (DC, Nyquist),
+        //      two real products (src/pffft_priv_impl.h:1680-1683) ----
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const CX p = cmul(v[i], h[i]);
+            if (i == 0) {
+                const CX r = mk<T>(v[0].x * h[0].x, v[0].y * h[0].y);
+                v[0] = KF::sel(t == 0, r, p);
+            } else {
+                v[i] = p;
+            }
+        }
+        PF_STAMP(5);
+        KB::pair_regs(v, t, wb);                       // half-complex spectrum -> packed spectrum of the inverse
+        PF_STAMP(6);
+        // ---- backward transform (first-stage operands are already in place) ----
+        KB::template butterflies<0>(v, t, wb, twg);
+        KB::template xwrite<0>(v, t, img); KB::xsync();
+        KB::template xread<0>(v, t, img); KB::xsync(); KB::template butterflies<1>(v, t, wb, twg);
+        if constexpr (NS > 2) { KB::template xwrite<1>(v, t, img); KB::xsync(); KB::template xread<1>(v, t, img); KB::xsync(); KB::template butterflies<2>(v, t, wb, twg); }
+        if constexpr (NS > 3) { KB::template xwrite<2>(v, t, img); KB::xsync(); KB::template xread<2>(v, t, img); KB::xsync(); KB::template butterflies<3>(v, t, wb, twg); }
+        PF_STAMP(7);
+        // ---- scatter the first numOut samples (src/pffastconv.c:255) ----
+        if (active) {
+            float* dst = y + off;
+#pragma unroll
+            for (int ii = 0; ii < 1; ++ii)
+#pragma unroll
+                for (int d = 0; d < RL; ++d) {
+                    const int e0 = 4 * (t + TPT * ii + d * (n / (2 * RL)));
+                    const CX a = v[(2 * ii) * RL + d], b = v[(2 * ii + 1) * RL + d];
+                    if (e0 + 3 < numOut) {
+                        F4u q4; q4.a = a.x; q4.b = a.y; q4.c = b.x; q4.d = b.y;
+                        *reinterpret_cast<F4u*>(dst + e0) = q4;
+                    } else {
+                        if (e0 < numOut) dst[e0] = a.x;
+                        if (e0 + 1 < numOut) dst[e0 + 1] = a.y;
+                        if (e0 + 2 < numOut) dst[e0 + 2] = b.x;
+                    }
+                }
+        }
+        KB::xsync();
+        PF_STAMP(8);
+        g = gn;
+    }
+    if (dyn && threadIdx.x == 0) {
+        __threadfence();
+        unsigned d = atomicAdd(&ctr[1], 1u);
+        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+    (void)Nfft;
+}
+
+// scale a canonical half-complex spectrum (n bins) into the table the fused kernel multiplies with
+__global__ void fastconv_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int count, float s) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) out[i] = in[i] * s;
+}
+
+// FIR configurations: WG = one block (TPT threads) so that a call with few blocks still spreads over the chip
+struct FirCfg {
+    typedef TiledCfg<float, 9, 32, 3, 8, 8, 8, 1, 4, 4, 3, 0, 64, 2> C512;
+    typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 0, 64, 2> C1024;
+    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 1, 3, 0, 128, 2> C2048;
+    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 1, 3, 0, 256, 2> C4096;
+    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 1, 3, 0, 512, 2> C8192;
+};
+
+}  // namespace pf

@@ -365,13 +365,17 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
         for (int i = threadIdx.x; i < n; i += C::WG_THREADS) tab[i] = twg[i];
         twt = tab;
     }
+    // ctr == nullptr: static assignment (the grid covers every group exactly once): small batches are
+    // latency-bound and skip the atomics; otherwise groups are pulled in order from the counter
+    const bool dyn = ctr != nullptr;
     unsigned pend = 0;
-    if (threadIdx.x == 0) {
+    unsigned g = blockIdx.x;
+    if (dyn && threadIdx.x == 0) {
         s_next[0] = atomicAdd(&ctr[0], 1u);
         pend = atomicAdd(&ctr[0], 1u);
     }
     __syncthreads();
-    unsigned g = s_next[0];
+    if (dyn) g = s_next[0];
     const size_t last = (size_t)batch - 1;
     chunk16 raw[NCH];
     {
@@ -379,7 +383,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
         K::load_raw(raw, in + (t0 < last ? t0 : last) * 2 * (size_t)n, t, plain_in);
     }
     for (unsigned it = 0; (size_t)g * C::T_PER_WG < batch; ++it) {
-        if (threadIdx.x == 0) {
+        if (dyn && threadIdx.x == 0) {
             s_next[(it + 1) & 1] = pend;
             pend = atomicAdd(&ctr[0], 1u);
         }
@@ -441,7 +445,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
         K::template butterflies<0>(v, t, w, twt);
         if constexpr (C::NS > 1) K::template xwrite<0>(v, t, img);
         __syncthreads();  // publishes s_next; first half of exchange 0
-        const unsigned gn = s_next[(it + 1) & 1];
+        const unsigned gn = dyn ? s_next[(it + 1) & 1] : g + gridDim.x;
         if constexpr (C::PREFETCH) {  // the loads of the next transform fly while this one is finished
             const size_t tn = (size_t)gn * C::T_PER_WG + slot;
             K::load_raw(raw, in + (tn < last ? tn : last) * 2 * (size_t)n, t, plain_in);
@@ -513,7 +517,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
         }
         g = gn;
     }
-    if (threadIdx.x == 0) {
+    if (dyn && threadIdx.x == 0) {
         __threadfence();
         unsigned d = atomicAdd(&ctr[1], 1u);
         if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }

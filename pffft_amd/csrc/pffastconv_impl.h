@@ -8,6 +8,7 @@
 //   gather -> rFFT fwd (internal layout) -> x Hf * 1/Nfft -> rFFT bwd -> scatter.
 // (included at the end of pffft_hip.hip)
 #pragma once
+#include "fft_fir.h"
 
 namespace pf {
 
@@ -20,6 +21,7 @@ struct FastConv {
     std::vector<float> h_filter_image;  // time-domain image the reference builds in Xt (:99-106)
     std::mutex mu;
     float* d_Hf = nullptr;
+    float* d_Hc = nullptr;  // canonical-order filter spectrum * 1/Nfft for the fused kernel
     float* d_work = nullptr; size_t work_floats = 0;
     float* d_x = nullptr; size_t x_floats = 0;
     float* d_y = nullptr; size_t y_floats = 0;
@@ -76,7 +78,33 @@ static int fc_ensure_device(FastConv* s) {
     PF_CHECK(hipMemcpy(s->d_Hf, s->h_filter_image.data(), sizeof(float) * s->Nfft, hipMemcpyHostToDevice));
     int rc = transform_batch<float>(s->st, s->d_Hf, s->d_Hf, 1, PFFFT_FORWARD, 0, nullptr);  // :108
     if (rc) return rc;
+    // fused path: canonical order (pffft_zreorder) and the 1/Nfft scale folded into the table
+    PF_CHECK(hipMalloc((void**)&s->d_Hc, sizeof(float) * s->Nfft));
+    rc = zreorder_batch<float>(s->st, s->d_Hf, s->d_Hc, 1, PFFFT_FORWARD, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fastconv_scale_kernel, dim3(64), dim3(256), 0, nullptr, s->d_Hc, s->d_Hc, s->Nfft, s->scale);
+    PF_CHECK(hipGetLastError());
     PF_CHECK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+template <class C>
+static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
+                           hipStream_t st) {
+    auto k = fastconv_fused_kernel<C>;
+    int rc = allow_big_lds(k, C::LDS_BYTES);
+    if (rc) return rc;
+    int per_cu = 0;
+    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, C::LDS_BYTES));
+    if (per_cu < 1) per_cu = 1;
+    size_t groups = ((size_t)nblk + C::T_PER_WG - 1) / C::T_PER_WG;
+    size_t grid = (size_t)num_cus() * per_cu;
+    if (grid > groups) grid = groups;
+    Setup* ps = s->st;
+    unsigned* ctr = groups <= grid ? nullptr : ps->d_ctr + 2 * (ps->ctr_slot.fetch_add(1) % CTR_RING);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), C::LDS_BYTES, st, d_x, d_y, (const cx<float>*)s->d_Hc,
+                       nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, ctr);
+    PF_CHECK(hipGetLastError());
     return 0;
 }
 
@@ -115,6 +143,16 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     const int nblk = mode ? 2 * nbt : nbt;
     const int Nfft = s->Nfft;
     const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
+    if (mode == 0 && g_variant != 30) {  // one real stream: the fused one-kernel path when Nfft/2 has a tiled kernel
+        switch (Nfft / 2) {
+            case 512: return fc_launch_fused<FirCfg::C512>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
+            case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
+            case 2048: return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
+            case 4096: return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
+            case 8192: return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
+            default: break;
+        }
+    }
     rc = fc_grow(&s->d_work, &s->work_floats, (size_t)nblk * Nfft);
     if (rc) return rc;
     const unsigned grid = (unsigned)std::min<size_t>(((size_t)nblk * Nfft + 255) / 256, (size_t)num_cus() * 16);
@@ -168,7 +206,7 @@ PF_EXPORT PFFASTCONV_Setup* pffastconv_new_setup(const float* filterCoeffs, int 
 PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
     if (!s) return;
     pffft_destroy_setup(s->st);
-    for (float* p : {s->d_Hf, s->d_work, s->d_x, s->d_y}) if (p) (void)hipFree(p);
+    for (float* p : {s->d_Hf, s->d_Hc, s->d_work, s->d_x, s->d_y}) if (p) (void)hipFree(p);
     s->magic = 0;
     delete s;
 }

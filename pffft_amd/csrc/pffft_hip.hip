@@ -348,7 +348,7 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
     const int flags = (((dir == PFFFT_BACKWARD) && !ordered) ? 1 : 0) | (((dir == PFFFT_FORWARD) && !ordered) ? 2 : 0);
-    unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = groups <= grid ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
     hipLaunchKernelGGL(e.fn, dim3((unsigned)grid), dim3(e.wg), e.lds, st, in, out, (unsigned)batch, flags,
                        (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
     PF_CHECK(hipGetLastError());
