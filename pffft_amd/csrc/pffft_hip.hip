@@ -17,6 +17,7 @@
 #include "fft_c1024.h"
 #include "fft_generic.h"
 #include "fft_tiled.h"
+#include "fft_big.h"
 
 namespace pf {
 
@@ -97,7 +98,7 @@ static void aligned_free64(void* p) {
 // ------------------------------------------------------------------------------------------------
 // the plan ("PFFFT_Setup": src/pffft_priv_impl.h:1051-1060)
 // ------------------------------------------------------------------------------------------------
-enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1, K_TILED = 2 };
+enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1, K_TILED = 2, K_BIG = 3 };
 constexpr size_t LDS_MAX = 160 * 1024;
 constexpr unsigned CTR_RING = 4096;
 
@@ -118,6 +119,12 @@ struct Setup {
     void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
     unsigned* d_ctr = nullptr;             // ring of {next, done} work counters for the dynamic kernels
     std::atomic<unsigned> ctr_slot{0};
+    // sizes beyond LDS (K_BIG): n = bigN[0] x bigN[1], one strided plan + twiddle table per factor
+    StridedPlan bigp[2];
+    void* d_bigtw[2] = {nullptr, nullptr};
+    std::mutex big_mu;                    // the two HBM work buffers are owned by the setup
+    void* d_big[2] = {nullptr, nullptr};
+    size_t big_bytes[2] = {0, 0};
     void* d_stage[3] = {nullptr, nullptr, nullptr};  // staging for host-pointer legacy calls
     size_t stage_bytes[3] = {0, 0, 0};
 };
@@ -155,6 +162,35 @@ static Setup* new_setup(int N, int transform, int is_double) {
     int th = (int)(((size_t)gp.G * s->n / 8 + 63) / 64 * 64);
     s->gthreads = th < 64 ? 64 : (th > 1024 ? 1024 : th);
     s->kernel = K_GENERIC;
+    if (s->glds > LDS_MAX) {
+        // four-step plan: split the prime factors of n into two balanced products
+        s->kernel = K_BIG;
+        std::vector<int> f;
+        int rr = s->n;
+        for (int q : {5, 3, 2}) while (rr % q == 0) { f.push_back(q); rr /= q; }
+        long long a = 1, b = 1;
+        for (int q : f) { if (a <= b) a *= q; else b *= q; }
+        const long long sub[2] = {a, b};
+        for (int i = 0; i < 2; ++i) {
+            StridedPlan& sp = s->bigp[i];
+            memset(&sp, 0, sizeof sp);
+            sp.n = (int)sub[i];
+            int r2 = sp.n, k = 0;
+            while (r2 % 5 == 0) { sp.radix[k++] = 5; r2 /= 5; }
+            while (r2 % 3 == 0) { sp.radix[k++] = 3; r2 /= 3; }
+            while (r2 % 4 == 0) { sp.radix[k++] = 4; r2 /= 4; }
+            if (r2 % 2 == 0) { sp.radix[k++] = 2; r2 /= 2; }
+            sp.nstages = k;
+            long long g = (long long)(96 * 1024) / ((long long)sp.n * (long long)esz);
+            sp.G = (int)(g < 1 ? 1 : (g > 32 ? 32 : g));
+            sp.vec = s->n;
+        }
+        // step A: columns (length N1 = sub[0], stride N2), twiddled;  step B: rows (length N2), transposed store
+        s->bigp[0].count = sub[1]; s->bigp[0].estride_in = sub[1]; s->bigp[0].tstride_in = 1;
+        s->bigp[0].estride_out = sub[1]; s->bigp[0].tstride_out = 1; s->bigp[0].twN = s->n;
+        s->bigp[1].count = sub[0]; s->bigp[1].estride_in = 1; s->bigp[1].tstride_in = sub[1];
+        s->bigp[1].estride_out = sub[0]; s->bigp[1].tstride_out = 1; s->bigp[1].twN = 0;
+    }
     if (!is_double && transform == PFFFT_COMPLEX && N == 1024) s->kernel = K_C1024_F32;
     else if ((s->n & (s->n - 1)) == 0 && s->n >= 512 && s->n <= 16384 &&
              (size_t)s->n * esz <= 128 * 1024)
@@ -169,6 +205,8 @@ static void destroy_setup(Setup* s) {
         if (s->d_twr) (void)hipFree(s->d_twr);
         if (s->d_ctr) (void)hipFree(s->d_ctr);
     }
+    for (void* p : s->d_bigtw) if (p) (void)hipFree(p);
+    for (void* p : s->d_big) if (p) (void)hipFree(p);
     for (void* p : s->d_stage) if (p) (void)hipFree(p);
     s->magic = 0;
     delete s;
@@ -178,9 +216,23 @@ template <typename T>
 static int ensure_device(Setup* s) {
     std::lock_guard<std::mutex> lk(s->mu);
     if (s->dev_ready) return 0;
-    if (s->glds > LDS_MAX) {
-        g_last_error = "pffft_hip: N too large for the LDS-resident kernels (multi-pass path not built yet)";
-        return (int)hipErrorInvalidValue;
+    if (s->kernel == K_BIG) {
+        for (int i = 0; i < 2; ++i) {
+            const int m = s->bigp[i].n;
+            if ((size_t)m * sizeof(cx<T>) > LDS_MAX) {
+                g_last_error = "pffft_hip: N too large even for the four-step path in this precision";
+                return (int)hipErrorInvalidValue;
+            }
+            std::vector<cx<T>> tw(m);
+            for (int j = 0; j < m; ++j) {
+                long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)m;
+                tw[j].x = (T)cosl(a); tw[j].y = (T)sinl(a);
+            }
+            PF_CHECK(hipMalloc(&s->d_bigtw[i], sizeof(cx<T>) * m));
+            PF_CHECK(hipMemcpy(s->d_bigtw[i], tw.data(), sizeof(cx<T>) * m, hipMemcpyHostToDevice));
+        }
+        s->dev_ready = true;
+        return 0;
     }
     const int n = s->n;
     std::vector<cx<T>> tw(n);
@@ -355,6 +407,68 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
     return 0;
 }
 
+template <typename T> static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, hipStream_t st);
+
+template <typename T>
+static int launch_strided(Setup* s, int which, const cx<T>* in, cx<T>* out, size_t batch, int dir, hipStream_t st) {
+    const StridedPlan& sp = s->bigp[which];
+    const size_t lds = (size_t)sp.G * sp.n * sizeof(cx<T>);
+    long long groups = (long long)batch * ((sp.count + sp.G - 1) / sp.G);
+    long long grid = (long long)num_cus() * 4;
+    if (grid > groups) grid = groups;
+    int th = (int)(((size_t)sp.G * sp.n / 8 + 63) / 64 * 64);
+    th = th < 64 ? 64 : (th > 1024 ? 1024 : th);
+    auto kf = fft_strided_kernel<T, FWD>;
+    auto kb = fft_strided_kernel<T, BWD>;
+    int rc = allow_big_lds(dir == PFFFT_FORWARD ? kf : kb, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dir == PFFFT_FORWARD ? kf : kb, dim3((unsigned)grid), dim3(th), lds, st, in, out, (long long)batch, sp,
+                       (const cx<T>*)s->d_bigtw[which]);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+// n beyond LDS: canonical complex four-step through two HBM work buffers, with the real pair pass and the
+// internal layout composed around it (fft_big.h)
+template <typename T>
+static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(s->big_mu);
+    const size_t bytes = batch * (size_t)s->n * sizeof(cx<T>);
+    for (int i = 0; i < 2; ++i)
+        if (s->big_bytes[i] < bytes) {
+            if (s->d_big[i]) (void)hipFree(s->d_big[i]);
+            s->d_big[i] = nullptr; s->big_bytes[i] = 0;
+            PF_CHECK(hipMalloc(&s->d_big[i], bytes));
+            s->big_bytes[i] = bytes;
+        }
+    cx<T>* bufA = (cx<T>*)s->d_big[0];
+    cx<T>* bufB = (cx<T>*)s->d_big[1];
+    const bool real = s->transform == PFFFT_REAL;
+    const bool fwd = dir == PFFFT_FORWARD;
+    const unsigned egrid = (unsigned)std::min<size_t>((batch * (size_t)s->n / 2 + 255) / 256, (size_t)num_cus() * 16);
+    const cx<T>* cur = (const cx<T>*)in;
+    int rc;
+    if (!fwd && !ordered) {  // internal -> canonical
+        if ((rc = zreorder_batch<T>(s, in, (T*)bufA, batch, PFFFT_FORWARD, st))) return rc;
+        cur = bufA;
+    }
+    if (!fwd && real) {      // half-complex spectrum -> packed spectrum (in place, never on the caller's input)
+        if (cur != bufA) { PF_CHECK(hipMemcpyAsync(bufA, cur, bytes, hipMemcpyDeviceToDevice, st)); cur = bufA; }
+        hipLaunchKernelGGL((real_pair_kernel<T, BWD>), dim3(egrid), dim3(256), 0, st, bufA, (long long)batch, (long long)s->n);
+        PF_CHECK(hipGetLastError());
+    }
+    if ((rc = launch_strided<T>(s, 0, cur, bufB, batch, dir, st))) return rc;
+    cx<T>* dest = (fwd && !ordered) ? bufA : (cx<T>*)out;
+    if ((rc = launch_strided<T>(s, 1, bufB, dest, batch, dir, st))) return rc;
+    if (fwd && real) {
+        hipLaunchKernelGGL((real_pair_kernel<T, FWD>), dim3(egrid), dim3(256), 0, st, dest, (long long)batch, (long long)s->n);
+        PF_CHECK(hipGetLastError());
+    }
+    if (fwd && !ordered)     // canonical -> internal
+        if ((rc = zreorder_batch<T>(s, (const T*)bufA, out, batch, PFFFT_BACKWARD, st))) return rc;
+    return 0;
+}
+
 template <typename T>
 static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     if (!s || s->magic != MAGIC || s->is_double != (sizeof(T) == 8)) {
@@ -370,6 +484,7 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
     }
     if (s->kernel == K_TILED && g_variant != 1 && batch < (1ull << 32))
         return launch_tiled<T>(s, in, out, batch, dir, ordered, st);
+    if (s->kernel == K_BIG) return launch_big<T>(s, in, out, batch, dir, ordered, st);
     return launch_generic<T>(s, in, out, batch, dir, ordered, st);
 }
 
@@ -589,6 +704,7 @@ PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
     switch (s->kernel) {
         case pf::K_C1024_F32: return "c1024_f32";
         case pf::K_TILED: return "tiled";
+        case pf::K_BIG: return "fourstep";
         default: return "generic";
     }
 }

@@ -307,3 +307,27 @@ def test_c4_fir_config(ref):
         naive = np.convolve(x[w.start: w.stop + taps - 1].astype(np.float64), h.astype(np.float64), mode="valid")
         assert np.abs(y.cpu().numpy()[w] - naive).max() <= lim
         fc.close()
+
+
+# ------------------------------------------------------------------ sizes beyond LDS (four-step path)
+@pytest.mark.parametrize("dt,tr,N", [("f32", 1, 32768), ("f32", 1, 65536), ("f32", 0, 65536), ("f32", 0, 131072),
+                                     ("f32", 1, 30000), ("f32", 0, 120000), ("f64", 1, 16384), ("f64", 1, 65536),
+                                     ("f64", 0, 65536), ("f32", 1, 1 << 20)])
+def test_large_sizes_against_reference(ref, dt, tr, N):
+    dtype = _dt(dt)
+    rng = np.random.default_rng(N)
+    rs, s = ref.setup(N, tr, dtype), pa.Setup(N, tr, dtype)
+    assert pa.kernel_name(s) == "fourstep"
+    x = rng.uniform(-1, 1, (2, s.vec_scalars)).astype(dtype)
+    tol = tol_for(dt, N) * (4 if dt == "f32" else 1)   # float error grows ~ sqrt(log N); the bar stays 1e-5-class
+    for ordered in (False, True):
+        want = rs.batch(x, 0, ordered)
+        got = s.transform_batch(_dev(x), None, pa.FORWARD, ordered).cpu().numpy()
+        assert relerr(got, want) <= tol, (ordered, "fwd")
+        wb = rs.batch(want, 1, ordered)
+        gb = s.transform_batch(_dev(want), None, pa.BACKWARD, ordered).cpu().numpy()
+        assert relerr(gb, wb) <= tol, (ordered, "bwd")
+    buf = _dev(x)
+    s.transform_batch(buf, buf, pa.FORWARD, True)      # in place
+    assert relerr(buf.cpu().numpy(), rs.batch(x, 0, True)) <= tol
+    s.close(); rs.close()
