@@ -1,0 +1,74 @@
+"""The reference's OWN test / validation / example programs (tests/test_pffft.c, test_pffft.cpp,
+test_fft_factors.c, test_pffastconv.c, benchmarks/bench_pffft.c --validate, examples/*), compiled from their
+sources against libpffft_hip.so by tests/refprogs/Makefile ("the cheapest, strongest
+proof of drop-in").  The executables are built in the dev container (where /root/reference exists) into
+tests/_refbin/ and travel to the GPU box with the snapshot; the tests skip when they are absent."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+BIN = os.path.join(ROOT, "tests", "_refbin")
+
+
+def _run(name, *args, timeout=900):
+    exe = os.path.join(BIN, name)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (make -C tests/refprogs needs /root/reference)")
+    p = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout)
+    return p.returncode, p.stdout + p.stderr
+
+
+def test_fft_factors_program():
+    """tests/test_fft_factors.c: accepted-size set == local 2/3/5 factorisation == new_setup != NULL.
+    Needs no GPU (setups are host-side plans): runs in the CPU suite."""
+    rc, out = _run("test_fft_factors")
+    assert rc == 0, out[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,ok", [("test_pffft_float", "all tests succeeded successfully"),
+                                     ("test_pffft_double", "all tests succeeded successfully")])
+def test_pffft_program(prog, ok):
+    """tests/test_pffft.c: N = 32..65536, real+complex, ordered+unordered: single-tone dynamic range >= 140 dB
+    (float) / 215 dB (double), phase, magnitude, round trip — through the legacy host-pointer entries."""
+    rc, out = _run(prog)
+    assert rc == 0 and ok in out, out[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", ["test_pffft_cpp", "test_pffft_cpp11"])
+def test_pffft_cpp_program(prog):
+    """tests/test_pffft.cpp through the header-only pffft.hpp wrapper (C++98 and C++11 builds)."""
+    rc, out = _run(prog)
+    assert rc == 0, out[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,sel", [("bench_pffft_float", "--cplx"), ("bench_pffft_float", "--real"),
+                                      ("bench_pffft_double", "--cplx"), ("bench_pffft_double", "--real")])
+def test_bench_pffft_validate(prog, sel):
+    """benchmarks/bench_pffft.c:292-455 --validate: forward vs FFTPACK, in-place == out-of-place bit-exactly,
+    zreorder round trip, inverse, zconvolve identity, for the radix-2/3/4/5 size list (:445).
+    (Selector first: `--validate` returns immediately, SURVEY.md Appendix C.)"""
+    rc, out = _run(prog, sel, "--validate")
+    assert rc == 0 and "successful" in out.lower(), out[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("--no-bench", "--quick"), ("--no-bench", "--quick", "--sym")])
+def test_pffastconv_program(args):
+    """tests/test_pffastconv.c (ctest: test_pfconv_lens_*): output lengths of every block size against the
+    naive FIR, real / complex 2xFFT / complex single-FFT."""
+    rc, out = _run("test_pffastconv", *args, timeout=1800)
+    assert rc == 0, out[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", ["example_c_real_flt_fwd", "example_c_cplx_dbl_fwd", "example_cpp98_real_flt_fwd",
+                                  "example_cpp11_cplx_dbl_fwd"])
+def test_examples(prog):
+    rc, out = _run(prog)
+    assert rc == 0, out[-2000:]
