@@ -85,24 +85,76 @@ __device__ __forceinline__ void stage(cx<T>* z, int total, int Ls, int tw_stride
     }
 }
 
+// LDS carve-up (bytes) of the generic kernel: data image, then (when they fit) the W_n^j table, the W_N^k
+// table of the real pair pass and the digit-reversal table — read thousands of times per transform, and a
+// global (L2) load in a barrier-separated pass is what such a kernel waits for.
+struct GenericLds {
+    size_t tw, twr, pos, next, total;
+};
+template <typename T>
+__host__ __device__ inline GenericLds generic_lds(int n, int G, int is_real, int tables) {
+    GenericLds l;
+    size_t o = (size_t)G * n * sizeof(cx<T>);
+    l.tw = o;  if (tables) o += (size_t)n * sizeof(cx<T>);
+    l.twr = o; if (tables && is_real) o += ((size_t)n / 2 + 1) * sizeof(cx<T>);
+    l.pos = o; if (tables) o += (((size_t)n * 2 + 15) / 16) * 16;
+    l.next = o; o += 16;
+    l.total = o;
+    return l;
+}
+
 template <typename T, int DIR>
 __global__ void __launch_bounds__(1024)
 fft_generic_kernel(const T* in, T* out, size_t batch, GenericPlan p, int in_internal, int out_internal,
-                   const cx<T>* __restrict__ tw, const cx<T>* __restrict__ twr) {
+                   const cx<T>* __restrict__ twg, const cx<T>* __restrict__ twrg, int tables, unsigned* ctr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cx<T>* z = reinterpret_cast<cx<T>*>(smem_raw);
     T* zs = reinterpret_cast<T*>(smem_raw);
     const int n = p.n, G = p.G;
+    const GenericLds L = generic_lds<T>(n, G, p.is_real, tables);
+    const cx<T>* tw = twg;
+    const cx<T>* twr = twrg;
+    const unsigned short* lpos = nullptr;
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + L.next);
+    if (tables) {
+        cx<T>* ltw = reinterpret_cast<cx<T>*>(smem_raw + L.tw);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) ltw[i] = twg[i];
+        tw = ltw;
+        if (p.is_real) {
+            cx<T>* ltwr = reinterpret_cast<cx<T>*>(smem_raw + L.twr);
+            for (int i = threadIdx.x; i <= n / 2; i += blockDim.x) ltwr[i] = twrg[i];
+            twr = ltwr;
+        }
+        unsigned short* lp = reinterpret_cast<unsigned short*>(smem_raw + L.pos);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) lp[i] = (unsigned short)pos_of(i, p);
+        lpos = lp;
+    }
+    auto POS = [&](int k) -> int { return lpos ? (int)lpos[k] : pos_of(k, p); };
     const int nv = n >> 1;  // 4-scalar groups per vector (2n scalars complex, N = 2n scalars real)
     const vec4<T>* in4 = reinterpret_cast<const vec4<T>*>(in);
     vec4<T>* out4 = reinterpret_cast<vec4<T>*>(out);
 
-    for (size_t t0 = (size_t)blockIdx.x * G; t0 < batch; t0 += (size_t)gridDim.x * G) {
+    // groups of G consecutive vectors are pulled in order from the counter (ctr == nullptr: one group per
+    // workgroup, static) — see fft_c1024.h for what in-order sweeping buys on HBM
+    const bool dyn = ctr != nullptr;
+    unsigned pend = 0, g0 = blockIdx.x;
+    if (dyn && threadIdx.x == 0) {
+        s_next[0] = atomicAdd(&ctr[0], 1u);
+        pend = atomicAdd(&ctr[0], 1u);
+    }
+    __syncthreads();
+    if (dyn) g0 = s_next[0];
+    for (unsigned it = 0; (size_t)g0 * G < batch; ++it) {
+        if (dyn && threadIdx.x == 0) {
+            s_next[(it + 1) & 1] = pend;
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        const size_t t0 = (size_t)g0 * G;
         const int g_here = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);
         const int totv = g_here * nv;
         // ---- L: load ----
         for (int iv = threadIdx.x; iv < totv; iv += blockDim.x) {
-            vec4<T> val = in4[t0 * nv + iv];
+            vec4<T> val = __builtin_nontemporal_load(in4 + t0 * nv + iv);
             if (!in_internal) {
                 z[2 * iv] = mk<T>(val.x, val.y);
                 z[2 * iv + 1] = mk<T>(val.z, val.w);
@@ -116,6 +168,7 @@ fft_generic_kernel(const T* in, T* out, size_t batch, GenericPlan p, int in_inte
             }
         }
         __syncthreads();
+        const unsigned gn = dyn ? s_next[(it + 1) & 1] : g0 + gridDim.x;
         // ---- P: real backward pre-processing: Z'[k] = (A+B) + i w (A-B), Z'[n-k] = conj((A+B) - i w (A-B)),
         //         A = X[k], B = conj X[n-k], w = exp(+2 pi i k / N)  (gives N*x after the unscaled inverse) ----
         if (p.is_real && DIR == BWD) {
@@ -167,10 +220,10 @@ fft_generic_kernel(const T* in, T* out, size_t batch, GenericPlan p, int in_inte
                     cx<T> a = zg[0];
                     zg[0] = mk<T>(a.x + a.y, a.x - a.y);  // (DC, Nyquist): include/pffft/pffft.h:144-152
                 } else if (k == half) {
-                    int pk = pos_of(half, p);
+                    int pk = POS(half);
                     zg[pk] = conj(zg[pk]);
                 } else {
-                    int pk = pos_of(k, p), pn = pos_of(n - k, p);
+                    int pk = POS(k), pn = POS(n - k);
                     cx<T> A = zg[pk], B = conj(zg[pn]);
                     cx<T> S = (A + B) * (T)0.5, Dm = cmul(A - B, twr[k]) * (T)0.5;
                     cx<T> D = mk<T>(Dm.y, -Dm.x);  // * (-i)
@@ -186,18 +239,24 @@ fft_generic_kernel(const T* in, T* out, size_t batch, GenericPlan p, int in_inte
             const cx<T>* zg = z + (size_t)g * n;
             vec4<T> val;
             if (!out_internal) {
-                cx<T> a = zg[pos_of(2 * v, p)], b = zg[pos_of(2 * v + 1, p)];
+                cx<T> a = zg[POS(2 * v)], b = zg[POS(2 * v + 1)];
                 val.x = a.x; val.y = a.y; val.z = b.x; val.w = b.y;
             } else {
                 const T* zp = reinterpret_cast<const T*>(zg) + (v & 1);
-                val.x = zp[2 * pos_of(bin_of(v, 0, n, p.is_real), p)];
-                val.y = zp[2 * pos_of(bin_of(v, 1, n, p.is_real), p)];
-                val.z = zp[2 * pos_of(bin_of(v, 2, n, p.is_real), p)];
-                val.w = zp[2 * pos_of(bin_of(v, 3, n, p.is_real), p)];
+                val.x = zp[2 * POS(bin_of(v, 0, n, p.is_real))];
+                val.y = zp[2 * POS(bin_of(v, 1, n, p.is_real))];
+                val.z = zp[2 * POS(bin_of(v, 2, n, p.is_real))];
+                val.w = zp[2 * POS(bin_of(v, 3, n, p.is_real))];
             }
-            out4[t0 * nv + iv] = val;
+            __builtin_nontemporal_store(val, out4 + t0 * nv + iv);
         }
         __syncthreads();
+        g0 = gn;
+    }
+    if (dyn && threadIdx.x == 0) {
+        __threadfence();
+        unsigned d = atomicAdd(&ctr[1], 1u);
+        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
     }
 }
 

@@ -527,6 +527,12 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
 // ---- configurations: <T, log2 n, threads/transform, stages, R0..R3, PAD0, PADN, TWMODE, PREFETCH> ----
 template <typename T> struct TiledPick;
 template <> struct TiledPick<float> {
+    // small transforms: several per wavefront (TPT < 64), wave-local exchanges only
+    typedef TiledCfg<float, 4, 2, 2, 4, 4, 1, 1, 1, 0, 0, 1> C16;
+    typedef TiledCfg<float, 5, 4, 3, 4, 2, 4, 1, 1, 0, 0, 1> C32;
+    typedef TiledCfg<float, 6, 4, 2, 8, 8, 1, 1, 1, 0, 0, 1> C64;
+    typedef TiledCfg<float, 7, 8, 3, 8, 2, 8, 1, 1, 0, 0, 1> C128;
+    typedef TiledCfg<float, 8, 16, 3, 8, 4, 8, 1, 2, 0, 0, 1> C256;
     typedef TiledCfg<float, 9, 32, 3, 8, 8, 8, 1, 4, 4, 3, 1> C512;
     typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 1> C1024;
     typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 1, 3, 1> C2048;
@@ -542,6 +548,11 @@ struct TiledAltF32 {
     typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 1, 3, 0, 512, 4> C8192;
 };
 template <> struct TiledPick<double> {
+    typedef TiledCfg<double, 4, 2, 2, 4, 4, 1, 1, 1, 0, 0, 0, 256> C16;
+    typedef TiledCfg<double, 5, 4, 3, 4, 2, 4, 1, 1, 0, 0, 0, 256> C32;
+    typedef TiledCfg<double, 6, 4, 2, 8, 8, 1, 1, 1, 0, 0, 0, 256> C64;
+    typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 0, 0, 256> C128;
+    typedef TiledCfg<double, 8, 16, 3, 8, 4, 8, 1, 2, 0, 0, 0, 256> C256;
     typedef TiledCfg<double, 9, 32, 3, 8, 8, 8, 1, 4, 0, 1, 0> C512;
     typedef TiledCfg<double, 10, 64, 3, 8, 16, 8, 1, 4, 0, 1, 0> C1024;
     typedef TiledCfg<double, 11, 128, 4, 8, 4, 8, 8, 4, 0, 1, 0, 256> C2048;

@@ -192,7 +192,7 @@ static Setup* new_setup(int N, int transform, int is_double) {
         s->bigp[1].estride_out = sub[0]; s->bigp[1].tstride_out = 1; s->bigp[1].twN = 0;
     }
     if (!is_double && transform == PFFFT_COMPLEX && N == 1024) s->kernel = K_C1024_F32;
-    else if ((s->n & (s->n - 1)) == 0 && s->n >= 512 && s->n <= 16384 &&
+    else if ((s->n & (s->n - 1)) == 0 && s->n >= 16 && s->n <= 16384 &&
              (size_t)s->n * esz <= 128 * 1024)
         s->kernel = K_TILED;  // power-of-two sizes: register-tiled kernels (fft_tiled.h)
     return s;
@@ -291,22 +291,23 @@ static int launch_generic(Setup* s, const T* in, T* out, size_t batch, int dir, 
     const GenericPlan& gp = s->gp;
     const int in_internal = (dir == PFFFT_BACKWARD) && !ordered;
     const int out_internal = (dir == PFFFT_FORWARD) && !ordered;
-    size_t passes = (batch + gp.G - 1) / gp.G;
-    size_t per_cu = LDS_MAX / (s->glds ? s->glds : 1);
+    // twiddle / digit-reversal tables in LDS when the image leaves room for them (n <= 65535 for the 16-bit map)
+    int tables = gp.n < 65536 && generic_lds<T>(gp.n, gp.G, gp.is_real, 1).total <= LDS_MAX;
+    if (g_variant == 40) tables = 0;
+    const size_t lds = generic_lds<T>(gp.n, gp.G, gp.is_real, tables).total;
+    size_t groups = (batch + gp.G - 1) / gp.G;
+    size_t per_cu = LDS_MAX / lds;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     size_t grid = (size_t)num_cus() * per_cu;
-    if (grid > passes) grid = passes;
+    if (grid > groups) grid = groups;
+    unsigned* ctr = (groups <= grid || g_variant == 41) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
     auto kf = fft_generic_kernel<T, FWD>;
     auto kb = fft_generic_kernel<T, BWD>;
-    int rc = allow_big_lds(dir == PFFFT_FORWARD ? kf : kb, s->glds);
+    int rc = allow_big_lds(dir == PFFFT_FORWARD ? kf : kb, lds);
     if (rc) return rc;
-    if (dir == PFFFT_FORWARD)
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(s->gthreads), s->glds, st, in, out, batch, gp, in_internal,
-                           out_internal, (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr);
-    else
-        hipLaunchKernelGGL(kb, dim3((unsigned)grid), dim3(s->gthreads), s->glds, st, in, out, batch, gp, in_internal,
-                           out_internal, (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr);
+    hipLaunchKernelGGL(dir == PFFFT_FORWARD ? kf : kb, dim3((unsigned)grid), dim3(s->gthreads), lds, st, in, out, batch, gp,
+                       in_internal, out_internal, (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, tables, ctr);
     PF_CHECK(hipGetLastError());
     return 0;
 }
@@ -375,6 +376,11 @@ static bool tiled_lookup(int n, int dir, int real, TiledEntry<T>* e) {
         }
     }
     switch (n) {
+        case 16: *e = tiled_entry<T, typename TiledPick<T>::C16>(dir, real); return true;
+        case 32: *e = tiled_entry<T, typename TiledPick<T>::C32>(dir, real); return true;
+        case 64: *e = tiled_entry<T, typename TiledPick<T>::C64>(dir, real); return true;
+        case 128: *e = tiled_entry<T, typename TiledPick<T>::C128>(dir, real); return true;
+        case 256: *e = tiled_entry<T, typename TiledPick<T>::C256>(dir, real); return true;
         case 512: *e = tiled_entry<T, typename TiledPick<T>::C512>(dir, real); return true;
         case 1024: *e = tiled_entry<T, typename TiledPick<T>::C1024>(dir, real); return true;
         case 2048: *e = tiled_entry<T, typename TiledPick<T>::C2048>(dir, real); return true;
