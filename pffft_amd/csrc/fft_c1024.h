@@ -38,8 +38,11 @@ constexpr int C1024_PLANE = 1120;              // floats per re/im plane of the 
 constexpr int C1024_WAVE_BYTES = 2 * C1024_PLANE * 4;  // 8960 >= 8*136*8 = 8704
 constexpr int C1024_LDS_BYTES = C1024_WAVES * C1024_WAVE_BYTES + 16;
 
-__device__ __forceinline__ int c1024_plane_addr(int part, int k) {  // float index inside the wave image
-    return part * C1024_PLANE + k + 16 * (k >> 8);
+// float index inside the wave image of the split re/im planes.  Two paddings (tools/search_x0.py): the X3
+// image (b64 writes, b128 reads) is conflict-free with plane 1120 / +16 per 256 bins; the X0 image (b128
+// writes, b64 reads) with plane 1116 / +8 — the X3 padding costs it 4x on the writes.
+template <int X0> __device__ __forceinline__ int c1024_plane_addr(int part, int k) {
+    return X0 ? part * 1116 + k + 8 * (k >> 8) : part * C1024_PLANE + k + 16 * (k >> 8);
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -73,14 +76,14 @@ __device__ __forceinline__ void c1024_part_a(const C1024V4 (&raw)[8], cx<float>*
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             int k0 = 256 * ((L >> 1) & 3) + 4 * (8 * s + (L >> 3));
-            *reinterpret_cast<V4*>(wf + c1024_plane_addr(L & 1, k0)) = raw[s];
+            *reinterpret_cast<V4*>(wf + c1024_plane_addr<1>(L & 1, k0)) = raw[s];
         }
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int k = 128 * j + 2 * L;
-            vec2<float> re = *reinterpret_cast<const vec2<float>*>(wf + c1024_plane_addr(0, k));
-            vec2<float> im = *reinterpret_cast<const vec2<float>*>(wf + c1024_plane_addr(1, k));
+            vec2<float> re = *reinterpret_cast<const vec2<float>*>(wf + c1024_plane_addr<1>(0, k));
+            vec2<float> im = *reinterpret_cast<const vec2<float>*>(wf + c1024_plane_addr<1>(1, k));
             a[j][0] = mk<float>(re.x, im.x);
             a[j][1] = mk<float>(re.y, im.y);
         }
@@ -168,14 +171,14 @@ __device__ __forceinline__ void c1024_part_b(float* out, size_t t, cx<float>* wl
             int k = 2 * L + 128 * kc;
             vec2<float> re, im;
             re.x = a[kc][0].x; re.y = a[kc][1].x; im.x = a[kc][0].y; im.y = a[kc][1].y;
-            *reinterpret_cast<vec2<float>*>(wf + c1024_plane_addr(0, k)) = re;
-            *reinterpret_cast<vec2<float>*>(wf + c1024_plane_addr(1, k)) = im;
+            *reinterpret_cast<vec2<float>*>(wf + c1024_plane_addr<0>(0, k)) = re;
+            *reinterpret_cast<vec2<float>*>(wf + c1024_plane_addr<0>(1, k)) = im;
         }
         wave_lds_fence();
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             int k0 = 256 * ((L >> 1) & 3) + 4 * (8 * s + (L >> 3));
-            V4 v = *reinterpret_cast<const V4*>(wf + c1024_plane_addr(L & 1, k0));
+            V4 v = *reinterpret_cast<const V4*>(wf + c1024_plane_addr<0>(L & 1, k0));
             __builtin_nontemporal_store(v, dst + 64 * s);
         }
     }
