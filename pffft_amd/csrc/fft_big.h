@@ -65,7 +65,7 @@ fft_strided_kernel(const cx<T>* in, cx<T>* out, long long batch, StridedPlan p, 
         for (int i = threadIdx.x; i < g_here * n; i += blockDim.x) {
             int g, e;
             if (t_fast_in) { e = i / g_here; g = i - e * g_here; } else { g = i / n; e = i - g * n; }
-            z[g * n + e] = src[(long long)g * p.tstride_in + (long long)e * p.estride_in];
+            z[gpad(g * n + e)] = src[(long long)g * p.tstride_in + (long long)e * p.estride_in];
         }
         __syncthreads();
         int Ls = n;
@@ -86,7 +86,7 @@ fft_strided_kernel(const cx<T>* in, cx<T>* out, long long batch, StridedPlan p, 
         for (int i = threadIdx.x; i < g_here * n; i += blockDim.x) {
             int g, k;
             if (t_fast_out) { k = i / g_here; g = i - k * g_here; } else { g = i / n; k = i - g * n; }
-            cx<T> v = z[g * n + pos_of_sp(k, p)];
+            cx<T> v = z[gpad(g * n + pos_of_sp(k, p))];
             if (p.twN) v = cmul(v, unit_root<T>((long long)k * (c0 + g), p.twN, DIR));
             dst[(long long)g * p.tstride_out + (long long)k * p.estride_out] = v;
         }

@@ -158,7 +158,7 @@ static Setup* new_setup(int N, int transform, int is_double) {
     gp.nstages = ns;
     const size_t esz = is_double ? 16 : 8;
     gp.G = s->n >= 2048 ? 1 : 2048 / s->n;
-    s->glds = (size_t)gp.G * s->n * esz;
+    s->glds = (((size_t)gp.G * s->n + ((size_t)gp.G * s->n >> 5) + 2) * esz + 15) / 16 * 16 + 16;  // padded image (gpad)
     int th = (int)(((size_t)gp.G * s->n / 8 + 63) / 64 * 64);
     s->gthreads = th < 64 ? 64 : (th > 1024 ? 1024 : th);
     s->kernel = K_GENERIC;
@@ -181,7 +181,7 @@ static Setup* new_setup(int N, int transform, int is_double) {
             while (r2 % 4 == 0) { sp.radix[k++] = 4; r2 /= 4; }
             if (r2 % 2 == 0) { sp.radix[k++] = 2; r2 /= 2; }
             sp.nstages = k;
-            long long g = (long long)(96 * 1024) / ((long long)sp.n * (long long)esz);
+            long long g = (long long)(92 * 1024) / ((long long)sp.n * (long long)esz);
             sp.G = (int)(g < 1 ? 1 : (g > 32 ? 32 : g));
             sp.vec = s->n;
         }
@@ -219,7 +219,7 @@ static int ensure_device(Setup* s) {
     if (s->kernel == K_BIG) {
         for (int i = 0; i < 2; ++i) {
             const int m = s->bigp[i].n;
-            if ((size_t)m * sizeof(cx<T>) > LDS_MAX) {
+            if (((size_t)m + (m >> 5) + 2) * sizeof(cx<T>) > LDS_MAX) {
                 g_last_error = "pffft_hip: N too large even for the four-step path in this precision";
                 return (int)hipErrorInvalidValue;
             }
@@ -301,7 +301,9 @@ static int launch_generic(Setup* s, const T* in, T* out, size_t batch, int dir, 
     if (per_cu < 1) per_cu = 1;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
-    unsigned* ctr = (groups <= grid || g_variant == 41) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    // in-order pulling pays once a group is tens of KiB; small groups are cheaper with the static grid-stride walk
+    const bool want_dyn = (size_t)gp.G * gp.n * sizeof(cx<T>) >= 24 * 1024 && g_variant != 41;
+    unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
     auto kf = fft_generic_kernel<T, FWD>;
     auto kb = fft_generic_kernel<T, BWD>;
     int rc = allow_big_lds(dir == PFFFT_FORWARD ? kf : kb, lds);
@@ -418,7 +420,7 @@ template <typename T> static int zreorder_batch(Setup* s, const T* in, T* out, s
 template <typename T>
 static int launch_strided(Setup* s, int which, const cx<T>* in, cx<T>* out, size_t batch, int dir, hipStream_t st) {
     const StridedPlan& sp = s->bigp[which];
-    const size_t lds = (size_t)sp.G * sp.n * sizeof(cx<T>);
+    const size_t lds = ((size_t)sp.G * sp.n + ((size_t)sp.G * sp.n >> 5) + 2) * sizeof(cx<T>);  // padded image (gpad)
     long long groups = (long long)batch * ((sp.count + sp.G - 1) / sp.G);
     long long grid = (long long)num_cus() * 4;
     if (grid > groups) grid = groups;
