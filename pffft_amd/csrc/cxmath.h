@@ -14,13 +14,21 @@ namespace pf {
 constexpr int FWD = 0;  // PFFFT_FORWARD  (include/pffft/pffft.h:112) : exp(-2*pi*i*nk/N)
 constexpr int BWD = 1;  // PFFFT_BACKWARD                            : exp(+2*pi*i*nk/N), unscaled
 
-template <typename T> struct alignas(2 * sizeof(T)) cx { T x, y; };
+// A complex number is a native 2-vector (re, im).  (A struct {T x, y} works arithmetically, but arrays of it
+// held in registers went through type-punned struct copies that the optimiser could not always promote out
+// of private memory — scratch traffic in the hot loops.  Vectors have built-in +, -, scalar * and are SSA values.)
+template <typename T> struct vec2t;
+template <> struct vec2t<float> { typedef __attribute__((ext_vector_type(2))) float type; };
+template <> struct vec2t<double> { typedef __attribute__((ext_vector_type(2))) double type; };
+template <typename T> using vec2 = typename vec2t<T>::type;
+template <typename T> using cx = vec2<T>;
+template <typename V> struct scalar_of;
+template <> struct scalar_of<vec2<float>> { typedef float type; };
+template <> struct scalar_of<vec2<double>> { typedef double type; };
+template <typename V> using sc = typename scalar_of<V>::type;
 
-template <typename T> __device__ __forceinline__ cx<T> mk(T x, T y) { cx<T> r; r.x = x; r.y = y; return r; }
-template <typename T> __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
-template <typename T> __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
-template <typename T> __device__ __forceinline__ cx<T> operator*(cx<T> a, T s) { return mk<T>(a.x * s, a.y * s); }
-template <typename T> __device__ __forceinline__ cx<T> conj(cx<T> a) { return mk<T>(a.x, -a.y); }
+template <typename T> __host__ __device__ __forceinline__ cx<T> mk(T x, T y) { cx<T> r; r.x = x; r.y = y; return r; }
+template <typename V> __device__ __forceinline__ V conj(V a) { return mk<sc<V>>(a.x, -a.y); }
 
 // The library is compiled with -ffp-contract=off and every fused multiply-add is written out, so
 // that the arithmetic of a butterfly is fixed by the source: all template instantiations of a kernel
@@ -31,27 +39,28 @@ __device__ __forceinline__ float fma_(float a, float b, float c) { return __buil
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // a * w
-template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> w) {
-    return mk<T>(fma_(a.x, w.x, -(a.y * w.y)), fma_(a.x, w.y, a.y * w.x));
+template <typename V> __device__ __forceinline__ V cmul(V a, V w) {
+    return mk<sc<V>>(fma_(a.x, w.x, -(a.y * w.y)), fma_(a.x, w.y, a.y * w.x));
 }
 // a * conj(w)
-template <typename T> __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> w) {
-    return mk<T>(fma_(a.x, w.x, a.y * w.y), fma_(a.y, w.x, -(a.x * w.y)));
+template <typename V> __device__ __forceinline__ V cmulc(V a, V w) {
+    return mk<sc<V>>(fma_(a.x, w.x, a.y * w.y), fma_(a.y, w.x, -(a.x * w.y)));
 }
 // a * w for the forward transform, a * conj(w) for the backward one (table holds exp(-i*theta))
-template <int DIR, typename T> __device__ __forceinline__ cx<T> twmul(cx<T> a, cx<T> w) {
+template <int DIR, typename V> __device__ __forceinline__ V twmul(V a, V w) {
     return DIR == FWD ? cmul(a, w) : cmulc(a, w);
 }
 // multiply by -i (forward) / +i (backward): the radix-4 "quarter turn"
-template <int DIR, typename T> __device__ __forceinline__ cx<T> rot(cx<T> a) {
-    return DIR == FWD ? mk<T>(a.y, -a.x) : mk<T>(-a.y, a.x);
+template <int DIR, typename V> __device__ __forceinline__ V rot(V a) {
+    return DIR == FWD ? mk<sc<V>>(a.y, -a.x) : mk<sc<V>>(-a.y, a.x);
 }
 
-template <int DIR, typename T> __device__ __forceinline__ void dft2(cx<T>& a0, cx<T>& a1) {
-    cx<T> t = a0 - a1; a0 = a0 + a1; a1 = t;
+template <int DIR, typename V> __device__ __forceinline__ void dft2(V& a0, V& a1) {
+    V t = a0 - a1; a0 = a0 + a1; a1 = t;
 }
 
-template <int DIR, typename T> __device__ __forceinline__ void dft3(cx<T>& a0, cx<T>& a1, cx<T>& a2) {
+template <int DIR, typename V> __device__ __forceinline__ void dft3(V& a0, V& a1, V& a2) {
+    typedef sc<V> T;
     const T s3 = (T)0.86602540378443864676372317075294L;  // sin(2*pi/3)
     cx<T> t1 = a1 + a2;
     cx<T> m = mk<T>(fma_((T)-0.5, t1.x, a0.x), fma_((T)-0.5, t1.y, a0.y));
@@ -59,14 +68,16 @@ template <int DIR, typename T> __device__ __forceinline__ void dft3(cx<T>& a0, c
     a0 = a0 + t1; a1 = m + d; a2 = m - d;
 }
 
-template <int DIR, typename T>
-__device__ __forceinline__ void dft4(cx<T>& a0, cx<T>& a1, cx<T>& a2, cx<T>& a3) {
+template <int DIR, typename V>
+__device__ __forceinline__ void dft4(V& a0, V& a1, V& a2, V& a3) {
+    typedef sc<V> T;
     cx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<DIR>(a1 - a3);
     a0 = t0 + t2; a1 = t1 + t3; a2 = t0 - t2; a3 = t1 - t3;
 }
 
-template <int DIR, typename T>
-__device__ __forceinline__ void dft5(cx<T>& a0, cx<T>& a1, cx<T>& a2, cx<T>& a3, cx<T>& a4) {
+template <int DIR, typename V>
+__device__ __forceinline__ void dft5(V& a0, V& a1, V& a2, V& a3, V& a4) {
+    typedef sc<V> T;
     const T c1 = (T)0.30901699437494742410229341718282L;   // cos(2*pi/5)
     const T c2 = (T)-0.80901699437494742410229341718282L;  // cos(4*pi/5)
     const T s1 = (T)0.95105651629515357211643933337938L;   // sin(2*pi/5)
@@ -80,17 +91,20 @@ __device__ __forceinline__ void dft5(cx<T>& a0, cx<T>& a1, cx<T>& a2, cx<T>& a3,
 }
 
 // a * exp(-/+ i*pi/4) and a * exp(-/+ 3i*pi/4)
-template <int DIR, typename T> __device__ __forceinline__ cx<T> mulw8_1(cx<T> a) {
+template <int DIR, typename V> __device__ __forceinline__ V mulw8_1(V a) {
+    typedef sc<V> T;
     const T h = (T)0.70710678118654752440084436210485L;
     return DIR == FWD ? mk<T>((a.x + a.y) * h, (a.y - a.x) * h) : mk<T>((a.x - a.y) * h, (a.x + a.y) * h);
 }
-template <int DIR, typename T> __device__ __forceinline__ cx<T> mulw8_3(cx<T> a) {
+template <int DIR, typename V> __device__ __forceinline__ V mulw8_3(V a) {
+    typedef sc<V> T;
     const T h = (T)0.70710678118654752440084436210485L;
     return DIR == FWD ? mk<T>((a.y - a.x) * h, -(a.x + a.y) * h) : mk<T>(-(a.x + a.y) * h, (a.x - a.y) * h);
 }
 
 // in-place radix-8, natural-order output (a[d] = sum_q a[q] W8^(q d))
-template <int DIR, typename T> __device__ __forceinline__ void dft8(cx<T> (&a)[8]) {
+template <int DIR, typename V> __device__ __forceinline__ void dft8(V (&a)[8]) {
+    typedef sc<V> T;
     cx<T> b0 = a[0] + a[4], c0 = a[0] - a[4];
     cx<T> b1 = a[1] + a[5], c1 = mulw8_1<DIR>(a[1] - a[5]);
     cx<T> b2 = a[2] + a[6], c2 = rot<DIR>(a[2] - a[6]);
@@ -102,7 +116,8 @@ template <int DIR, typename T> __device__ __forceinline__ void dft8(cx<T> (&a)[8
 }
 
 // in-place radix-16, natural-order output
-template <int DIR, typename T> __device__ __forceinline__ void dft16(cx<T> (&a)[16]) {
+template <int DIR, typename V> __device__ __forceinline__ void dft16(V (&a)[16]) {
+    typedef sc<V> T;
     const T c1 = (T)0.92387953251128675612818318939679L;  // cos(pi/8)
     const T s1 = (T)0.38268343236508977172845998403040L;  // sin(pi/8)
     cx<T> b[8], c[8];
@@ -123,7 +138,7 @@ template <int DIR, typename T> __device__ __forceinline__ void dft16(cx<T> (&a)[
     for (int d = 0; d < 8; ++d) { a[2 * d] = b[d]; a[2 * d + 1] = c[d]; }
 }
 
-template <int R, int DIR, typename T> __device__ __forceinline__ void dftR(cx<T> (&a)[R]) {
+template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a)[R]) {
     if constexpr (R == 2) dft2<DIR>(a[0], a[1]);
     else if constexpr (R == 3) dft3<DIR>(a[0], a[1], a[2]);
     else if constexpr (R == 4) dft4<DIR>(a[0], a[1], a[2], a[3]);
@@ -137,9 +152,5 @@ template <typename T> struct vec4t;
 template <> struct vec4t<float> { typedef __attribute__((ext_vector_type(4))) float type; };
 template <> struct vec4t<double> { typedef __attribute__((ext_vector_type(4))) double type; };
 template <typename T> using vec4 = typename vec4t<T>::type;
-template <typename T> struct vec2t;
-template <> struct vec2t<float> { typedef __attribute__((ext_vector_type(2))) float type; };
-template <> struct vec2t<double> { typedef __attribute__((ext_vector_type(2))) double type; };
-template <typename T> using vec2 = typename vec2t<T>::type;
 
 }  // namespace pf

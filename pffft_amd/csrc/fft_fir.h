@@ -174,9 +174,9 @@ __global__ void fastconv_scale_kernel(const float* __restrict__ in, float* __res
 struct FirCfg {
     typedef TiledCfg<float, 9, 32, 3, 8, 8, 8, 1, 4, 4, 3, 0, 64, 2> C512;
     typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 0, 64, 2> C1024;
-    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 1, 3, 0, 128, 2> C2048;
-    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 1, 3, 0, 256, 2> C4096;
-    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 1, 3, 0, 512, 2> C8192;
+    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 8, 3, 0, 128, 2> C2048;
+    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 0, 256, 2> C4096;
+    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 0, 512, 2> C8192;
 };
 
 }  // namespace pf

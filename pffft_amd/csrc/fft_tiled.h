@@ -79,14 +79,19 @@ template <class C> __device__ __forceinline__ int phys_trn(int P) {  // image af
 
 // LDS accesses of one complex point as ONE typed vector access (struct copies of cx<T> through memory
 // left type-punned private allocas behind = scratch traffic in the hot loop)
-template <typename T> __device__ __forceinline__ void lds_st(cx<T>* p, cx<T> v) {
-    vec2<T> x; x.x = v.x; x.y = v.y;
-    *reinterpret_cast<vec2<T>*>(p) = x;
+template <typename V> __device__ __forceinline__ void lds_st(V* p, V v) { *p = v; }
+template <typename V> __device__ __forceinline__ V lds_ld(const V* p) { return *p; }
+
+// two adjacent float points in one 16-byte access
+__device__ __forceinline__ void lds_st2(cx<float>* p, cx<float> a, cx<float> b) {
+    vec4<float> x; x.x = a.x; x.y = a.y; x.z = b.x; x.w = b.y;
+    *reinterpret_cast<vec4<float>*>(p) = x;
 }
-template <typename T> __device__ __forceinline__ cx<T> lds_ld(const cx<T>* p) {
-    const vec2<T> x = *reinterpret_cast<const vec2<T>*>(p);
-    return mk<T>(x.x, x.y);
+__device__ __forceinline__ vec4<float> lds_ld2(const cx<float>* p) {  // by value: reference out-parameters into
+    return *reinterpret_cast<const vec4<float>*>(p);                     // the register array left private allocas behind
 }
+__device__ __forceinline__ void lds_st2(cx<double>*, cx<double>, cx<double>) {}
+__device__ __forceinline__ vec4<float> lds_ld2(const cx<double>*) { return vec4<float>(); }
 
 typedef vec4<float> chunk16;  // a 16-byte register quantum, reinterpreted per precision
 
@@ -225,9 +230,30 @@ struct Tiled {
     //                   strides c used here (multiples of Ns, resp. of n/R >= 64)
     //   transposed    : phys(P) = (P mod R0)*ROW + P div R0
     static __device__ __forceinline__ constexpr int nat_off(int c) { return c + C::PADN * (c >> 6); }
+    // stages whose butterflies come in adjacent pairs (j, j+1) move two points per 16-byte LDS access
+    template <int S> static constexpr bool pair_stage() {
+        return StageInfo<C, S>::PAIR && S != SYM_STAGE && (C::PAD0 % 2 == 0) && (C::PADN % 2 == 0);
+    }
     template <int S> static __device__ __forceinline__ void xwrite(const CX (&v)[E], int t, CX* img) {
         typedef StageInfo<C, S> SW;
         constexpr int R = SW::R, Ns = SW::Ns, ROW = n / R0 + C::PAD0;
+        if constexpr (pair_stage<S>() && (S == 0 || Ns >= 2)) {
+#pragma unroll
+            for (int ii = 0; ii < SW::B / 2; ++ii) {
+                const int j = jm<S>(t, 2 * ii);  // even; j + 1 is the partner
+                if constexpr (S == 0) {
+                    CX* p = img + j;
+#pragma unroll
+                    for (int d = 0; d < R; ++d) lds_st2(p + d * ROW, v[(2 * ii) * R + d], v[(2 * ii + 1) * R + d]);
+                } else {
+                    const int Ha = (j / Ns) * (Ns * R) + (j & (Ns - 1));
+                    CX* p = img + Ha + C::PADN * (Ha >> 6);
+#pragma unroll
+                    for (int d = 0; d < R; ++d) lds_st2(p + nat_off(d * Ns), v[(2 * ii) * R + d], v[(2 * ii + 1) * R + d]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < SW::B; ++u) {
             const int j = jm<S>(t, u);
@@ -248,6 +274,20 @@ struct Tiled {
         constexpr int R2 = SR::R, ROW = n / R0 + C::PAD0;
         static_assert((n / R2) % 64 == 0 || C::PADN == 0, "operand stride must be a multiple of the padding period");
         static_assert((n / R2) % R0 == 0, "operand stride must be a multiple of R0");
+        if constexpr (S > 0 && pair_stage<S + 1>()) {
+#pragma unroll
+            for (int ii = 0; ii < SR::B / 2; ++ii) {
+                const int j = jm<S + 1>(t, 2 * ii);
+                const CX* p = img + j + C::PADN * (j >> 6);
+#pragma unroll
+                for (int q = 0; q < R2; ++q) {
+                    const vec4<float> x = lds_ld2(p + nat_off(q * (n / R2)));
+                    v[(2 * ii) * R2 + q] = mk<T>((T)x.x, (T)x.y);
+                    v[(2 * ii + 1) * R2 + q] = mk<T>((T)x.z, (T)x.w);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < SR::B; ++u) {
             const int j = jm<S + 1>(t, u);
@@ -332,6 +372,13 @@ struct Tiled {
     }
 };
 
+#ifdef PF_TILED_DEBUG
+__device__ long long pf_tdbg[64];
+#define PF_TSTAMP(i) do { if (blockIdx.x == 7 && threadIdx.x == 0 && it == 3) pf_tdbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PF_TSTAMP(i) do { } while (0)
+#endif
+
 // flags: bit0 = input in internal layout, bit1 = output in internal layout
 template <class C, int DIR, int REAL>
 __global__ void __launch_bounds__(C::WG_THREADS, C::WG_THREADS >= 1024 ? 4 : C::OCC)
@@ -396,6 +443,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
         int tl = t;
         asm volatile("" : "+v"(tl));
 
+        PF_TSTAMP(0);
         // ------------------------------------------------------------------ input
         if (plain_in) {
             if constexpr (VEC == 2) {
@@ -441,18 +489,21 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
             if constexpr (REAL) K::pair_regs(v, t, w);  // half-complex spectrum -> packed spectrum, in registers
         }
 
+        PF_TSTAMP(1);
         // ------------------------------------------------------------------ transform
         K::template butterflies<0>(v, t, w, twt);
+        PF_TSTAMP(2);
         if constexpr (C::NS > 1) K::template xwrite<0>(v, t, img);
         __syncthreads();  // publishes s_next; first half of exchange 0
+        PF_TSTAMP(3);
         const unsigned gn = dyn ? s_next[(it + 1) & 1] : g + gridDim.x;
         if constexpr (C::PREFETCH) {  // the loads of the next transform fly while this one is finished
             const size_t tn = (size_t)gn * C::T_PER_WG + slot;
             K::load_raw(raw, in + (tn < last ? tn : last) * 2 * (size_t)n, t, plain_in);
         }
-        if constexpr (C::NS > 1) { K::template xread<0>(v, t, img); K::xsync(); K::template butterflies<1>(v, t, w, twt); }
-        if constexpr (C::NS > 2) { K::template xwrite<1>(v, t, img); K::xsync(); K::template xread<1>(v, t, img); K::xsync(); K::template butterflies<2>(v, t, w, twt); }
-        if constexpr (C::NS > 3) { K::template xwrite<2>(v, t, img); K::xsync(); K::template xread<2>(v, t, img); K::xsync(); K::template butterflies<3>(v, t, w, twt); }
+        if constexpr (C::NS > 1) { K::template xread<0>(v, t, img); K::xsync(); PF_TSTAMP(4); K::template butterflies<1>(v, t, w, twt); PF_TSTAMP(5); }
+        if constexpr (C::NS > 2) { K::template xwrite<1>(v, t, img); K::xsync(); PF_TSTAMP(6); K::template xread<1>(v, t, img); K::xsync(); PF_TSTAMP(7); K::template butterflies<2>(v, t, w, twt); PF_TSTAMP(8); }
+        if constexpr (C::NS > 3) { K::template xwrite<2>(v, t, img); K::xsync(); PF_TSTAMP(9); K::template xread<2>(v, t, img); K::xsync(); PF_TSTAMP(10); K::template butterflies<3>(v, t, w, twt); PF_TSTAMP(11); }
 
         // ------------------------------------------------------------------ output
         if (plain_out) {
@@ -481,6 +532,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
         } else {
             // (real: pair pass in registers) canonical spectrum -> natural-order image -> linear chunks of the output layout
             if constexpr (REAL) K::pair_regs(v, t, w);
+            PF_TSTAMP(12);
 #pragma unroll
             for (int u = 0; u < SL::B; ++u)
 #pragma unroll
@@ -489,6 +541,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
                     lds_st(img + j + C::PADN * (j >> 6) + K::nat_off(d * (n / RL)), v[u * RL + d]);
                 }
             K::xsync();
+            PF_TSTAMP(13);
             chunk16* d16 = reinterpret_cast<chunk16*>(dst);
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
@@ -509,8 +562,10 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
                 }
                 if (active) __builtin_nontemporal_store(o, d16 + c);
             }
+            PF_TSTAMP(14);
             K::xsync();
         }
+        PF_TSTAMP(15);
         if constexpr (!C::PREFETCH) {
             const size_t tn = (size_t)gn * C::T_PER_WG + slot;
             K::load_raw(raw, in + (tn < last ? tn : last) * 2 * (size_t)n, t, plain_in);
@@ -535,17 +590,17 @@ template <> struct TiledPick<float> {
     typedef TiledCfg<float, 8, 16, 3, 8, 4, 8, 1, 2, 0, 0, 1> C256;
     typedef TiledCfg<float, 9, 32, 3, 8, 8, 8, 1, 4, 4, 3, 1> C512;
     typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 1> C1024;
-    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 1, 3, 1> C2048;
-    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 1, 3, 1> C4096;
-    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 1, 3, 1> C8192;
-    typedef TiledCfg<float, 14, 1024, 4, 8, 16, 16, 8, 4, 1, 3, 0> C16384;
+    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 8, 3, 1> C2048;
+    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 1> C4096;
+    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 1> C8192;
+    typedef TiledCfg<float, 14, 1024, 4, 8, 16, 16, 8, 4, 8, 3, 0> C16384;
 };
 // experimental alternatives (pffft_hip_set_variant(20)): no register prefetch, 128-VGPR budget, two
 // workgroups per CU so that independent transforms overlap each other's barrier phases
 struct TiledAltF32 {
-    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 1, 3, 0, 256, 4> C2048;
-    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 1, 3, 0, 256, 4> C4096;
-    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 1, 3, 0, 512, 4> C8192;
+    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 8, 3, 0, 256, 4> C2048;
+    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 0, 256, 4> C4096;
+    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 0, 512, 4> C8192;
 };
 template <> struct TiledPick<double> {
     typedef TiledCfg<double, 4, 2, 2, 4, 4, 1, 1, 1, 0, 0, 0, 256> C16;
