@@ -55,7 +55,12 @@ struct TiledCfg {
     static constexpr int TW_COUNT = tw_off(NS_);
     static constexpr int IMG_NAT = n + PADN_ * (n / 64);
     static constexpr int IMG_TRN = R0_ * (n / R0_ + PAD0_);
-    static constexpr int IMG = (IMG_NAT > IMG_TRN ? IMG_NAT : IMG_TRN) + 8;
+    // image of the pffft-internal layout: blocks of 32 scalars padded to IBS scalars (bank-conflict-free
+    // scalar scatter on one side, linear 16-byte accesses on the other)
+    static constexpr int IBS = 32 + (sizeof(T) == 4 ? 4 : 2);
+    static constexpr int IMG_INT = (n / 16) * IBS / 2 + 2;  // in points
+    static constexpr int IMG_A = IMG_NAT > IMG_TRN ? IMG_NAT : IMG_TRN;
+    static constexpr int IMG = (IMG_A > IMG_INT ? IMG_A : IMG_INT) + 8;
     static constexpr int WG_THREADS = TPT > WGT_ ? TPT : WGT_;
     static constexpr int T_PER_WG = WG_THREADS / TPT;
     static constexpr size_t TABLE_BYTES = TWMODE_ == 1 ? (size_t)n * 2 * sizeof(T) : 0;
@@ -324,6 +329,17 @@ struct Tiled {
         }
     }
 
+    // scalar index, inside the internal-layout image, of the real part of bin k = j + d n/RR (imaginary part: + 4).
+    // RR/4 operands per spectrum quarter; odd quarters of a real spectrum run backwards (bin_of, fft_generic.h).
+    template <int RR> static __device__ __forceinline__ int ipos(int j, int d) {
+        constexpr int per = RR / 4;
+        const int qq = d / per;
+        const int r = j + (d % per) * (n / RR);
+        int tt = r;
+        if (REAL && (qq & 1)) tt = (n / 4 - r) & (n / 4 - 1);
+        return C::IBS * (tt >> 2) + 8 * qq + (tt & 3);
+    }
+
     // one mirror pair: a holds the bin k, b the bin n-k (spectrum X forward-out / backward-in, packed Z on the other side)
     struct Pair { CX a, b; };
     static __device__ __forceinline__ Pair pair1(CX A, CX Bin, CX wk) {
@@ -460,15 +476,31 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
                 for (int i = 0; i < NCH; ++i) v[i] = mk<T>(CO::get(raw[i], 0), CO::get(raw[i], 1));
             }
         } else {
-            // spectrum input: linear chunks -> natural-order image
+            if (in_int) {
+                // internal layout: linear 16-byte chunks into the padded block image, then every thread picks
+                // the scalars of its own stage-0 operands
+                chunk16* im16 = reinterpret_cast<chunk16*>(imgs);
+                constexpr int CPB = 32 / CH;  // chunks per 32-scalar block
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = t + TPT * i;
+                    im16[(c / CPB) * (C::IBS / CH) + (c % CPB)] = raw[i];
+                }
+                K::xsync();
+#pragma unroll
+                for (int u = 0; u < S0::B; ++u)
+#pragma unroll
+                    for (int q = 0; q < R0; ++q) {
+                        const int ip = K::template ipos<R0>(K::template jm<0>(t, u), q);
+                        v[u * R0 + q] = mk<T>(imgs[ip], imgs[ip + 4]);
+                    }
+                K::xsync();
+                if constexpr (REAL) K::pair_regs(v, t, w);
+            } else {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int c = tl + TPT * i;
-                if (in_int) {  // chunk c = scalars [c*CH, c*CH+CH) of the internal layout
-                    const int gi = (c * CH) >> 2, l0 = (c * CH) & 3, part = gi & 1;
-#pragma unroll
-                    for (int s = 0; s < CH; ++s) imgs[2 * phys_nat<C>(bin_of(gi, l0 + s, n, REAL)) + part] = CO::get(raw[i], s);
-                } else {       // canonical: CH/2 consecutive bins
+                {       // canonical: CH/2 consecutive bins
                     if constexpr (VEC == 2) {
                         lds_st(img + phys_nat<C>(2 * c), mk<T>(raw[i].x, raw[i].y));
                         lds_st(img + phys_nat<C>(2 * c + 1), mk<T>(raw[i].z, raw[i].w));
@@ -487,6 +519,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
                 }
             K::xsync();
             if constexpr (REAL) K::pair_regs(v, t, w);  // half-complex spectrum -> packed spectrum, in registers
+            }
         }
 
         PF_TSTAMP(1);
@@ -530,9 +563,33 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
                 }
             }
         } else {
-            // (real: pair pass in registers) canonical spectrum -> natural-order image -> linear chunks of the output layout
+            // (real: pair pass in registers) canonical spectrum -> LDS image -> linear chunks of the output layout
             if constexpr (REAL) K::pair_regs(v, t, w);
             PF_TSTAMP(12);
+            if (out_int) {
+                // scatter re / im scalars into the padded internal-layout image, read it back linearly
+#pragma unroll
+                for (int u = 0; u < SL::B; ++u)
+#pragma unroll
+                    for (int d = 0; d < RL; ++d) {
+                        const int ip = K::template ipos<RL>(K::template jm<C::NS - 1>(t, u), d);
+                        imgs[ip] = v[u * RL + d].x;
+                        imgs[ip + 4] = v[u * RL + d].y;
+                    }
+                K::xsync();
+                PF_TSTAMP(13);
+                const chunk16* im16 = reinterpret_cast<const chunk16*>(imgs);
+                chunk16* d16o = reinterpret_cast<chunk16*>(dst);
+                constexpr int CPB = 32 / CH;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = t + TPT * i;
+                    const chunk16 o = im16[(c / CPB) * (C::IBS / CH) + (c % CPB)];
+                    if (active) __builtin_nontemporal_store(o, d16o + c);
+                }
+                PF_TSTAMP(14);
+                K::xsync();
+            } else {
 #pragma unroll
             for (int u = 0; u < SL::B; ++u)
 #pragma unroll
@@ -564,6 +621,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
             }
             PF_TSTAMP(14);
             K::xsync();
+            }
         }
         PF_TSTAMP(15);
         if constexpr (!C::PREFETCH) {

@@ -365,11 +365,11 @@ static TiledEntry<T> tiled_entry(int dir, int real) {
     return e;
 }
 template <typename T>
-static bool tiled_lookup(int n, int dir, int real, TiledEntry<T>* e) {
+static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e) {
     if constexpr (sizeof(T) == 4) {
-        // real transforms of n >= 2048 points: the no-prefetch / two-workgroups-per-CU variants measure
-        // 10-30 % faster (gpurun_out/tiled3.log); complex ones keep the prefetching variants
-        if ((real && g_variant != 22) || g_variant == 20) {
+        // the no-prefetch / two-workgroups-per-CU variants only win for canonical-layout real transforms of
+        // 8192 points (0.65 vs 0.57 of the roofline, gpurun_out/tiled7.log); everything else prefetches
+        if ((real && ordered && n == 8192 && g_variant != 22) || g_variant == 20) {
             switch (n) {
                 case 2048: *e = tiled_entry<T, TiledAltF32::C2048>(dir, real); return true;
                 case 4096: *e = tiled_entry<T, TiledAltF32::C4096>(dir, real); return true;
@@ -397,7 +397,7 @@ template <typename T>
 static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     TiledEntry<T> e;
     const int real = s->transform == PFFFT_REAL;
-    if (!tiled_lookup<T>(s->n, dir, real, &e)) return -1;
+    if (!tiled_lookup<T>(s->n, dir, real, ordered, &e)) return -1;
     int rc = allow_big_lds(e.fn, e.lds);
     if (rc) return rc;
     int per_cu = 0;
