@@ -138,12 +138,48 @@ template <int DIR, typename V> __device__ __forceinline__ void dft16(V (&a)[16])
     for (int d = 0; d < 8; ++d) { a[2 * d] = b[d]; a[2 * d + 1] = c[d]; }
 }
 
+template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a)[R]);
+
+// Radix P*Q with coprime P, Q as a P x Q two-dimensional DFT (Good-Thomas index maps): no twiddles between
+// the two passes, the input / output permutations are compile-time register renamings.
+//   input  i(a, b)   = (Q a + P b) mod R        output k(ka, kb) = (ka Q (Q^-1 mod P) + kb P (P^-1 mod Q)) mod R
+__host__ __device__ constexpr int modinv_(int a, int m) {
+    for (int x = 1; x < m; ++x) if ((a * x) % m == 1) return x;
+    return 1;
+}
+template <int P, int Q, int DIR, typename V> __device__ __forceinline__ void dft_pfa(V (&a)[P * Q]) {
+    constexpr int R = P * Q, Qi = modinv_(Q % P, P), Pi = modinv_(P % Q, Q);
+    V y[P][Q];
+#pragma unroll
+    for (int b = 0; b < Q; ++b) {
+        V t[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) t[i] = a[(Q * i + P * b) % R];
+        dftR<P, DIR>(t);
+#pragma unroll
+        for (int i = 0; i < P; ++i) y[i][b] = t[i];
+    }
+#pragma unroll
+    for (int ka = 0; ka < P; ++ka) {
+        V u[Q];
+#pragma unroll
+        for (int b = 0; b < Q; ++b) u[b] = y[ka][b];
+        dftR<Q, DIR>(u);
+#pragma unroll
+        for (int kb = 0; kb < Q; ++kb) a[(ka * Q * Qi + kb * P * Pi) % R] = u[kb];
+    }
+}
+
 template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a)[R]) {
     if constexpr (R == 2) dft2<DIR>(a[0], a[1]);
     else if constexpr (R == 3) dft3<DIR>(a[0], a[1], a[2]);
     else if constexpr (R == 4) dft4<DIR>(a[0], a[1], a[2], a[3]);
     else if constexpr (R == 5) dft5<DIR>(a[0], a[1], a[2], a[3], a[4]);
+    else if constexpr (R == 6) dft_pfa<2, 3, DIR>(a);
     else if constexpr (R == 8) dft8<DIR>(a);
+    else if constexpr (R == 10) dft_pfa<2, 5, DIR>(a);
+    else if constexpr (R == 12) dft_pfa<4, 3, DIR>(a);
+    else if constexpr (R == 15) dft_pfa<3, 5, DIR>(a);
     else if constexpr (R == 16) dft16<DIR>(a);
 }
 

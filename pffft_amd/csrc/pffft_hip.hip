@@ -18,6 +18,8 @@
 #include "fft_generic.h"
 #include "fft_tiled.h"
 #include "fft_big.h"
+#include "fft_stock.h"
+#include "stock_plan.h"
 
 namespace pf {
 
@@ -111,6 +113,10 @@ struct Setup {
     GenericPlan gp;
     int gthreads;
     size_t glds;
+    // mixed-radix Stockham plans (fft_stock.h): [0] forward order, [1] backward order of the same radices
+    StockPlan sk[2];
+    int sk_threads = 0;
+    bool sk_ok = false;
     // device state (lazy: creating a setup never touches the GPU)
     std::mutex mu;        // guards the lazy device initialisation
     std::mutex stage_mu;  // guards the staging buffers of the legacy host-pointer entries
@@ -195,6 +201,10 @@ static Setup* new_setup(int N, int transform, int is_double) {
     else if ((s->n & (s->n - 1)) == 0 && s->n >= 16 && s->n <= 16384 &&
              (size_t)s->n * esz <= 128 * 1024)
         s->kernel = K_TILED;  // power-of-two sizes: register-tiled kernels (fft_tiled.h)
+    // every other size that fits: mixed-radix Stockham kernel (fft_stock.h); the in-place kernel of
+    // fft_generic.h keeps the sizes whose two images exceed LDS
+    if (s->kernel != K_BIG && s->n >= 32)
+        s->sk_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->sk, &s->sk_threads, LDS_MAX);
     return s;
 }
 
@@ -415,6 +425,31 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
     return 0;
 }
 
+template <typename T>
+static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    const bool bwd = dir == PFFFT_BACKWARD;
+    const StockPlan& sp = s->sk[bwd ? 1 : 0];
+    const size_t lds = stock_lds<T>(sp).total;
+    auto k = fft_stock_kernel<T>;
+    int rc = allow_big_lds(k, lds);
+    if (rc) return rc;
+    int per_cu = 0;
+    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), s->sk_threads, lds));
+    if (per_cu < 1) per_cu = 1;
+    if (g_variant >= 10 && g_variant < 20 && per_cu > g_variant - 10 && g_variant > 10) per_cu = g_variant - 10;
+    const size_t groups = (batch + sp.G - 1) / sp.G;
+    size_t grid = (size_t)num_cus() * per_cu;
+    if (grid > groups) grid = groups;
+    const bool want_dyn = (size_t)sp.G * sp.n * sizeof(cx<T>) >= 16 * 1024 && g_variant != 41;
+    unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    const int flags = ((bwd && !ordered) ? 1 : 0) | ((!bwd && !ordered) ? 2 : 0) | (bwd ? 4 : 0) |
+                      (s->transform == PFFFT_REAL ? 8 : 0);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(s->sk_threads), lds, st, in, out, batch, sp, flags,
+                       (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <typename T> static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, hipStream_t st);
 
 template <typename T>
@@ -487,12 +522,15 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
     int rc = ensure_device<T>(s);
     if (rc) return rc;
     if constexpr (sizeof(T) == 4) {
-        if (s->kernel == K_C1024_F32 && g_variant != 1 && batch < (1ull << 32))
+        if (s->kernel == K_C1024_F32 && g_variant != 1 && g_variant != 50 && batch < (1ull << 32))
             return launch_c1024(s, in, out, batch, dir, ordered, st);
     }
-    if (s->kernel == K_TILED && g_variant != 1 && batch < (1ull << 32))
+    if (s->kernel == K_TILED && g_variant != 1 && g_variant != 50 && batch < (1ull << 32))
         return launch_tiled<T>(s, in, out, batch, dir, ordered, st);
     if (s->kernel == K_BIG) return launch_big<T>(s, in, out, batch, dir, ordered, st);
+    // variants (A/B only): 50 = Stockham kernel also for the sizes that have a tiled kernel, 51 = never
+    if (s->sk_ok && ((s->kernel == K_GENERIC && g_variant != 1 && g_variant != 51) || g_variant == 50))
+        return launch_stock<T>(s, in, out, batch, dir, ordered, st);
     return launch_generic<T>(s, in, out, batch, dir, ordered, st);
 }
 
@@ -713,7 +751,7 @@ PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
         case pf::K_C1024_F32: return "c1024_f32";
         case pf::K_TILED: return "tiled";
         case pf::K_BIG: return "fourstep";
-        default: return "generic";
+        default: return (s->sk_ok && pf::g_variant != 51) ? "stockham" : "generic";
     }
 }
 PF_EXPORT const char* pffft_hip_last_error(void) { return pf::g_last_error.c_str(); }
