@@ -12,16 +12,20 @@
 //     stages for every size up to 9216;
 //   * Stockham autosort, twiddles on the inputs:  stage s (radix R, Ns = product of earlier radices),
 //     butterfly j < n/R reads x[j + q n/R] W_{Ns R}^(q (j mod Ns)), writes y[(j div Ns) Ns R + (j mod Ns) + d Ns];
-//     the first stage reads the vector straight from HBM, the last one writes the canonical spectrum
-//     straight back (both 8/16-byte accesses, consecutive lanes on consecutive points);
+//     the last stage writes the canonical spectrum straight to HBM (8/16-byte accesses, consecutive lanes on
+//     consecutive points);
 //   * exchanges ping-pong between two LDS images -> one barrier per stage; the image written by stage s is
 //     padded by pad[s] points per block of Ns R points (chosen on the host by simulating the bank
 //     conflicts of the write and of the following read);
+//   * WAVE SPECIALISATION: the workgroup is C compute threads + P producer wavefronts.  A producer issues the
+//     16-byte loads of the NEXT group of vectors at the top of an iteration, sits through the iteration's
+//     barriers with the loads in flight, and deposits them into the free image just before the closing
+//     barrier.  (First version, every wave loading its own stage-0 operands: the loads were in flight for
+//     one phase out of four, ~24 KB per CU on average = 2.4 TB/s by Little's law, measured 2.3-2.6.)
 //   * pffft-internal layout through an image of the layout itself (32-scalar blocks padded to IBS scalars):
 //     linear 16-byte chunks on the HBM side, scalar picks on the butterfly side (complex) or in the pair
 //     pass (real);
-//   * the backward transform is conj o forward o conj (sign flips on the HBM-side accesses), so there is
-//     one set of stage bodies per precision;
+//   * the backward transform is conj o forward o conj, so there is one set of stage bodies per precision;
 //   * groups of G consecutive vectors are pulled in order from the work counter (see fft_c1024.h).
 #pragma once
 #include "cxmath.h"
@@ -29,16 +33,31 @@
 
 namespace pf {
 
-constexpr int SK_MAX_STAGES = 6;
+constexpr int SK_MAX_STAGES = 4;
+constexpr int SK_NCHP = 16;  // 16-byte chunks a producer lane holds in registers
+
+// everything a stage needs, precomputed on the host (stock_plan.h): the kernel keeps the structs of all stages
+// in SGPRs for its whole life (first version: derived per stage per iteration with integer divisions and
+// indexed kernarg loads - 900 SALU + 1400 VALU instructions per 1024-point transform, 62 % of the wave
+// cycles waiting)
+struct StockStage {
+    int R, nb, Ns;           // radix, butterflies per vector (n / R), product of the earlier radices
+    int rpad, rstride;       // LDS source: operand q of butterfly j at j + (j div Ns) rpad + q rstride
+    int wblk;                // LDS destination: result d at (j div Ns) wblk + (j mod Ns) + d Ns
+    int twstep;              // W_{Ns R}^(q jm) = W_n^(q jm twstep)
+    unsigned m_nb, m_Ns;     // magic multipliers: x div d = umulhi(x, m) for x < 65536
+};
 
 struct StockPlan {
     int n, ns;       // complex points per transform, stages
     int G;           // transforms per workgroup pass
     int img;         // complex points per image slot (largest padded image)
-    int twmode;      // 0: padded W_n^j table in LDS, 1: base twiddle from the global table, powers recomputed
+    int twmode;      // 0: every twiddle from the padded W_n^j table in LDS; 2: base twiddle from that table,
+                     // powers recomputed (<= 4 products deep); 1: base twiddle from the global table, powers recomputed
     int twr_lds;     // W_N^k table of the real pair pass in LDS
-    unsigned char radix[SK_MAX_STAGES];
-    unsigned char pad[SK_MAX_STAGES];  // pad[s]: points added after every block of Ns_s R_s points of the image stage s writes
+    int C, P;        // compute threads, producer wavefronts (blockDim = C + 64 P)
+    unsigned m_n4, m_per, m_nchk;  // magic multipliers for n/4, n/2 + 1, 16-byte chunks per vector
+    StockStage st[SK_MAX_STAGES];
 };
 
 template <typename T> struct StockLds { size_t buf, tab, twr, next, total; };
@@ -46,7 +65,7 @@ template <typename T> __host__ __device__ inline StockLds<T> stock_lds(const Sto
     StockLds<T> l;
     size_t o = 0;
     l.buf = o; o += (size_t)2 * p.G * p.img * sizeof(cx<T>);
-    l.tab = o; if (p.twmode == 0) o += ((size_t)p.n + (p.n >> 5) + 1) * sizeof(cx<T>);
+    l.tab = o; if (p.twmode != 1) o += ((size_t)p.n + (p.n >> 5) + 1) * sizeof(cx<T>);
     l.twr = o; if (p.twr_lds) o += ((size_t)p.n / 2 + 1) * sizeof(cx<T>);
     l.next = o; o += 16;
     l.total = o;
@@ -57,62 +76,73 @@ enum { SK_G = 0, SK_L = 1, SK_I = 2 };  // operand source / result destination: 
 
 template <typename T> struct SkIbs { static constexpr int v = 32 + (sizeof(T) == 4 ? 4 : 2); };
 
+__device__ __forceinline__ int udiv(int x, unsigned m) { return (int)__umulhi((unsigned)x, m); }
+
 template <typename T> struct SkArgs {
-    int n, nb, Ns, total;        // total = vectors in this group * nb butterflies
-    float inv_nb, inv_Ns, inv_n4;
+    int tid, nthr;               // worker thread index / count (workgroup's compute threads, or one wavefront)
+    int slot0;                   // first image slot / vector of the group this worker owns
+    int n, total, maxtotal;      // total = vectors of this worker * nb butterflies (<= maxtotal, the plan's bound:
+                                 // the loops run to the plan's bound under a predicate so that a compile-time plan
+                                 // gives compile-time trip counts)
+    unsigned m_n4;
     int img;                     // slot stride of the LDS images (complex points)
-    int rpad, rstride;           // LDS source: operand q of butterfly j at j + (j div Ns) rpad + q rstride
-    int wblk;                    // LDS destination: result d at (j div Ns) wblk + (j mod Ns) + d Ns
-    int twstep, twmode;
-    T sgn_in, sgn_out;           // -1 conjugates on the HBM-side access (backward transform)
-    const cx<T>* lsrc; cx<T>* ldst;
-    const cx<T>* gsrc; cx<T>* gdst;   // vector 0 of the group (stride n)
-    const cx<T>* tw;
+    int twmode;
+    bool cj_in, cj_out;          // conjugate on the way in (first stage) / out (HBM store): backward transform
+    // LDS is addressed as (one base pointer) + integer offsets: a pointer selected between the two images or
+    // between an LDS and a global table becomes a generic pointer and every access a FLAT instruction
+    cx<T>* lds;                  // start of dynamic LDS
+    int src_off, dst_off, tab_off;   // source image, destination image, W_n^j table (complex points)
+    cx<T>* gdst;                 // vector 0 of the group (stride n)
+    const cx<T>* twg;            // global W_n^j table (twmode 1)
 };
 
 __device__ __forceinline__ int tpad(int i) { return i + (i >> 5); }
 
 template <typename T, int R, int SRC, int DST>
-__device__ __forceinline__ void sk_stage(const SkArgs<T>& a) {
+__device__ __forceinline__ void sk_stage(const StockStage& st, const SkArgs<T>& a) {
     typedef cx<T> CX;
     constexpr int IBS = SkIbs<T>::v;
     const int n4 = a.n >> 2;
-    for (int i = threadIdx.x; i < a.total; i += blockDim.x) {
-        const int g = fdiv(i, a.nb, a.inv_nb), j = i - g * a.nb;
+#pragma unroll
+    for (int i0 = 0; i0 < a.maxtotal; i0 += a.nthr) {
+        const int i = i0 + a.tid;
+        if (i >= a.total) continue;
+        const int gl = udiv(i, st.m_nb), j = i - gl * st.nb, g = a.slot0 + gl;
         int jd = j, jm = 0;
-        if (a.Ns > 1) { jd = fdiv(j, a.Ns, a.inv_Ns); jm = j - jd * a.Ns; }
+        if (st.Ns > 1) { jd = udiv(j, st.m_Ns); jm = j - jd * st.Ns; }
         CX v[R];
         // ---- operands
-        if constexpr (SRC == SK_G) {
-            const CX* p = a.gsrc + (size_t)g * a.n + j;
+        if constexpr (SRC == SK_L) {
+            const CX* p = a.lds + a.src_off + g * a.img + j + jd * st.rpad;
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[q] = __builtin_nontemporal_load(p + q * a.nb);
-#pragma unroll
-            for (int q = 0; q < R; ++q) v[q].y *= a.sgn_in;
-        } else if constexpr (SRC == SK_L) {
-            const CX* p = a.lsrc + g * a.img + j + jd * a.rpad;
-#pragma unroll
-            for (int q = 0; q < R; ++q) v[q] = p[q * a.rstride];
+            for (int q = 0; q < R; ++q) v[q] = p[q * st.rstride];
         } else {  // complex spectrum in the internal layout: point P = j + q nb sits in quarter P div n/4
-            const T* p = reinterpret_cast<const T*>(a.lsrc + g * a.img);
+            const T* p = reinterpret_cast<const T*>(a.lds + a.src_off + g * a.img);
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 int qq, r;
-                if constexpr (R % 4 == 0) { qq = q / (R / 4); r = j + (q % (R / 4)) * a.nb; }
-                else { const int P = j + q * a.nb; qq = fdiv(P, n4, a.inv_n4); r = P - qq * n4; }
+                if constexpr (R % 4 == 0) { qq = q / (R / 4); r = j + (q % (R / 4)) * st.nb; }
+                else { const int P = j + q * st.nb; qq = udiv(P, a.m_n4); r = P - qq * n4; }
                 const int ip = IBS * (r >> 2) + 8 * qq + (r & 3);
-                v[q] = mk<T>(p[ip], p[ip + 4] * a.sgn_in);
+                v[q] = mk<T>(p[ip], p[ip + 4]);
             }
         }
+        if (a.cj_in) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[q].y = -v[q].y;
+        }
         // ---- twiddles W_{Ns R}^(q jm) = W_n^(q jm twstep)
-        if (a.Ns > 1) {
-            const int k = jm * a.twstep;
+        if (st.Ns > 1) {
+            const int k = jm * st.twstep;
             if (a.twmode == 0) {
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], a.tw[tpad(q * k)]);
+                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], a.lds[a.tab_off + tpad(q * k)]);
             } else {
                 CX p[R < 4 ? 4 : R];
-                p[1] = a.tw[k];
+                // (the empty asm keeps the two loads in separate blocks: merged into one load through a selected
+                // pointer they become FLAT instructions)
+                if (a.twmode == 2) p[1] = a.lds[a.tab_off + tpad(k)];
+                else { p[1] = a.twg[k]; asm volatile(""); }
                 p[2] = cmul(p[1], p[1]);
                 if constexpr (R > 3) p[3] = cmul(p[2], p[1]);
                 if constexpr (R > 4) p[4] = cmul(p[2], p[2]);
@@ -135,23 +165,23 @@ __device__ __forceinline__ void sk_stage(const SkArgs<T>& a) {
         // ---- results
         if constexpr (DST == SK_G) {  // last stage: Ns = nb, result d is bin j + d nb
             CX* p = a.gdst + (size_t)g * a.n + j;
+            if (a.cj_out) {
 #pragma unroll
-            for (int d = 0; d < R; ++d) {
-                CX o = v[d];
-                o.y *= a.sgn_out;
-                __builtin_nontemporal_store(o, p + d * a.nb);
+                for (int d = 0; d < R; ++d) v[d].y = -v[d].y;
             }
-        } else if constexpr (DST == SK_L) {
-            CX* p = a.ldst + g * a.img + jd * a.wblk + jm;
 #pragma unroll
-            for (int d = 0; d < R; ++d) p[d * a.Ns] = v[d];
+            for (int d = 0; d < R; ++d) __builtin_nontemporal_store(v[d], p + d * st.nb);
+        } else if constexpr (DST == SK_L) {
+            CX* p = a.lds + a.dst_off + g * a.img + jd * st.wblk + jm;
+#pragma unroll
+            for (int d = 0; d < R; ++d) p[d * st.Ns] = v[d];
         } else {  // last stage, forward, complex: bin j + d nb into the internal-layout image
-            T* p = reinterpret_cast<T*>(a.ldst + g * a.img);
+            T* p = reinterpret_cast<T*>(a.lds + a.dst_off + g * a.img);
 #pragma unroll
             for (int d = 0; d < R; ++d) {
                 int qq, r;
-                if constexpr (R % 4 == 0) { qq = d / (R / 4); r = j + (d % (R / 4)) * a.nb; }
-                else { const int P = j + d * a.nb; qq = fdiv(P, n4, a.inv_n4); r = P - qq * n4; }
+                if constexpr (R % 4 == 0) { qq = d / (R / 4); r = j + (d % (R / 4)) * st.nb; }
+                else { const int P = j + d * st.nb; qq = udiv(P, a.m_n4); r = P - qq * n4; }
                 const int ip = IBS * (r >> 2) + 8 * qq + (r & 3);
                 p[ip] = v[d].x;
                 p[ip + 4] = v[d].y;
@@ -161,19 +191,19 @@ __device__ __forceinline__ void sk_stage(const SkArgs<T>& a) {
 }
 
 template <typename T, int SRC, int DST>
-__device__ __forceinline__ void sk_run(int R, const SkArgs<T>& a) {
-    switch (R) {
-        case 3: sk_stage<T, 3, SRC, DST>(a); break;
-        case 4: sk_stage<T, 4, SRC, DST>(a); break;
-        case 5: sk_stage<T, 5, SRC, DST>(a); break;
-        case 6: sk_stage<T, 6, SRC, DST>(a); break;
-        case 8: sk_stage<T, 8, SRC, DST>(a); break;
-        case 10: sk_stage<T, 10, SRC, DST>(a); break;
-        case 12: sk_stage<T, 12, SRC, DST>(a); break;
+__device__ __forceinline__ void sk_run(const StockStage& st, const SkArgs<T>& a) {
+    switch (st.R) {
+        case 3: sk_stage<T, 3, SRC, DST>(st, a); break;
+        case 4: sk_stage<T, 4, SRC, DST>(st, a); break;
+        case 5: sk_stage<T, 5, SRC, DST>(st, a); break;
+        case 6: sk_stage<T, 6, SRC, DST>(st, a); break;
+        case 8: sk_stage<T, 8, SRC, DST>(st, a); break;
+        case 10: sk_stage<T, 10, SRC, DST>(st, a); break;
+        case 12: sk_stage<T, 12, SRC, DST>(st, a); break;
         default:
             if constexpr (sizeof(T) == 4) {  // double stops at radix 12 (register budget)
-                if (R == 15) sk_stage<T, 15, SRC, DST>(a);
-                else sk_stage<T, 16, SRC, DST>(a);
+                if (st.R == 15) sk_stage<T, 15, SRC, DST>(st, a);
+                else sk_stage<T, 16, SRC, DST>(st, a);
             }
             break;
     }
@@ -181,205 +211,414 @@ __device__ __forceinline__ void sk_run(int R, const SkArgs<T>& a) {
 
 // scalar index (real part; imaginary part + 4) of half-complex bin k of a REAL transform inside the
 // internal-layout image: odd quarters run backwards (bin_of, fft_generic.h)
-template <typename T> __device__ __forceinline__ int sk_iposr(int k, int n4, float inv_n4) {
-    const int qq = fdiv(k, n4, inv_n4), r = k - qq * n4;
+template <typename T> __device__ __forceinline__ int sk_iposr(int k, int n4, unsigned m_n4) {
+    const int qq = udiv(k, m_n4), r = k - qq * n4;
     const int tt = (qq & 1) ? (r ? n4 - r : 0) : r;
     return SkIbs<T>::v * (tt >> 2) + 8 * qq + (tt & 3);
 }
 
+// One pass of the compute side over `cnt` vectors (image slots slot0 .. slot0 + cnt - 1) whose input sits in
+// image w ^ 1: (real backward pair pass) -> stages -> (real forward pair pass) -> (internal-layout copy-out).
+// WL = false: the worker is the workgroup's compute threads, phases are separated by __syncthreads.
+// WL = true : the worker is ONE wavefront that owns its slots, phases are separated by wave-local fences.
+// Every LDS-writing phase flips w; on return image w is free.
+template <bool WL> __device__ __forceinline__ void sk_sync() {
+    if constexpr (WL) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+
+template <typename T> struct SkCtx {
+    cx<T>* lds;
+    int bufsz, tab_off, twr_off;
+    bool in_int, out_int, bwd, real, twr_lds;
+    const cx<T>* twg;
+    const cx<T>* twrg;
+};
+
+template <typename T, bool WL>
+__device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStage& st0, const StockStage& st1,
+                                             const StockStage& st2, const StockStage& st3, const SkCtx<T>& c,
+                                             int wtid, int wn, int slot0, int cnt, int maxcnt, cx<T>* gout, int& w) {
+    typedef cx<T> CX;
+    typedef vec4<float> chunk16;
+    constexpr int IBS = SkIbs<T>::v, CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = IBS / CH;
+    CX* const lds = c.lds;
+    const int n = p.n, ns = p.ns, bufsz = c.bufsz;
+    const int n4 = n >> 2, half = n >> 1, per = half + 1;
+    const int nchk = (int)((size_t)n * sizeof(CX) / 16);       // 16-byte chunks per vector
+    const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);  // slot stride in chunks (img is even)
+    const bool in_int = c.in_int, out_int = c.out_int, bwd = c.bwd, real = c.real;
+
+    // ---- real backward: half-complex spectrum X -> conj of the packed spectrum Z' (the stages then run
+    //      a forward transform; the final conjugation happens on the store):
+    //      Z'[k] = S + D, Z'[n-k] = conj(S - D), S = A + B, D = i conj(W_N^k) (A - B), A = X[k], B = conj X[n-k]
+    if (real && bwd) {
+#pragma unroll
+        for (int id0 = 0; id0 < maxcnt * per; id0 += wn) {
+            const int id = id0 + wtid;
+            if (id >= cnt * per) continue;
+            const int gl = udiv(id, p.m_per), k = id - gl * per, g = slot0 + gl;
+            CX A, Bn;
+            if (in_int) {
+                const T* ps = reinterpret_cast<const T*>(lds + (w ^ 1) * bufsz + g * p.img);
+                const int ia = sk_iposr<T>(k, n4, p.m_n4);
+                A = mk<T>(ps[ia], ps[ia + 4]);
+                if (k != 0 && k != half) {
+                    const int ib = sk_iposr<T>(n - k, n4, p.m_n4);
+                    Bn = mk<T>(ps[ib], ps[ib + 4]);
+                } else Bn = A;
+            } else {
+                const CX* ps = lds + (w ^ 1) * bufsz + g * p.img;
+                A = ps[k];
+                Bn = (k != 0 && k != half) ? ps[n - k] : A;
+            }
+            CX* pd = lds + w * bufsz + g * p.img;
+            if (k == 0) {
+                pd[0] = mk<T>(A.x + A.y, -(A.x - A.y));
+            } else if (k == half) {
+                pd[half] = mk<T>((T)2 * A.x, (T)2 * A.y);  // conj(2 conj(A))
+            } else {
+                const CX B = conj(Bn);
+                CX wk;
+                if (c.twr_lds) wk = lds[c.twr_off + k];
+                else { wk = c.twrg[k]; asm volatile(""); }
+                const CX S = A + B, Dm = cmulc(A - B, wk);
+                const CX D = mk<T>(-Dm.y, Dm.x);
+                pd[k] = conj(S + D);
+                pd[n - k] = S - D;  // conj(conj(S - D))
+            }
+        }
+        w ^= 1;
+        sk_sync<WL>();
+    }
+    // ---- stages (unrolled over the at most SK_MAX_STAGES stage structs held in SGPRs)
+    {
+        SkArgs<T> a;
+        a.tid = wtid; a.nthr = wn; a.slot0 = slot0; a.n = n; a.m_n4 = p.m_n4; a.img = p.img; a.twmode = p.twmode;
+        a.lds = lds; a.tab_off = c.tab_off; a.gdst = gout; a.twg = c.twg;
+        a.cj_out = bwd;
+#pragma unroll
+        for (int s = 0; s < SK_MAX_STAGES; ++s) {
+            if (s < ns) {
+                const StockStage& st = s == 0 ? st0 : s == 1 ? st1 : s == 2 ? st2 : st3;
+                a.total = cnt * st.nb; a.maxtotal = maxcnt * st.nb;
+                a.src_off = (w ^ 1) * bufsz; a.dst_off = w * bufsz;
+                a.cj_in = (s == 0) && bwd && !real;   // real backward: the pair pass already conjugated
+                if (s < ns - 1) {
+                    if (s == 0 && in_int && !real) sk_run<T, SK_I, SK_L>(st, a);
+                    else sk_run<T, SK_L, SK_L>(st, a);
+                    w ^= 1;
+                    sk_sync<WL>();
+                } else {
+                    if (real && !bwd) { sk_run<T, SK_L, SK_L>(st, a); w ^= 1; sk_sync<WL>(); }
+                    else if (out_int) { sk_run<T, SK_L, SK_I>(st, a); w ^= 1; sk_sync<WL>(); }
+                    else sk_run<T, SK_L, SK_G>(st, a);
+                }
+            }
+        }
+    }
+    // ---- real forward: packed spectrum Z (natural image) -> half-complex spectrum X:
+    //      X[k] = S + D, X[n-k] = conj(S - D), S = (A+B)/2, D = -(i/2) W_N^k (A-B), A = Z[k], B = conj Z[n-k]
+    if (real && !bwd) {
+#pragma unroll
+        for (int id0 = 0; id0 < maxcnt * per; id0 += wn) {
+            const int id = id0 + wtid;
+            if (id >= cnt * per) continue;
+            const int gl = udiv(id, p.m_per), k = id - gl * per, g = slot0 + gl;
+            const CX* ps = lds + (w ^ 1) * bufsz + g * p.img;
+            CX Xa, Xb;
+            if (k == 0) {
+                const CX A = ps[0];
+                Xa = mk<T>(A.x + A.y, A.x - A.y);  // (DC, Nyquist): include/pffft/pffft.h:144-152
+                Xb = Xa;
+            } else if (k == half) {
+                Xa = conj(ps[half]);
+                Xb = Xa;
+            } else {
+                const CX A = ps[k], B = conj(ps[n - k]);
+                CX wk;
+                if (c.twr_lds) wk = lds[c.twr_off + k];
+                else { wk = c.twrg[k]; asm volatile(""); }
+                const CX S = (A + B) * (T)0.5, Dm = cmul((A - B) * (T)0.5, wk);
+                const CX D = mk<T>(Dm.y, -Dm.x);
+                Xa = S + D;
+                Xb = conj(S - D);
+            }
+            if (out_int) {
+                T* pd = reinterpret_cast<T*>(lds + w * bufsz + g * p.img);
+                const int ia = sk_iposr<T>(k, n4, p.m_n4);
+                pd[ia] = Xa.x; pd[ia + 4] = Xa.y;
+                if (k != 0 && k != half) {
+                    const int ib = sk_iposr<T>(n - k, n4, p.m_n4);
+                    pd[ib] = Xb.x; pd[ib + 4] = Xb.y;
+                }
+            } else {
+                CX* pd = gout + (size_t)g * n;
+                __builtin_nontemporal_store(Xa, pd + k);
+                if (k != 0 && k != half) __builtin_nontemporal_store(Xb, pd + (n - k));
+            }
+        }
+        if (out_int) { w ^= 1; sk_sync<WL>(); }
+    }
+    // ---- internal-layout output: the padded block image leaves as linear 16-byte chunks
+    if (out_int) {
+        const chunk16* s16 = reinterpret_cast<const chunk16*>(lds + (w ^ 1) * bufsz);
+        chunk16* d16 = reinterpret_cast<chunk16*>(gout);
+#pragma unroll
+        for (int cb = 0; cb < maxcnt * nchk; cb += wn) {
+            const int cc0 = cb + wtid;
+            if (cc0 >= cnt * nchk) continue;
+            const int gl = udiv(cc0, p.m_nchk), cc = cc0 - gl * nchk, g = slot0 + gl;
+            __builtin_nontemporal_store(s16[g * img16 + (cc / CPB) * BCH + (cc % CPB)], d16 + (size_t)g * nchk + cc);
+        }
+    }
+}
+
+// linear 16-byte chunk c of a group -> chunk offset inside the images (natural image, or internal-layout block image)
+template <typename T> __device__ __forceinline__ int sk_chunk_off(int g, int cc, int img16, bool in_int) {
+    constexpr int CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = SkIbs<T>::v / CH;
+    return g * img16 + (in_int ? (cc / CPB) * BCH + (cc % CPB) : cc);
+}
+
 // flags: bit0 input in internal layout, bit1 output in internal layout, bit2 backward, bit3 real
+//
+// Workgroup-phase kernel: C compute threads share every stage of the G vectors of a group; P producer wavefronts
+// hold the next group in registers across the iteration's barriers.
 template <typename T>
 __global__ void __launch_bounds__(1024)
 fft_stock_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, const cx<T>* __restrict__ twg,
                  const cx<T>* __restrict__ twrg, unsigned* ctr) {
     typedef cx<T> CX;
     typedef vec4<float> chunk16;
-    constexpr int IBS = SkIbs<T>::v, CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = IBS / CH;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const StockLds<T> L = stock_lds<T>(p);
-    CX* bufs[2];
-    bufs[0] = reinterpret_cast<CX*>(smem_raw + L.buf);
-    bufs[1] = bufs[0] + (size_t)p.G * p.img;
+    SkCtx<T> c;
+    c.lds = reinterpret_cast<CX*>(smem_raw);
+    CX* const lds = c.lds;
+    c.bufsz = p.G * p.img;          // image b starts at complex offset b * bufsz (L.buf == 0)
+    c.tab_off = (int)(L.tab / sizeof(CX)); c.twr_off = (int)(L.twr / sizeof(CX));
+    c.in_int = flags & 1; c.out_int = flags & 2; c.bwd = flags & 4; c.real = flags & 8;
+    c.twg = twg; c.twrg = twrg;
+    c.twr_lds = p.twr_lds && c.real;
     unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + L.next);
-    const int n = p.n, G = p.G, ns = p.ns;
-    const bool in_int = flags & 1, out_int = flags & 2, bwd = flags & 4, real = flags & 8;
-    const CX* tw = twg;
-    const CX* twr = twrg;
-    if (p.twmode == 0) {
-        CX* t = reinterpret_cast<CX*>(smem_raw + L.tab);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) t[tpad(i)] = twg[i];
-        tw = t;
-    }
-    if (p.twr_lds && real) {
-        CX* t = reinterpret_cast<CX*>(smem_raw + L.twr);
-        for (int i = threadIdx.x; i <= n / 2; i += blockDim.x) t[i] = twrg[i];
-        twr = t;
-    }
-    const int n4 = n >> 2, half = n >> 1, per = half + 1;
-    const int nchk = (int)((size_t)n * sizeof(CX) / 16);  // 16-byte chunks per vector
-    const float inv_n4 = 1.0f / (float)n4, inv_per = 1.0f / (float)per, inv_nchk = 1.0f / (float)nchk;
-    const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);  // slot stride in chunks (img is even)
+    const int n = p.n, G = p.G, ns = p.ns, C = p.C;
+    const int tid = threadIdx.x;
+    if (p.twmode != 1)
+        for (int i = tid; i < n; i += blockDim.x) lds[c.tab_off + tpad(i)] = twg[i];
+    if (c.twr_lds)
+        for (int i = tid; i <= n / 2; i += blockDim.x) lds[c.twr_off + i] = twrg[i];
+    const int nchk = (int)((size_t)n * sizeof(CX) / 16);
+    const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);
+    // LDS-writing compute phases per iteration (each followed by one barrier); + the closing barrier
+    const int last_lds = (c.real && !c.bwd) || c.out_int;
+    const int Fc = ((c.real && c.bwd) ? 1 : 0) + (ns - 1) + (last_lds ? 1 : 0) + ((c.real && !c.bwd && c.out_int) ? 1 : 0);
 
     const bool dyn = ctr != nullptr;
-    unsigned pend = 0, g0 = blockIdx.x;
-    if (dyn && threadIdx.x == 0) {
+    unsigned pend = 0;
+    if (dyn && tid == C) {
         s_next[0] = atomicAdd(&ctr[0], 1u);
+        s_next[1] = atomicAdd(&ctr[0], 1u);
         pend = atomicAdd(&ctr[0], 1u);
     }
     __syncthreads();
-    if (dyn) g0 = s_next[0];
-    int w = 0;  // image the next LDS-writing phase writes; the phase after it reads bufs[w ^ 1] ... (ping-pong)
-    for (unsigned it = 0; (size_t)g0 * G < batch; ++it) {
-        if (dyn && threadIdx.x == 0) {
-            s_next[(it + 1) & 1] = pend;
+    unsigned gcur = dyn ? s_next[0] : blockIdx.x;
+    unsigned gnx = dyn ? s_next[1] : blockIdx.x + gridDim.x;
+    __syncthreads();
+    int w = 0;  // image the next LDS-writing phase writes; the phase after it reads image w ^ 1 (ping-pong)
+
+    if (tid >= C) {
+        // ======================================================================= producer wavefronts
+        const int pl = tid - C, PT = blockDim.x - C;
+        const chunk16* s16 = reinterpret_cast<const chunk16*>(in);
+        chunk16 raw[SK_NCHP];
+        // unconditional loads (a predicated load costs a branch and pins its address): chunks beyond the
+        // group's vectors re-read its last chunk, groups beyond the batch re-read chunk 0 of the input
+        auto issue = [&](unsigned grp) {
+            const size_t t0 = (size_t)grp * G;
+            const int cnt = t0 < batch ? (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G) : 0;
+            const int lastc = cnt ? cnt * nchk - 1 : 0;
+            const chunk16* s = cnt ? s16 + t0 * nchk : s16;
+#pragma unroll
+            for (int i = 0; i < SK_NCHP; ++i) {
+                const int cix = pl + PT * i;
+                raw[i] = __builtin_nontemporal_load(s + (cix < lastc ? cix : lastc));
+            }
+        };
+        auto deposit = [&](int boff) {
+            chunk16* d16 = reinterpret_cast<chunk16*>(lds + boff);
+            const int tot = G * nchk;  // chunks beyond the group's vectors hold stale values nobody reads
+#pragma unroll
+            for (int i = 0; i < SK_NCHP; ++i) {
+                const int cix = pl + PT * i;
+                if (cix < tot) {
+                    const int g = udiv(cix, p.m_nchk), cc = cix - g * nchk;
+                    d16[sk_chunk_off<T>(g, cc, img16, c.in_int)] = raw[i];
+                }
+            }
+        };
+        issue(gcur);
+        deposit(w * c.bufsz);
+        w ^= 1;
+        __syncthreads();
+        for (unsigned it = 0; (size_t)gcur * G < batch; ++it) {
+            issue(gnx);
+            if (dyn && tid == C) {
+                s_next[it & 1] = pend;
+                pend = atomicAdd(&ctr[0], 1u);
+            }
+            for (int b = 0; b < Fc; ++b) __syncthreads();
+            w ^= (Fc & 1);
+            deposit(w * c.bufsz);
+            w ^= 1;
+            __syncthreads();
+            gcur = gnx;
+            gnx = dyn ? s_next[it & 1] : gnx + gridDim.x;
+        }
+        if (dyn && tid == C) {
+            __threadfence();
+            unsigned d = atomicAdd(&ctr[1], 1u);
+            if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+        }
+        return;
+    }
+
+    // =========================================================================== compute wavefronts
+    const StockStage st0 = p.st[0], st1 = p.st[1], st2 = p.st[2], st3 = p.st[3];
+    w ^= 1;
+    __syncthreads();  // first deposit
+    for (unsigned it = 0; (size_t)gcur * G < batch; ++it) {
+        const size_t t0 = (size_t)gcur * G;
+        const int g_here = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);
+        CX* gout = reinterpret_cast<CX*>(out) + t0 * n;
+        sk_iteration<T, false>(p, st0, st1, st2, st3, c, tid, C, 0, g_here, G, gout, w);
+        // ---- closing barrier: the producers have deposited the next group into image w
+        w ^= 1;
+        __syncthreads();
+        gcur = gnx;
+        gnx = dyn ? s_next[it & 1] : gnx + gridDim.x;
+    }
+}
+
+// Wave-local kernel (small n): every wavefront owns G / (waves per workgroup) image slots and runs ALL phases on
+// them between wave-local fences - no workgroup barrier inside a transform, wavefronts drift apart and hide each
+// other's LDS / HBM latency.  Each wavefront prefetches its own slots of the next group into SK_NCHW registers
+// per lane.  One __syncthreads per iteration hands the next group index over.
+constexpr int SK_NCHW = 8;
+constexpr int SK_WL_WAVES = 4;  // wavefronts per workgroup of the wave-local kernel
+template <typename T>
+__device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, const StockPlan& p, int flags,
+                                           const cx<T>* __restrict__ twg, const cx<T>* __restrict__ twrg, unsigned* ctr) {
+    typedef cx<T> CX;
+    typedef vec4<float> chunk16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const StockLds<T> L = stock_lds<T>(p);
+    SkCtx<T> c;
+    c.lds = reinterpret_cast<CX*>(smem_raw);
+    CX* const lds = c.lds;
+    c.bufsz = p.G * p.img;
+    c.tab_off = (int)(L.tab / sizeof(CX)); c.twr_off = (int)(L.twr / sizeof(CX));
+    c.in_int = flags & 1; c.out_int = flags & 2; c.bwd = flags & 4; c.real = flags & 8;
+    c.twg = twg; c.twrg = twrg;
+    c.twr_lds = p.twr_lds && c.real;
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + L.next);
+    const int n = p.n, G = p.G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Gw = G / SK_WL_WAVES, slot0 = wave * Gw;
+    if (p.twmode != 1)
+        for (int i = tid; i < n; i += 64 * SK_WL_WAVES) lds[c.tab_off + tpad(i)] = twg[i];
+    if (c.twr_lds)
+        for (int i = tid; i <= n / 2; i += 64 * SK_WL_WAVES) lds[c.twr_off + i] = twrg[i];
+    const int nchk = (int)((size_t)n * sizeof(CX) / 16);
+    const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);
+    const StockStage st0 = p.st[0], st1 = p.st[1], st2 = p.st[2], st3 = p.st[3];
+
+    const bool dyn = ctr != nullptr;
+    unsigned pend = 0;
+    if (dyn && tid == 0) {
+        s_next[0] = atomicAdd(&ctr[0], 1u);
+        s_next[1] = atomicAdd(&ctr[0], 1u);
+        pend = atomicAdd(&ctr[0], 1u);
+    }
+    __syncthreads();
+    unsigned gcur = dyn ? s_next[0] : blockIdx.x;
+    unsigned gnx = dyn ? s_next[1] : blockIdx.x + gridDim.x;
+    __syncthreads();
+
+    const chunk16* s16 = reinterpret_cast<const chunk16*>(in);
+    chunk16 raw[SK_NCHW];
+    // this wavefront's vectors of group grp: count, and their chunks into registers (clamped, unconditional)
+    auto mine = [&](unsigned grp) -> int {
+        const size_t t0 = (size_t)grp * G + slot0;
+        return t0 < batch ? (int)((batch - t0) < (size_t)Gw ? (batch - t0) : (size_t)Gw) : 0;
+    };
+    auto issue = [&](unsigned grp) {
+        const int cnt = mine(grp);
+        const int lastc = cnt ? cnt * nchk - 1 : 0;
+        const chunk16* s = cnt ? s16 + ((size_t)grp * G + slot0) * nchk : s16;
+#pragma unroll
+        for (int i = 0; i < SK_NCHW; ++i) {
+            const int cix = lane + 64 * i;
+            raw[i] = __builtin_nontemporal_load(s + (cix < lastc ? cix : lastc));
+        }
+    };
+    auto deposit = [&](int boff) {
+        chunk16* d16 = reinterpret_cast<chunk16*>(lds + boff);
+        const int tot = Gw * nchk;
+#pragma unroll
+        for (int i = 0; i < SK_NCHW; ++i) {
+            const int cix = lane + 64 * i;
+            if (cix < tot) {
+                const int gl = udiv(cix, p.m_nchk), cc = cix - gl * nchk;
+                d16[sk_chunk_off<T>(slot0 + gl, cc, img16, c.in_int)] = raw[i];
+            }
+        }
+    };
+    int w = 0;
+    issue(gcur);
+    deposit(w * c.bufsz);
+    w ^= 1;
+    sk_sync<true>();
+    for (unsigned it = 0; (size_t)gcur * G < batch; ++it) {
+        if (dyn && tid == 0) {
+            s_next[it & 1] = pend;
             pend = atomicAdd(&ctr[0], 1u);
         }
-        const size_t t0 = (size_t)g0 * G;
-        const int g_here = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);
-        const CX* gin = reinterpret_cast<const CX*>(in) + t0 * n;
-        CX* gout = reinterpret_cast<CX*>(out) + t0 * n;
-        unsigned gn = g0 + gridDim.x;
-        bool have_gn = !dyn;
-#define SK_SYNC() do { __syncthreads(); if (!have_gn) { gn = s_next[(it + 1) & 1]; have_gn = true; } } while (0)
-
-        // ---- internal-layout input: linear 16-byte chunks into the padded block image
-        if (in_int) {
-            const chunk16* s16 = reinterpret_cast<const chunk16*>(gin);
-            chunk16* d16 = reinterpret_cast<chunk16*>(bufs[w]);
-            for (int c = threadIdx.x; c < g_here * nchk; c += blockDim.x) {
-                const int g = fdiv(c, nchk, inv_nchk), cc = c - g * nchk;
-                d16[g * img16 + (cc / CPB) * BCH + (cc % CPB)] = __builtin_nontemporal_load(s16 + c);
-            }
-            w ^= 1;
-            SK_SYNC();
-        }
-        // ---- real backward: half-complex spectrum X -> conj of the packed spectrum Z' (the stages then run
-        //      a forward transform; the final conjugation happens on the store):
-        //      Z'[k] = S + D, Z'[n-k] = conj(S - D), S = A + B, D = i conj(W_N^k) (A - B), A = X[k], B = conj X[n-k]
-        if (real && bwd) {
-            const T* si = reinterpret_cast<const T*>(bufs[w ^ 1]);
-            for (int id = threadIdx.x; id < g_here * per; id += blockDim.x) {
-                const int g = fdiv(id, per, inv_per), k = id - g * per;
-                CX A, Bn;
-                if (in_int) {
-                    const T* ps = si + (size_t)g * p.img * 2;
-                    const int ia = sk_iposr<T>(k, n4, inv_n4);
-                    A = mk<T>(ps[ia], ps[ia + 4]);
-                    if (k != 0 && k != half) {
-                        const int ib = sk_iposr<T>(n - k, n4, inv_n4);
-                        Bn = mk<T>(ps[ib], ps[ib + 4]);
-                    } else Bn = A;
-                } else {
-                    const CX* ps = gin + (size_t)g * n;
-                    A = ps[k];
-                    Bn = (k != 0 && k != half) ? ps[n - k] : A;
-                }
-                CX* pd = bufs[w] + g * p.img;
-                if (k == 0) {
-                    pd[0] = mk<T>(A.x + A.y, -(A.x - A.y));
-                } else if (k == half) {
-                    pd[half] = mk<T>((T)2 * A.x, (T)2 * A.y);  // conj(2 conj(A))
-                } else {
-                    const CX B = conj(Bn);
-                    const CX S = A + B, Dm = cmulc(A - B, twr[k]);
-                    const CX D = mk<T>(-Dm.y, Dm.x);
-                    pd[k] = conj(S + D);
-                    pd[n - k] = S - D;  // conj(conj(S - D))
-                }
-            }
-            w ^= 1;
-            SK_SYNC();
-        }
-        // ---- stages
-        {
-            int Ns = 1;
-            for (int s = 0; s < ns; ++s) {
-                const int R = p.radix[s];
-                SkArgs<T> a;
-                a.n = n; a.nb = n / R; a.Ns = Ns; a.total = g_here * a.nb;
-                a.inv_nb = 1.0f / (float)a.nb; a.inv_Ns = 1.0f / (float)Ns; a.inv_n4 = inv_n4;
-                a.img = p.img;
-                a.rpad = s ? p.pad[s - 1] : 0;
-                a.rstride = a.nb + (s ? (a.nb / Ns) * p.pad[s - 1] : 0);
-                a.wblk = Ns * R + p.pad[s];
-                a.twstep = n / (Ns * R); a.twmode = p.twmode;
-                a.sgn_in = bwd ? (T)-1 : (T)1; a.sgn_out = a.sgn_in;
-                a.lsrc = bufs[w ^ 1]; a.ldst = bufs[w];
-                a.gsrc = gin; a.gdst = gout;
-                a.tw = tw;
-                if (s == 0) {
-                    if (real && bwd) sk_run<T, SK_L, SK_L>(R, a);
-                    else if (in_int) sk_run<T, SK_I, SK_L>(R, a);
-                    else sk_run<T, SK_G, SK_L>(R, a);
-                    w ^= 1;
-                    SK_SYNC();
-                } else if (s < ns - 1) {
-                    sk_run<T, SK_L, SK_L>(R, a);
-                    w ^= 1;
-                    SK_SYNC();
-                } else {
-                    if (real && !bwd) { a.wblk = n; sk_run<T, SK_L, SK_L>(R, a); w ^= 1; SK_SYNC(); }
-                    else if (out_int) { sk_run<T, SK_L, SK_I>(R, a); w ^= 1; SK_SYNC(); }
-                    else sk_run<T, SK_L, SK_G>(R, a);
-                }
-                Ns *= R;
-            }
-        }
-        // ---- real forward: packed spectrum Z (natural image) -> half-complex spectrum X:
-        //      X[k] = S + D, X[n-k] = conj(S - D), S = (A+B)/2, D = -(i/2) W_N^k (A-B), A = Z[k], B = conj Z[n-k]
-        if (real && !bwd) {
-            T* di = reinterpret_cast<T*>(bufs[w]);
-            for (int id = threadIdx.x; id < g_here * per; id += blockDim.x) {
-                const int g = fdiv(id, per, inv_per), k = id - g * per;
-                const CX* ps = bufs[w ^ 1] + g * p.img;
-                CX Xa, Xb;
-                if (k == 0) {
-                    const CX A = ps[0];
-                    Xa = mk<T>(A.x + A.y, A.x - A.y);  // (DC, Nyquist): include/pffft/pffft.h:144-152
-                    Xb = Xa;
-                } else if (k == half) {
-                    Xa = conj(ps[half]);
-                    Xb = Xa;
-                } else {
-                    const CX A = ps[k], B = conj(ps[n - k]);
-                    const CX S = (A + B) * (T)0.5, Dm = cmul((A - B) * (T)0.5, twr[k]);
-                    const CX D = mk<T>(Dm.y, -Dm.x);
-                    Xa = S + D;
-                    Xb = conj(S - D);
-                }
-                if (out_int) {
-                    T* pd = di + (size_t)g * p.img * 2;
-                    const int ia = sk_iposr<T>(k, n4, inv_n4);
-                    pd[ia] = Xa.x; pd[ia + 4] = Xa.y;
-                    if (k != 0 && k != half) {
-                        const int ib = sk_iposr<T>(n - k, n4, inv_n4);
-                        pd[ib] = Xb.x; pd[ib + 4] = Xb.y;
-                    }
-                } else {
-                    CX* pd = gout + (size_t)g * n;
-                    __builtin_nontemporal_store(Xa, pd + k);
-                    if (k != 0 && k != half) __builtin_nontemporal_store(Xb, pd + (n - k));
-                }
-            }
-            if (out_int) { w ^= 1; SK_SYNC(); }
-        }
-        // ---- internal-layout output: the padded block image leaves as linear 16-byte chunks
-        if (out_int) {
-            const chunk16* s16 = reinterpret_cast<const chunk16*>(bufs[w ^ 1]);
-            chunk16* d16 = reinterpret_cast<chunk16*>(gout);
-            for (int c = threadIdx.x; c < g_here * nchk; c += blockDim.x) {
-                const int g = fdiv(c, nchk, inv_nchk), cc = c - g * nchk;
-                __builtin_nontemporal_store(s16[g * img16 + (cc / CPB) * BCH + (cc % CPB)], d16 + c);
-            }
-        }
-#undef SK_SYNC
-        g0 = gn;
+        issue(gnx);
+        const int cnt = mine(gcur);
+        CX* gout = reinterpret_cast<CX*>(out) + (size_t)gcur * G * n;
+        sk_iteration<T, true>(p, st0, st1, st2, st3, c, lane, 64, slot0, cnt, Gw, gout, w);
+        sk_sync<true>();          // the last phase's LDS reads are done before ...
+        deposit(w * c.bufsz);     // ... the next group lands in the free image
+        w ^= 1;
+        __syncthreads();          // (also orders the deposit against the next iteration's reads)
+        gcur = gnx;
+        gnx = dyn ? s_next[it & 1] : gnx + gridDim.x;
     }
-    if (dyn && threadIdx.x == 0) {
+    if (dyn && tid == 0) {
         __threadfence();
         unsigned d = atomicAdd(&ctr[1], 1u);
         if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+fft_stock_wl_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, const cx<T>* __restrict__ twg,
+                    const cx<T>* __restrict__ twrg, unsigned* ctr) {
+    sk_wl_body<T>(in, out, batch, p, flags, twg, twrg, ctr);
+}
+
+// The same body with the plan and the flags as compile-time constants (stock_plans_gen.h, written by
+// tools/gen_stock_plans): radix dispatch, index arithmetic, LDS offsets and loop trip counts fold away, what is
+// left per butterfly is its loads, twiddle products, the DFT and its stores.  (The run-time plan costs ~100
+// VALU + ~60 SALU instructions per point and is issue-bound at 0.3 of the HBM roofline whatever the
+// organisation - workgroup phases, producer wavefronts or wave-local all measured 0.26-0.44.)
+template <typename T, class PT, int FLAGS>
+__global__ void __launch_bounds__(256)
+fft_stock_wl_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
+                       const cx<T>* __restrict__ twrg, unsigned* ctr) {
+    constexpr StockPlan p = PT::value;
+    sk_wl_body<T>(in, out, batch, p, FLAGS, twg, twrg, ctr);
 }
 
 }  // namespace pf

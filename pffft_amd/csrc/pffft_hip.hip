@@ -20,6 +20,7 @@
 #include "fft_big.h"
 #include "fft_stock.h"
 #include "stock_plan.h"
+#include "stock_plans_gen.h"
 
 namespace pf {
 
@@ -114,9 +115,9 @@ struct Setup {
     int gthreads;
     size_t glds;
     // mixed-radix Stockham plans (fft_stock.h): [0] forward order, [1] backward order of the same radices
-    StockPlan sk[2];
-    int sk_threads = 0;
-    bool sk_ok = false;
+    StockPlan sk[2], skw[2];          // workgroup-phase plans; wave-local plans (small n)
+    int sk_threads = 0, skw_threads = 0;
+    bool sk_ok = false, skw_ok = false;
     // device state (lazy: creating a setup never touches the GPU)
     std::mutex mu;        // guards the lazy device initialisation
     std::mutex stage_mu;  // guards the staging buffers of the legacy host-pointer entries
@@ -204,7 +205,11 @@ static Setup* new_setup(int N, int transform, int is_double) {
     // every other size that fits: mixed-radix Stockham kernel (fft_stock.h); the in-place kernel of
     // fft_generic.h keeps the sizes whose two images exceed LDS
     if (s->kernel != K_BIG && s->n >= 32)
-        s->sk_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->sk, &s->sk_threads, LDS_MAX);
+    {
+        bool wl = false;
+        s->sk_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->sk, &s->sk_threads, &wl, false, LDS_MAX);
+        s->skw_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->skw, &s->skw_threads, &wl, true, LDS_MAX) && wl;
+    }
     return s;
 }
 
@@ -428,23 +433,45 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
 template <typename T>
 static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     const bool bwd = dir == PFFFT_BACKWARD;
-    const StockPlan& sp = s->sk[bwd ? 1 : 0];
+    // variant 52: workgroup-phase kernel also where the wave-local one applies (A/B)
+    const bool wl = s->skw_ok && g_variant != 52;
+    const StockPlan& sp = wl ? s->skw[bwd ? 1 : 0] : s->sk[bwd ? 1 : 0];
+    const int threads = wl ? s->skw_threads : s->sk_threads;
     const size_t lds = stock_lds<T>(sp).total;
-    auto k = fft_stock_kernel<T>;
+    const int flags = ((bwd && !ordered) ? 1 : 0) | ((!bwd && !ordered) ? 2 : 0) | (bwd ? 4 : 0) |
+                      (s->transform == PFFFT_REAL ? 8 : 0);
+    const size_t groups = (batch + sp.G - 1) / sp.G;
+    const bool want_dyn = (size_t)sp.G * sp.n * sizeof(cx<T>) >= 16 * 1024 && g_variant != 41;
+    // the same kernel body instantiated on this very plan as a compile-time constant, when there is one
+    // (stock_plans_gen.h; variant 53 = always the run-time plan, A/B)
+    if constexpr (sizeof(T) == 4) {
+        StockCtFn cf = (wl && g_variant != 53) ? stock_ct_lookup_f32(sp, flags) : nullptr;
+        if (cf) {
+            int rc = allow_big_lds(cf, lds);
+            if (rc) return rc;
+            int per_cu = 0;
+            PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(cf), threads, lds));
+            if (per_cu < 1) per_cu = 1;
+            size_t grid = (size_t)num_cus() * per_cu;
+            if (grid > groups) grid = groups;
+            unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+            hipLaunchKernelGGL(cf, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch,
+                               (const cx<float>*)s->d_tw, (const cx<float>*)s->d_twr, ctr);
+            PF_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
+    auto k = wl ? fft_stock_wl_kernel<T> : fft_stock_kernel<T>;
     int rc = allow_big_lds(k, lds);
     if (rc) return rc;
     int per_cu = 0;
-    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), s->sk_threads, lds));
+    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), threads, lds));
     if (per_cu < 1) per_cu = 1;
     if (g_variant >= 10 && g_variant < 20 && per_cu > g_variant - 10 && g_variant > 10) per_cu = g_variant - 10;
-    const size_t groups = (batch + sp.G - 1) / sp.G;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
-    const bool want_dyn = (size_t)sp.G * sp.n * sizeof(cx<T>) >= 16 * 1024 && g_variant != 41;
     unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
-    const int flags = ((bwd && !ordered) ? 1 : 0) | ((!bwd && !ordered) ? 2 : 0) | (bwd ? 4 : 0) |
-                      (s->transform == PFFFT_REAL ? 8 : 0);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(s->sk_threads), lds, st, in, out, batch, sp, flags,
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch, sp, flags,
                        (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
     PF_CHECK(hipGetLastError());
     return 0;

@@ -39,6 +39,9 @@ static int sk_lds_cycles(int kind, const long long* addr) {
     return tot;
 }
 
+// x div d == umulhi(x, sk_magic(d)) for x < 65536, 1 < d < 65536
+static unsigned sk_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1); }
+
 static void sk_search(int rem, int minr, const std::vector<int>& set, std::vector<int>& cur, std::vector<int>& best) {
     if (rem == 1) {
         auto sum = [](const std::vector<int>& v) { int s = 0; for (int x : v) s += x; return s; };
@@ -113,44 +116,71 @@ static int sk_pick_pad(int n, int esz, int G, int threads, int Ns, int R, int Rn
 }
 
 // returns false when the size cannot run on this kernel (single stage, or the images do not fit in LDS)
-static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* threads_out, size_t lds_max) {
+static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* threads_out, bool* wl_out, bool allow_wl,
+                     size_t lds_max) {
     const int esz = is_double ? 16 : 8;
     static const std::vector<int> setf = {16, 15, 12, 10, 8, 6, 5, 4, 3};
     static const std::vector<int> setd = {12, 10, 8, 6, 5, 4, 3};
     std::vector<int> cur, best;
     sk_search(n, 0, is_double ? setd : setf, cur, best);
-    if (best.size() < 2) return false;
-    const int target = is_double ? 1024 : 2048;
-    int G = std::max(1, target / n);
-    int threads = (int)(((size_t)G * n / 8 + 63) / 64 * 64);
-    threads = std::min(1024, std::max(128, threads));
+    if (best.size() < 2 || best.size() > SK_MAX_STAGES) return false;
+    const int nchk = n * esz / 16;
+    // small n: wave-local kernel, 4 wavefronts per workgroup, each owning Gw vectors (<= 4 KiB, or one vector)
+    const bool wl = allow_wl && (size_t)n * esz <= 64 * SK_NCHW * 16;
+    int G, P = 0, threads;
+    if (wl) {
+        const int Gw = std::max(1, 4096 / (n * esz));
+        G = 4 * Gw;
+        threads = 256;
+    } else {
+        const int target = is_double ? 1024 : 2048;
+        G = std::max(1, target / n);
+        // producer wavefronts: SK_NCHP 16-byte chunks per lane hold one group of G vectors
+        P = (G * nchk + 64 * SK_NCHP - 1) / (64 * SK_NCHP);
+        threads = (int)(((size_t)G * n / 8 + 63) / 64 * 64);
+        threads = std::min(1024 - 64 * P, std::max(128, threads));
+        if (threads < 64) return false;
+    }
     for (int dir = 0; dir < 2; ++dir) {
         StockPlan& p = out[dir];
         memset(&p, 0, sizeof p);
         const std::vector<int> r = sk_order(best, dir == 1);
-        p.n = n; p.ns = (int)r.size(); p.G = G;
-        int Ns = 1, img = n;
+        p.n = n; p.ns = (int)r.size(); p.G = G; p.C = threads; p.P = P;
+        int Ns = 1, img = n, prevpad = 0;
         for (int s = 0; s < p.ns; ++s) {
-            p.radix[s] = (unsigned char)r[s];
+            StockStage& st = p.st[s];
+            const int R = r[s], nb = n / R;
+            int pad = 0;
             if (s + 1 < p.ns) {
-                p.pad[s] = (unsigned char)sk_pick_pad(n, esz, G, threads, Ns, r[s], r[s + 1]);
-                img = std::max(img, n + (n / (Ns * r[s])) * p.pad[s]);
+                pad = wl ? sk_pick_pad(n, esz, G / 4, 64, Ns, R, r[s + 1]) : sk_pick_pad(n, esz, G, threads, Ns, R, r[s + 1]);
+                img = std::max(img, n + (n / (Ns * R)) * pad);
             }
-            Ns *= r[s];
+            st.R = R; st.nb = nb; st.Ns = Ns;
+            st.rpad = prevpad;
+            st.rstride = nb + (s ? (nb / Ns) * prevpad : 0);
+            st.wblk = Ns * R + pad;
+            st.twstep = n / (Ns * R);
+            st.m_nb = sk_magic(nb); st.m_Ns = sk_magic(Ns);
+            prevpad = pad;
+            Ns *= R;
         }
+        p.m_n4 = sk_magic(n / 4); p.m_per = sk_magic(n / 2 + 1); p.m_nchk = sk_magic(nchk);
         const int ibs = 32 + (is_double ? 2 : 4);
         img = std::max(img, (n / 16) * ibs / 2);
         p.img = (img + 3) / 2 * 2;
-        p.twmode = ((size_t)n * esz <= 16 * 1024) ? 0 : 1;
-        p.twr_lds = (real && p.twmode == 0) ? 1 : 0;
+        // small n: every twiddle straight from the table (the reference's 140 dB single-tone test leaves no
+        // room for recomputed powers there); otherwise one table read per butterfly + <= 4-deep products
+        p.twmode = n < 512 ? 0 : ((size_t)n * esz <= 32 * 1024 ? 2 : 1);
+        p.twr_lds = (real && p.twmode != 1) ? 1 : 0;
         size_t tot = is_double ? stock_lds<double>(p).total : stock_lds<float>(p).total;
-        if (tot > lds_max && p.twmode == 0) {
+        if (tot > lds_max && p.twmode != 1) {
             p.twmode = 1; p.twr_lds = 0;
             tot = is_double ? stock_lds<double>(p).total : stock_lds<float>(p).total;
         }
         if (tot > lds_max) return false;
     }
-    *threads_out = threads;
+    *threads_out = threads + 64 * P;
+    *wl_out = wl;
     return true;
 }
 
