@@ -46,14 +46,17 @@ struct StockStage {
     int wblk;                // LDS destination: result d at (j div Ns) wblk + (j mod Ns) + d Ns
     int twstep;              // W_{Ns R}^(q jm) = W_n^(q jm twstep)
     unsigned m_nb, m_Ns;     // magic multipliers: x div d = umulhi(x, m) for x < 65536
+    int tw_off;              // twmode 2: this stage's Ns base twiddles W_{Ns R}^jm start here in the compact table
 };
 
 struct StockPlan {
     int n, ns;       // complex points per transform, stages
     int G;           // transforms per workgroup pass
     int img;         // complex points per image slot (largest padded image)
-    int twmode;      // 0: every twiddle from the padded W_n^j table in LDS; 2: base twiddle from that table,
-                     // powers recomputed (<= 4 products deep); 1: base twiddle from the global table, powers recomputed
+    int twmode;      // 0: every twiddle from the padded W_n^j table in LDS; 2: base twiddle W_{Ns R}^jm from the compact
+                     // per-stage table in LDS (ctab entries: sum of Ns over the stages), powers recomputed (<= 4
+                     // products deep); 1: base twiddle from the global W_n^j table, powers recomputed
+    int ctab;        // entries of the compact table
     int twr_lds;     // W_N^k table of the real pair pass in LDS
     int C, P;        // compute threads, producer wavefronts (blockDim = C + 64 P)
     unsigned m_n4, m_per, m_nchk;  // magic multipliers for n/4, n/2 + 1, 16-byte chunks per vector
@@ -65,7 +68,8 @@ template <typename T> __host__ __device__ inline StockLds<T> stock_lds(const Sto
     StockLds<T> l;
     size_t o = 0;
     l.buf = o; o += (size_t)2 * p.G * p.img * sizeof(cx<T>);
-    l.tab = o; if (p.twmode != 1) o += ((size_t)p.n + (p.n >> 5) + 1) * sizeof(cx<T>);
+    l.tab = o; if (p.twmode == 0) o += ((size_t)p.n + (p.n >> 5) + 1) * sizeof(cx<T>);
+    if (p.twmode == 2) o += (size_t)(p.ctab + 1) * sizeof(cx<T>);
     l.twr = o; if (p.twr_lds) o += ((size_t)p.n / 2 + 1) * sizeof(cx<T>);
     l.next = o; o += 16;
     l.total = o;
@@ -93,7 +97,7 @@ template <typename T> struct SkArgs {
     cx<T>* lds;                  // start of dynamic LDS
     int src_off, dst_off, tab_off;   // source image, destination image, W_n^j table (complex points)
     cx<T>* gdst;                 // vector 0 of the group (stride n)
-    const cx<T>* twg;            // global W_n^j table (twmode 1)
+    const cx<T>* twg;            // global W_n^j table (twmode 1; in twmode 2 the kernel is handed the compact table)
 };
 
 __device__ __forceinline__ int tpad(int i) { return i + (i >> 5); }
@@ -141,7 +145,7 @@ __device__ __forceinline__ void sk_stage(const StockStage& st, const SkArgs<T>& 
                 CX p[R < 4 ? 4 : R];
                 // (the empty asm keeps the two loads in separate blocks: merged into one load through a selected
                 // pointer they become FLAT instructions)
-                if (a.twmode == 2) p[1] = a.lds[a.tab_off + tpad(k)];
+                if (a.twmode == 2) p[1] = a.lds[a.tab_off + st.tw_off + jm];
                 else { p[1] = a.twg[k]; asm volatile(""); }
                 p[2] = cmul(p[1], p[1]);
                 if constexpr (R > 3) p[3] = cmul(p[2], p[1]);
@@ -374,6 +378,51 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
     }
 }
 
+// Work distribution.  ctr == nullptr: static, group = blockIdx + it * gridDim.  Otherwise CHUNKS of K consecutive
+// groups are pulled in order from the counter by one owner thread, one chunk ahead, through a ring of three LDS
+// slots (published at the top of the iteration at whose end it is consumed).  K keeps the atomic rate down: all
+// workgroups hit ONE address, which serves ~80 M atomics/s - with one 19 KiB group per atomic the n = 2400 kernel
+// ran at 0.37 of the roofline, statically scheduled at 0.64.
+struct SkSched {
+    unsigned gcur, gnx, sub, rslot, wslot, pend, K;
+    bool dyn;
+    unsigned* ctr;
+    unsigned* s_next;
+    __device__ __forceinline__ void grab(bool owner) {   // before the first barrier
+        if (dyn && owner) {
+            s_next[0] = atomicAdd(&ctr[0], 1u);
+            s_next[1] = atomicAdd(&ctr[0], 1u);
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+    }
+    __device__ __forceinline__ void start() {            // after it
+        if (!dyn) { gcur = blockIdx.x; gnx = gcur + gridDim.x; sub = 0; rslot = wslot = 0; return; }
+        gcur = K * s_next[0];
+        if (K > 1) { gnx = gcur + 1; sub = 1; rslot = 1; }
+        else { gnx = s_next[1]; sub = 0; rslot = 2; }
+        wslot = 2;
+    }
+    __device__ __forceinline__ void top(bool owner) {    // top of an iteration
+        if (dyn && sub + 1 >= K) {
+            if (owner) { s_next[wslot] = pend; pend = atomicAdd(&ctr[0], 1u); }
+            wslot = wslot == 2 ? 0 : wslot + 1;
+        }
+    }
+    __device__ __forceinline__ void advance() {          // after the iteration's closing barrier
+        gcur = gnx;
+        if (!dyn) gnx += gridDim.x;
+        else if (sub + 1 < K) { ++gnx; ++sub; }
+        else { gnx = K * s_next[rslot]; rslot = rslot == 2 ? 0 : rslot + 1; sub = 0; }
+    }
+    __device__ __forceinline__ void finish(bool owner) {
+        if (dyn && owner) {
+            __threadfence();
+            unsigned d = atomicAdd(&ctr[1], 1u);
+            if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+        }
+    }
+};
+
 // linear 16-byte chunk c of a group -> chunk offset inside the images (natural image, or internal-layout block image)
 template <typename T> __device__ __forceinline__ int sk_chunk_off(int g, int cc, int img16, bool in_int) {
     constexpr int CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = SkIbs<T>::v / CH;
@@ -385,9 +434,9 @@ template <typename T> __device__ __forceinline__ int sk_chunk_off(int g, int cc,
 // Workgroup-phase kernel: C compute threads share every stage of the G vectors of a group; P producer wavefronts
 // hold the next group in registers across the iteration's barriers.
 template <typename T>
-__global__ void __launch_bounds__(1024)
-fft_stock_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, const cx<T>* __restrict__ twg,
-                 const cx<T>* __restrict__ twrg, unsigned* ctr) {
+__device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, const StockPlan& p, int flags,
+                                           const cx<T>* __restrict__ twg, const cx<T>* __restrict__ twrg, unsigned* ctr,
+                                           unsigned kchunk) {
     typedef cx<T> CX;
     typedef vec4<float> chunk16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -402,33 +451,30 @@ fft_stock_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, cons
     c.twr_lds = p.twr_lds && c.real;
     unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + L.next);
     const int n = p.n, G = p.G, ns = p.ns, C = p.C;
-    const int tid = threadIdx.x;
-    if (p.twmode != 1)
-        for (int i = tid; i < n; i += blockDim.x) lds[c.tab_off + tpad(i)] = twg[i];
+    const int tid = threadIdx.x, nthreads = p.C + 64 * p.P;
+    if (p.twmode == 0)
+        for (int i = tid; i < n; i += nthreads) lds[c.tab_off + tpad(i)] = twg[i];
+    if (p.twmode == 2)
+        for (int i = tid; i < p.ctab; i += nthreads) lds[c.tab_off + i] = twg[i];
     if (c.twr_lds)
-        for (int i = tid; i <= n / 2; i += blockDim.x) lds[c.twr_off + i] = twrg[i];
+        for (int i = tid; i <= n / 2; i += nthreads) lds[c.twr_off + i] = twrg[i];
     const int nchk = (int)((size_t)n * sizeof(CX) / 16);
     const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);
     // LDS-writing compute phases per iteration (each followed by one barrier); + the closing barrier
     const int last_lds = (c.real && !c.bwd) || c.out_int;
     const int Fc = ((c.real && c.bwd) ? 1 : 0) + (ns - 1) + (last_lds ? 1 : 0) + ((c.real && !c.bwd && c.out_int) ? 1 : 0);
 
-    const bool dyn = ctr != nullptr;
-    unsigned pend = 0;
-    if (dyn && tid == C) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        s_next[1] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
+    SkSched sch;
+    sch.dyn = ctr != nullptr; sch.ctr = ctr; sch.s_next = s_next; sch.K = kchunk; sch.pend = 0;
+    sch.grab(tid == C);
     __syncthreads();
-    unsigned gcur = dyn ? s_next[0] : blockIdx.x;
-    unsigned gnx = dyn ? s_next[1] : blockIdx.x + gridDim.x;
+    sch.start();
     __syncthreads();
     int w = 0;  // image the next LDS-writing phase writes; the phase after it reads image w ^ 1 (ping-pong)
 
     if (tid >= C) {
         // ======================================================================= producer wavefronts
-        const int pl = tid - C, PT = blockDim.x - C;
+        const int pl = tid - C, PT = 64 * p.P;
         const chunk16* s16 = reinterpret_cast<const chunk16*>(in);
         chunk16 raw[SK_NCHP];
         // unconditional loads (a predicated load costs a branch and pins its address): chunks beyond the
@@ -456,29 +502,21 @@ fft_stock_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, cons
                 }
             }
         };
-        issue(gcur);
+        issue(sch.gcur);
         deposit(w * c.bufsz);
         w ^= 1;
         __syncthreads();
-        for (unsigned it = 0; (size_t)gcur * G < batch; ++it) {
-            issue(gnx);
-            if (dyn && tid == C) {
-                s_next[it & 1] = pend;
-                pend = atomicAdd(&ctr[0], 1u);
-            }
+        while ((size_t)sch.gcur * G < batch) {
+            issue(sch.gnx);
+            sch.top(tid == C);
             for (int b = 0; b < Fc; ++b) __syncthreads();
             w ^= (Fc & 1);
             deposit(w * c.bufsz);
             w ^= 1;
             __syncthreads();
-            gcur = gnx;
-            gnx = dyn ? s_next[it & 1] : gnx + gridDim.x;
+            sch.advance();
         }
-        if (dyn && tid == C) {
-            __threadfence();
-            unsigned d = atomicAdd(&ctr[1], 1u);
-            if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
-        }
+        sch.finish(tid == C);
         return;
     }
 
@@ -486,16 +524,16 @@ fft_stock_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, cons
     const StockStage st0 = p.st[0], st1 = p.st[1], st2 = p.st[2], st3 = p.st[3];
     w ^= 1;
     __syncthreads();  // first deposit
-    for (unsigned it = 0; (size_t)gcur * G < batch; ++it) {
-        const size_t t0 = (size_t)gcur * G;
+    while ((size_t)sch.gcur * G < batch) {
+        const size_t t0 = (size_t)sch.gcur * G;
+        sch.top(false);
         const int g_here = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);
         CX* gout = reinterpret_cast<CX*>(out) + t0 * n;
         sk_iteration<T, false>(p, st0, st1, st2, st3, c, tid, C, 0, g_here, G, gout, w);
         // ---- closing barrier: the producers have deposited the next group into image w
         w ^= 1;
         __syncthreads();
-        gcur = gnx;
-        gnx = dyn ? s_next[it & 1] : gnx + gridDim.x;
+        sch.advance();
     }
 }
 
@@ -507,7 +545,8 @@ constexpr int SK_NCHW = 8;
 constexpr int SK_WL_WAVES = 4;  // wavefronts per workgroup of the wave-local kernel
 template <typename T>
 __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, const StockPlan& p, int flags,
-                                           const cx<T>* __restrict__ twg, const cx<T>* __restrict__ twrg, unsigned* ctr) {
+                                           const cx<T>* __restrict__ twg, const cx<T>* __restrict__ twrg, unsigned* ctr,
+                                           unsigned kchunk) {
     typedef cx<T> CX;
     typedef vec4<float> chunk16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -524,24 +563,21 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
     const int n = p.n, G = p.G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Gw = G / SK_WL_WAVES, slot0 = wave * Gw;
-    if (p.twmode != 1)
+    if (p.twmode == 0)
         for (int i = tid; i < n; i += 64 * SK_WL_WAVES) lds[c.tab_off + tpad(i)] = twg[i];
+    if (p.twmode == 2)
+        for (int i = tid; i < p.ctab; i += 64 * SK_WL_WAVES) lds[c.tab_off + i] = twg[i];
     if (c.twr_lds)
         for (int i = tid; i <= n / 2; i += 64 * SK_WL_WAVES) lds[c.twr_off + i] = twrg[i];
     const int nchk = (int)((size_t)n * sizeof(CX) / 16);
     const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);
     const StockStage st0 = p.st[0], st1 = p.st[1], st2 = p.st[2], st3 = p.st[3];
 
-    const bool dyn = ctr != nullptr;
-    unsigned pend = 0;
-    if (dyn && tid == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        s_next[1] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
+    SkSched sch;
+    sch.dyn = ctr != nullptr; sch.ctr = ctr; sch.s_next = s_next; sch.K = kchunk; sch.pend = 0;
+    sch.grab(tid == 0);
     __syncthreads();
-    unsigned gcur = dyn ? s_next[0] : blockIdx.x;
-    unsigned gnx = dyn ? s_next[1] : blockIdx.x + gridDim.x;
+    sch.start();
     __syncthreads();
 
     const chunk16* s16 = reinterpret_cast<const chunk16*>(in);
@@ -574,38 +610,37 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
         }
     };
     int w = 0;
-    issue(gcur);
+    issue(sch.gcur);
     deposit(w * c.bufsz);
     w ^= 1;
     sk_sync<true>();
-    for (unsigned it = 0; (size_t)gcur * G < batch; ++it) {
-        if (dyn && tid == 0) {
-            s_next[it & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
-        }
-        issue(gnx);
-        const int cnt = mine(gcur);
-        CX* gout = reinterpret_cast<CX*>(out) + (size_t)gcur * G * n;
+    while ((size_t)sch.gcur * G < batch) {
+        sch.top(tid == 0);
+        issue(sch.gnx);
+        const int cnt = mine(sch.gcur);
+        CX* gout = reinterpret_cast<CX*>(out) + (size_t)sch.gcur * G * n;
         sk_iteration<T, true>(p, st0, st1, st2, st3, c, lane, 64, slot0, cnt, Gw, gout, w);
         sk_sync<true>();          // the last phase's LDS reads are done before ...
         deposit(w * c.bufsz);     // ... the next group lands in the free image
         w ^= 1;
         __syncthreads();          // (also orders the deposit against the next iteration's reads)
-        gcur = gnx;
-        gnx = dyn ? s_next[it & 1] : gnx + gridDim.x;
+        sch.advance();
     }
-    if (dyn && tid == 0) {
-        __threadfence();
-        unsigned d = atomicAdd(&ctr[1], 1u);
-        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
-    }
+    sch.finish(tid == 0);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024)
+fft_stock_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, const cx<T>* __restrict__ twg,
+                 const cx<T>* __restrict__ twrg, unsigned* ctr, unsigned kchunk) {
+    sk_wg_body<T>(in, out, batch, p, flags, twg, twrg, ctr, kchunk);
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256)
 fft_stock_wl_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, const cx<T>* __restrict__ twg,
-                    const cx<T>* __restrict__ twrg, unsigned* ctr) {
-    sk_wl_body<T>(in, out, batch, p, flags, twg, twrg, ctr);
+                    const cx<T>* __restrict__ twrg, unsigned* ctr, unsigned kchunk) {
+    sk_wl_body<T>(in, out, batch, p, flags, twg, twrg, ctr, kchunk);
 }
 
 // The same body with the plan and the flags as compile-time constants (stock_plans_gen.h, written by
@@ -616,9 +651,17 @@ fft_stock_wl_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, c
 template <typename T, class PT, int FLAGS>
 __global__ void __launch_bounds__(256)
 fft_stock_wl_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
-                       const cx<T>* __restrict__ twrg, unsigned* ctr) {
+                       const cx<T>* __restrict__ twrg, unsigned* ctr, unsigned kchunk) {
     constexpr StockPlan p = PT::value;
-    sk_wl_body<T>(in, out, batch, p, FLAGS, twg, twrg, ctr);
+    sk_wl_body<T>(in, out, batch, p, FLAGS, twg, twrg, ctr, kchunk);
+}
+
+template <typename T, class PT, int FLAGS>
+__global__ void __launch_bounds__(PT::value.C + 64 * PT::value.P)
+fft_stock_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
+                    const cx<T>* __restrict__ twrg, unsigned* ctr, unsigned kchunk) {
+    constexpr StockPlan p = PT::value;
+    sk_wg_body<T>(in, out, batch, p, FLAGS, twg, twrg, ctr, kchunk);
 }
 
 }  // namespace pf

@@ -124,6 +124,7 @@ struct Setup {
     bool dev_ready = false;
     void* d_tw = nullptr;   // W_n^j, j < n
     void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
+    void* d_twc[2] = {nullptr, nullptr};  // compact per-stage base twiddles of the Stockham plans (forward / backward order)
     unsigned* d_ctr = nullptr;             // ring of {next, done} work counters for the dynamic kernels
     std::atomic<unsigned> ctr_slot{0};
     // sizes beyond LDS (K_BIG): n = bigN[0] x bigN[1], one strided plan + twiddle table per factor
@@ -218,6 +219,7 @@ static void destroy_setup(Setup* s) {
     if (s->dev_ready) {
         if (s->d_tw) (void)hipFree(s->d_tw);
         if (s->d_twr) (void)hipFree(s->d_twr);
+        for (void* q : s->d_twc) if (q) (void)hipFree(q);
         if (s->d_ctr) (void)hipFree(s->d_ctr);
     }
     for (void* p : s->d_bigtw) if (p) (void)hipFree(p);
@@ -266,6 +268,20 @@ static int ensure_device(Setup* s) {
         }
         PF_CHECK(hipMalloc(&s->d_twr, sizeof(cx<T>) * m));
         PF_CHECK(hipMemcpy(s->d_twr, twr.data(), sizeof(cx<T>) * m, hipMemcpyHostToDevice));
+    }
+    for (int d = 0; d < 2; ++d) {
+        const StockPlan* sp = (s->sk_ok && s->sk[d].twmode == 2) ? &s->sk[d] : (s->skw_ok && s->skw[d].twmode == 2) ? &s->skw[d] : nullptr;
+        if (!sp) continue;
+        std::vector<cx<T>> tc(sp->ctab + 1);
+        for (int st = 1; st < sp->ns; ++st) {
+            const StockStage& g = sp->st[st];
+            for (int jm = 0; jm < g.Ns; ++jm) {   // W_{Ns R}^jm
+                long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)jm / (long double)(g.Ns * g.R);
+                tc[g.tw_off + jm].x = (T)cosl(a); tc[g.tw_off + jm].y = (T)sinl(a);
+            }
+        }
+        PF_CHECK(hipMalloc(&s->d_twc[d], sizeof(cx<T>) * tc.size()));
+        PF_CHECK(hipMemcpy(s->d_twc[d], tc.data(), sizeof(cx<T>) * tc.size(), hipMemcpyHostToDevice));
     }
     {
         // Each launch of a dynamic kernel takes its own {next, done} counter pair from this ring; the
@@ -438,25 +454,40 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
     const StockPlan& sp = wl ? s->skw[bwd ? 1 : 0] : s->sk[bwd ? 1 : 0];
     const int threads = wl ? s->skw_threads : s->sk_threads;
     const size_t lds = stock_lds<T>(sp).total;
+    const cx<T>* twp = (const cx<T>*)(sp.twmode == 2 ? s->d_twc[bwd ? 1 : 0] : s->d_tw);
     const int flags = ((bwd && !ordered) ? 1 : 0) | ((!bwd && !ordered) ? 2 : 0) | (bwd ? 4 : 0) |
                       (s->transform == PFFFT_REAL ? 8 : 0);
     const size_t groups = (batch + sp.G - 1) / sp.G;
-    const bool want_dyn = (size_t)sp.G * sp.n * sizeof(cx<T>) >= 16 * 1024 && g_variant != 41;
+    // Static assignment by default: unlike the register-tiled kernels (0.64 -> 0.83 with in-order pulling) these
+    // kernels sit at ~0.6 of the roofline on latency / issue, not on the HBM access order, and the hand-over of
+    // the next chunk costs more than the ordering buys (measured: 0.63 static vs 0.54 chunked-dynamic on N = 96..800,
+    // 0.64 vs 0.56 on N = 2400, 0.68 vs 0.59 on N = 4000).  Variant 42 = chunked in-order pulling (A/B).
+    const bool want_dyn = g_variant == 42;
+    // groups are pulled from the counter in chunks of K (>= 64 KiB per atomic: all workgroups hit one address),
+    // but never so large that a workgroup sees fewer than ~8 chunks
+    const size_t gbytes = (size_t)sp.G * sp.n * sizeof(cx<T>);
+    auto chunk_for = [&](size_t grid) -> unsigned {
+        size_t k = (65536 + gbytes - 1) / gbytes, cap = groups / (8 * grid);
+        if (k > cap) k = cap;
+        return (unsigned)(k < 1 ? 1 : (k > 64 ? 64 : k));
+    };
     // the same kernel body instantiated on this very plan as a compile-time constant, when there is one
     // (stock_plans_gen.h; variant 53 = always the run-time plan, A/B)
-    if constexpr (sizeof(T) == 4) {
-        StockCtFn cf = (wl && g_variant != 53) ? stock_ct_lookup_f32(sp, flags) : nullptr;
+    {
+        auto cf = g_variant != 53 ? stock_ct_lookup(sp, flags, wl, (const T*)nullptr) : nullptr;
         if (cf) {
             int rc = allow_big_lds(cf, lds);
             if (rc) return rc;
             int per_cu = 0;
             PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(cf), threads, lds));
             if (per_cu < 1) per_cu = 1;
+            if (g_variant > 10 && g_variant < 20 && per_cu > g_variant - 10) per_cu = g_variant - 10;  // A/B: cap WGs per CU
+            if (g_variant > 20 && g_variant < 30) per_cu = g_variant - 20;                             // A/B: force WGs per CU
             size_t grid = (size_t)num_cus() * per_cu;
             if (grid > groups) grid = groups;
             unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
-            hipLaunchKernelGGL(cf, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch,
-                               (const cx<float>*)s->d_tw, (const cx<float>*)s->d_twr, ctr);
+            hipLaunchKernelGGL(cf, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch, twp,
+                               (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
             PF_CHECK(hipGetLastError());
             return 0;
         }
@@ -471,8 +502,8 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
     unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch, sp, flags,
-                       (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch, sp, flags, twp,
+                       (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
     PF_CHECK(hipGetLastError());
     return 0;
 }

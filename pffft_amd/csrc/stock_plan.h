@@ -126,7 +126,9 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
     if (best.size() < 2 || best.size() > SK_MAX_STAGES) return false;
     const int nchk = n * esz / 16;
     // small n: wave-local kernel, 4 wavefronts per workgroup, each owning Gw vectors (<= 4 KiB, or one vector)
-    const bool wl = allow_wl && (size_t)n * esz <= 64 * SK_NCHW * 16;
+    // (beyond 4 KiB per vector a wavefront would own a single vector: measured 0.40-0.49 of the roofline for
+    // n = 640..800 float against 0.62-0.66 below, and the workgroup kernel reaches 0.66 on the same bytes)
+    const bool wl = allow_wl && (size_t)n * esz <= 4096;
     int G, P = 0, threads;
     if (wl) {
         const int Gw = std::max(1, 4096 / (n * esz));
@@ -137,16 +139,22 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         G = std::max(1, target / n);
         // producer wavefronts: SK_NCHP 16-byte chunks per lane hold one group of G vectors
         P = (G * nchk + 64 * SK_NCHP - 1) / (64 * SK_NCHP);
-        threads = (int)(((size_t)G * n / 8 + 63) / 64 * 64);
-        threads = std::min(1024 - 64 * P, std::max(128, threads));
-        if (threads < 64) return false;
+        // one butterfly per thread in the stage with the most butterflies (two rounds when that exceeds the workgroup)
+        int maxb = 0;
+        for (int r : best) maxb = std::max(maxb, G * (n / r));
+        const int cap = 1024 - 64 * P;
+        if (cap < 64) return false;
+        int rounds = 1;
+        while ((maxb + rounds - 1) / rounds > cap) ++rounds;
+        threads = std::max(128, ((maxb + rounds - 1) / rounds + 63) / 64 * 64);
+        threads = std::min(threads, cap / 64 * 64);
     }
     for (int dir = 0; dir < 2; ++dir) {
         StockPlan& p = out[dir];
         memset(&p, 0, sizeof p);
         const std::vector<int> r = sk_order(best, dir == 1);
         p.n = n; p.ns = (int)r.size(); p.G = G; p.C = threads; p.P = P;
-        int Ns = 1, img = n, prevpad = 0;
+        int Ns = 1, img = n, prevpad = 0, ctab = 0;
         for (int s = 0; s < p.ns; ++s) {
             StockStage& st = p.st[s];
             const int R = r[s], nb = n / R;
@@ -161,16 +169,20 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
             st.wblk = Ns * R + pad;
             st.twstep = n / (Ns * R);
             st.m_nb = sk_magic(nb); st.m_Ns = sk_magic(Ns);
+            st.tw_off = ctab; if (s) ctab += Ns;
             prevpad = pad;
             Ns *= R;
         }
+        p.ctab = ctab;
         p.m_n4 = sk_magic(n / 4); p.m_per = sk_magic(n / 2 + 1); p.m_nchk = sk_magic(nchk);
         const int ibs = 32 + (is_double ? 2 : 4);
         img = std::max(img, (n / 16) * ibs / 2);
         p.img = (img + 3) / 2 * 2;
         // small n: every twiddle straight from the table (the reference's 140 dB single-tone test leaves no
         // room for recomputed powers there); otherwise one table read per butterfly + <= 4-deep products
-        p.twmode = n < 512 ? 0 : ((size_t)n * esz <= 32 * 1024 ? 2 : 1);
+        // (mode 1 - base twiddles from the global table - is kept for A/B only: the L2 latency per stage cost
+        //  n = 4000 float 0.60 -> 0.50 although it doubled the resident workgroups)
+        p.twmode = n < 512 ? 0 : 2;
         p.twr_lds = (real && p.twmode != 1) ? 1 : 0;
         size_t tot = is_double ? stock_lds<double>(p).total : stock_lds<float>(p).total;
         if (tot > lds_max && p.twmode != 1) {

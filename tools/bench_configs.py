@@ -22,7 +22,7 @@ def run(N, tr, dtype, batch, label, ordered=False, direction=pa.FORWARD, inplace
     print(f"{label:46s} [{pa.kernel_name(s):10s}] {t*1e3:9.3f} ms {byts/t/1e9:8.1f} GB/s {batch/t/1e6:9.3f} M/s  frac={byts/t/8e12:.3f}")
     del x, y; torch.cuda.empty_cache(); s.close()
 
-which = sys.argv[1:] or ["configs", "sweep"]
+which = (sys.argv[1:] or ["configs", "sweep"]) if __name__ == "__main__" else []
 if "configs" in which:
     run(1024, pa.COMPLEX, np.float32, 1 << 20, "C2 N=1024 cplx f32 fwd unordered")
     run(1024, pa.COMPLEX, np.float32, 1 << 20, "C2 N=1024 cplx f32 inv unordered", direction=pa.BACKWARD)
