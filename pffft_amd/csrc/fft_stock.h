@@ -57,15 +57,16 @@ struct StockPlan {
                      // per-stage table in LDS (ctab entries: sum of Ns over the stages), powers recomputed (<= 4
                      // products deep); 1: base twiddle from the global W_n^j table, powers recomputed
     int ctab;        // entries of the compact table
+    int ibs;         // scalars per padded 32-scalar block of the internal-layout image (36 float / 34 double; 32 when LDS is tight)
     int twr_lds;     // W_N^k table of the real pair pass in LDS
     int C, P;        // compute threads, producer wavefronts (blockDim = C + 64 P)
     unsigned m_n4, m_per, m_nchk;  // magic multipliers for n/4, n/2 + 1, 16-byte chunks per vector
     StockStage st[SK_MAX_STAGES];
 };
 
-template <typename T> struct StockLds { size_t buf, tab, twr, next, total; };
-template <typename T> __host__ __device__ inline StockLds<T> stock_lds(const StockPlan& p) {
-    StockLds<T> l;
+template <typename T> struct StockLds { size_t buf = 0, tab = 0, twr = 0, next = 0, total = 0; };
+template <typename T> __host__ __device__ constexpr StockLds<T> stock_lds(const StockPlan& p) {
+    StockLds<T> l{};
     size_t o = 0;
     l.buf = o; o += (size_t)2 * p.G * p.img * sizeof(cx<T>);
     l.tab = o; if (p.twmode == 0) o += ((size_t)p.n + (p.n >> 5) + 1) * sizeof(cx<T>);
@@ -90,7 +91,7 @@ template <typename T> struct SkArgs {
                                  // gives compile-time trip counts)
     unsigned m_n4;
     int img;                     // slot stride of the LDS images (complex points)
-    int twmode;
+    int twmode, ibs;
     bool cj_in, cj_out;          // conjugate on the way in (first stage) / out (HBM store): backward transform
     // LDS is addressed as (one base pointer) + integer offsets: a pointer selected between the two images or
     // between an LDS and a global table becomes a generic pointer and every access a FLAT instruction
@@ -105,7 +106,7 @@ __device__ __forceinline__ int tpad(int i) { return i + (i >> 5); }
 template <typename T, int R, int SRC, int DST>
 __device__ __forceinline__ void sk_stage(const StockStage& st, const SkArgs<T>& a) {
     typedef cx<T> CX;
-    constexpr int IBS = SkIbs<T>::v;
+    const int IBS = a.ibs;
     const int n4 = a.n >> 2;
 #pragma unroll
     for (int i0 = 0; i0 < a.maxtotal; i0 += a.nthr) {
@@ -215,10 +216,10 @@ __device__ __forceinline__ void sk_run(const StockStage& st, const SkArgs<T>& a)
 
 // scalar index (real part; imaginary part + 4) of half-complex bin k of a REAL transform inside the
 // internal-layout image: odd quarters run backwards (bin_of, fft_generic.h)
-template <typename T> __device__ __forceinline__ int sk_iposr(int k, int n4, unsigned m_n4) {
+template <typename T> __device__ __forceinline__ int sk_iposr(int k, int n4, unsigned m_n4, int ibs) {
     const int qq = udiv(k, m_n4), r = k - qq * n4;
     const int tt = (qq & 1) ? (r ? n4 - r : 0) : r;
-    return SkIbs<T>::v * (tt >> 2) + 8 * qq + (tt & 3);
+    return ibs * (tt >> 2) + 8 * qq + (tt & 3);
 }
 
 // One pass of the compute side over `cnt` vectors (image slots slot0 .. slot0 + cnt - 1) whose input sits in
@@ -245,7 +246,8 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
                                              int wtid, int wn, int slot0, int cnt, int maxcnt, cx<T>* gout, int& w) {
     typedef cx<T> CX;
     typedef vec4<float> chunk16;
-    constexpr int IBS = SkIbs<T>::v, CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = IBS / CH;
+    constexpr int CH = 16 / (int)sizeof(T), CPB = 32 / CH;
+    const int BCH = p.ibs / CH;
     CX* const lds = c.lds;
     const int n = p.n, ns = p.ns, bufsz = c.bufsz;
     const int n4 = n >> 2, half = n >> 1, per = half + 1;
@@ -265,10 +267,10 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
             CX A, Bn;
             if (in_int) {
                 const T* ps = reinterpret_cast<const T*>(lds + (w ^ 1) * bufsz + g * p.img);
-                const int ia = sk_iposr<T>(k, n4, p.m_n4);
+                const int ia = sk_iposr<T>(k, n4, p.m_n4, p.ibs);
                 A = mk<T>(ps[ia], ps[ia + 4]);
                 if (k != 0 && k != half) {
-                    const int ib = sk_iposr<T>(n - k, n4, p.m_n4);
+                    const int ib = sk_iposr<T>(n - k, n4, p.m_n4, p.ibs);
                     Bn = mk<T>(ps[ib], ps[ib + 4]);
                 } else Bn = A;
             } else {
@@ -298,7 +300,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
     // ---- stages (unrolled over the at most SK_MAX_STAGES stage structs held in SGPRs)
     {
         SkArgs<T> a;
-        a.tid = wtid; a.nthr = wn; a.slot0 = slot0; a.n = n; a.m_n4 = p.m_n4; a.img = p.img; a.twmode = p.twmode;
+        a.tid = wtid; a.nthr = wn; a.slot0 = slot0; a.n = n; a.m_n4 = p.m_n4; a.img = p.img; a.twmode = p.twmode; a.ibs = p.ibs;
         a.lds = lds; a.tab_off = c.tab_off; a.gdst = gout; a.twg = c.twg;
         a.cj_out = bwd;
 #pragma unroll
@@ -350,10 +352,10 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
             }
             if (out_int) {
                 T* pd = reinterpret_cast<T*>(lds + w * bufsz + g * p.img);
-                const int ia = sk_iposr<T>(k, n4, p.m_n4);
+                const int ia = sk_iposr<T>(k, n4, p.m_n4, p.ibs);
                 pd[ia] = Xa.x; pd[ia + 4] = Xa.y;
                 if (k != 0 && k != half) {
-                    const int ib = sk_iposr<T>(n - k, n4, p.m_n4);
+                    const int ib = sk_iposr<T>(n - k, n4, p.m_n4, p.ibs);
                     pd[ib] = Xb.x; pd[ib + 4] = Xb.y;
                 }
             } else {
@@ -424,8 +426,9 @@ struct SkSched {
 };
 
 // linear 16-byte chunk c of a group -> chunk offset inside the images (natural image, or internal-layout block image)
-template <typename T> __device__ __forceinline__ int sk_chunk_off(int g, int cc, int img16, bool in_int) {
-    constexpr int CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = SkIbs<T>::v / CH;
+template <typename T> __device__ __forceinline__ int sk_chunk_off(int g, int cc, int img16, bool in_int, int ibs) {
+    constexpr int CH = 16 / (int)sizeof(T), CPB = 32 / CH;
+    const int BCH = ibs / CH;
     return g * img16 + (in_int ? (cc / CPB) * BCH + (cc % CPB) : cc);
 }
 
@@ -498,7 +501,7 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
                 const int cix = pl + PT * i;
                 if (cix < tot) {
                     const int g = udiv(cix, p.m_nchk), cc = cix - g * nchk;
-                    d16[sk_chunk_off<T>(g, cc, img16, c.in_int)] = raw[i];
+                    d16[sk_chunk_off<T>(g, cc, img16, c.in_int, p.ibs)] = raw[i];
                 }
             }
         };
@@ -605,7 +608,7 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
             const int cix = lane + 64 * i;
             if (cix < tot) {
                 const int gl = udiv(cix, p.m_nchk), cc = cix - gl * nchk;
-                d16[sk_chunk_off<T>(slot0 + gl, cc, img16, c.in_int)] = raw[i];
+                d16[sk_chunk_off<T>(slot0 + gl, cc, img16, c.in_int, p.ibs)] = raw[i];
             }
         }
     };
@@ -648,8 +651,20 @@ fft_stock_wl_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, c
 // left per butterfly is its loads, twiddle products, the DFT and its stores.  (The run-time plan costs ~100
 // VALU + ~60 SALU instructions per point and is issue-bound at 0.3 of the HBM roofline whatever the
 // organisation - workgroup phases, producer wavefronts or wave-local all measured 0.26-0.44.)
+// wavefronts per SIMD the register allocator should leave room for: what LDS lets a CU hold, capped at 5 (<= 96 VGPRs)
+// (a kernel that spills at that budget gets a lower cap in stock_wpe_gen.h, written by tools/tune_stock_wpe.py from
+// the compiler's resource remarks: squeezed into spilling, N = 640 fell from 0.60 to 0.55)
+template <class PT, int FLAGS> struct SkWpeCap { static constexpr int v = 5; };
+template <typename T> constexpr int sk_waves_per_simd(const StockPlan& p, int threads, int cap) {
+    const size_t lds = stock_lds<T>(p).total;
+    int wgs = (int)(160 * 1024 / lds);
+    wgs = wgs > 8 ? 8 : (wgs < 1 ? 1 : wgs);
+    const int wpe = wgs * (threads / 64) / 4;
+    return wpe > cap ? cap : (wpe < 1 ? 1 : wpe);
+}
+
 template <typename T, class PT, int FLAGS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, sk_waves_per_simd<T>(PT::value, 256, SkWpeCap<PT, FLAGS>::v))
 fft_stock_wl_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
                        const cx<T>* __restrict__ twrg, unsigned* ctr, unsigned kchunk) {
     constexpr StockPlan p = PT::value;
@@ -657,7 +672,7 @@ fft_stock_wl_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restric
 }
 
 template <typename T, class PT, int FLAGS>
-__global__ void __launch_bounds__(PT::value.C + 64 * PT::value.P)
+__global__ void __launch_bounds__(PT::value.C + 64 * PT::value.P, sk_waves_per_simd<T>(PT::value, PT::value.C + 64 * PT::value.P, SkWpeCap<PT, FLAGS>::v))
 fft_stock_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
                     const cx<T>* __restrict__ twrg, unsigned* ctr, unsigned kchunk) {
     constexpr StockPlan p = PT::value;

@@ -79,9 +79,10 @@ static std::vector<int> sk_order(std::vector<int> r, bool bwd) {
     return o;
 }
 
-static int sk_pick_pad(int n, int esz, int G, int threads, int Ns, int R, int Rnext) {
+static int sk_pick_pad(int n, int esz, int G, int threads, int Ns, int R, int Rnext, int maxextra) {
     const int blk = Ns * R, nb = n / R, nb2 = n / Rnext;
-    const int maxpad = std::min(31, std::max(1, blk / 8));
+    // maxextra: points the image may grow by (LDS budget of the two images)
+    const int maxpad = std::min(std::min(31, std::max(1, blk / 8)), maxextra / (n / blk));
     int best = 0;
     long long bestc = -1;
     for (int pad = 0; pad <= maxpad; ++pad) {
@@ -155,12 +156,15 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         const std::vector<int> r = sk_order(best, dir == 1);
         p.n = n; p.ns = (int)r.size(); p.G = G; p.C = threads; p.P = P;
         int Ns = 1, img = n, prevpad = 0, ctab = 0;
+        // what is left of LDS after two unpadded images (+ ~n/8 twiddles, the pair-pass table, slack), per image
+        const long long spare = (long long)lds_max - 2LL * G * n * esz - (long long)(n / 6 + (real ? n / 2 : 0) + 64) * esz;
+        const int maxextra = spare <= 0 ? 0 : (int)std::min<long long>(n / 4, spare / (2LL * G * esz));
         for (int s = 0; s < p.ns; ++s) {
             StockStage& st = p.st[s];
             const int R = r[s], nb = n / R;
             int pad = 0;
             if (s + 1 < p.ns) {
-                pad = wl ? sk_pick_pad(n, esz, G / 4, 64, Ns, R, r[s + 1]) : sk_pick_pad(n, esz, G, threads, Ns, R, r[s + 1]);
+                pad = wl ? sk_pick_pad(n, esz, G / 4, 64, Ns, R, r[s + 1], maxextra) : sk_pick_pad(n, esz, G, threads, Ns, R, r[s + 1], maxextra);
                 img = std::max(img, n + (n / (Ns * R)) * pad);
             }
             st.R = R; st.nb = nb; st.Ns = Ns;
@@ -175,7 +179,11 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         }
         p.ctab = ctab;
         p.m_n4 = sk_magic(n / 4); p.m_per = sk_magic(n / 2 + 1); p.m_nchk = sk_magic(nchk);
-        const int ibs = 32 + (is_double ? 2 : 4);
+        // internal-layout image: 32-scalar blocks padded to 36 (float) / 34 (double) scalars, unpadded if that
+        // alone would push the two images out of LDS
+        int ibs = 32 + (is_double ? 2 : 4);
+        if ((size_t)2 * G * ((n / 16) * ibs / 2 + 4) * esz + (size_t)(ctab + n / 2 + 64) * esz > lds_max) ibs = 32;
+        p.ibs = ibs;
         img = std::max(img, (n / 16) * ibs / 2);
         p.img = (img + 3) / 2 * 2;
         // small n: every twiddle straight from the table (the reference's 140 dB single-tone test leaves no
