@@ -331,3 +331,65 @@ def test_large_sizes_against_reference(ref, dt, tr, N):
     s.transform_batch(buf, buf, pa.FORWARD, True)      # in place
     assert relerr(buf.cpu().numpy(), rs.batch(x, 0, True)) <= tol
     s.close(); rs.close()
+
+
+# ------------------------------------------------------------------ mixed-radix Stockham kernels (non-power-of-two sizes)
+STOCK_C = [48, 96, 160, 240, 480, 640, 800, 960, 1200, 2400, 2592, 4000, 9216]
+STOCK_R = [96, 160, 480, 800, 1600, 2400, 4000, 9216, 12000]
+
+
+@pytest.mark.parametrize("variant", [0, 53, 52, 42])
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_stockham_paths_against_float64_dft(dt, variant):
+    """Every code path of fft_stock.h: compile-time plans (0), run-time plans (53), the workgroup kernel where the
+    wave-local one is the default (52), chunked in-order scheduling (42) - against numpy's float64 FFT, with batches
+    that need several passes per workgroup, a ragged tail, ordered == zreorder(unordered) bit-exactly, and the
+    round trip through both inverse layouts."""
+    dtype = _dt(dt)
+    tol = 2e-6 if dt == "f32" else 1e-12
+    rng = np.random.default_rng(77)
+    pa.set_variant(variant)
+    try:
+        for tr, sizes in ((1, STOCK_C), (0, STOCK_R)):
+            if variant != 0:
+                sizes = sizes[::3]
+            for N in sizes:
+                s = pa.Setup(N, tr, dtype)
+                if pa.kernel_name(s) != "stockham":   # (double: the two images of the largest sizes exceed LDS)
+                    s.close(); continue
+                batch = max(3, min(4099, (48 << 20) // (s.vec_scalars * np.dtype(dtype).itemsize)))
+                x = rng.uniform(-1, 1, (batch, s.vec_scalars)).astype(dtype)
+                xd = _dev(x)
+                fo = s.transform_batch(xd, None, pa.FORWARD, True)
+                g = fo.cpu().numpy().astype(np.float64)
+                if tr == 1:
+                    want = np.fft.fft(x[:, 0::2].astype(np.float64) + 1j * x[:, 1::2], axis=1)
+                else:
+                    full = np.fft.rfft(x.astype(np.float64), axis=1)
+                    want = full[:, :-1].copy(); want[:, 0] = full[:, 0].real + 1j * full[:, -1].real
+                err = np.abs((g[:, 0::2] + 1j * g[:, 1::2]) - want).max() / np.abs(want).max()
+                assert err <= tol, (dt, tr, N, variant, err)
+                fu = s.transform_batch(xd, None, pa.FORWARD, False)
+                assert torch.equal(s.zreorder_batch(fu, None, pa.FORWARD), fo), (dt, tr, N, variant)
+                for spec, ordered in ((fo, True), (fu, False)):
+                    back = s.transform_batch(spec, None, pa.BACKWARD, ordered).cpu().numpy().astype(np.float64) / N
+                    assert np.abs(back - x).max() <= 4 * tol, (dt, tr, N, variant, ordered)
+                s.close()
+    finally:
+        pa.set_variant(0)
+
+
+def test_stockham_matches_reference_inplace(ref):
+    """In place == out of place bit-exactly (benchmarks/bench_pffft.c:343-349) with prefetching producers running ahead."""
+    for N, tr in ((2400, 1), (480, 1), (9216, 0), (800, 0)):
+        s, rs = pa.Setup(N, tr, np.float32), ref.setup(N, tr, np.float32)
+        x = np.random.default_rng(N).uniform(-1, 1, (1500, s.vec_scalars)).astype(np.float32)
+        for d, o in ((pa.FORWARD, False), (pa.FORWARD, True), (pa.BACKWARD, True), (pa.BACKWARD, False)):
+            buf = _dev(x)
+            oop = s.transform_batch(buf, None, d, o)
+            s.transform_batch(buf, buf, d, o)
+            assert torch.equal(buf, oop), (N, tr, d, o)
+        want = rs.batch(x[:4], 0, False)
+        got = s.transform_batch(_dev(x[:4]), None, pa.FORWARD, False).cpu().numpy()
+        assert relerr(got, want) <= 1e-5
+        s.close(); rs.close()
