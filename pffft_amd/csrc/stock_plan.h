@@ -156,8 +156,12 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         const std::vector<int> r = sk_order(best, dir == 1);
         p.n = n; p.ns = (int)r.size(); p.G = G; p.C = threads; p.P = P;
         int Ns = 1, img = n, prevpad = 0, ctab = 0;
-        // what is left of LDS after two unpadded images (+ ~n/8 twiddles, the pair-pass table, slack), per image
-        const long long spare = (long long)lds_max - 2LL * G * n * esz - (long long)(n / 6 + (real ? n / 2 : 0) + 64) * esz;
+        // what is left of LDS after two unpadded images, ~n/6 twiddles and slack; the pair-pass table (real) stays
+        // in L2 when it would leave less than ~6 % for the paddings
+        const long long base = 2LL * G * n * esz + (long long)(n / 6 + 64) * esz;
+        const long long twr_bytes = real ? (long long)(n / 2 + 1) * esz : 0;
+        const bool want_twr = real && base + twr_bytes + (2LL * G * n * esz) / 16 <= (long long)lds_max;
+        const long long spare = (long long)lds_max - base - (want_twr ? twr_bytes : 0);
         const int maxextra = spare <= 0 ? 0 : (int)std::min<long long>(n / 4, spare / (2LL * G * esz));
         for (int s = 0; s < p.ns; ++s) {
             StockStage& st = p.st[s];
@@ -182,7 +186,7 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         // internal-layout image: 32-scalar blocks padded to 36 (float) / 34 (double) scalars, unpadded if that
         // alone would push the two images out of LDS
         int ibs = 32 + (is_double ? 2 : 4);
-        if ((size_t)2 * G * ((n / 16) * ibs / 2 + 4) * esz + (size_t)(ctab + n / 2 + 64) * esz > lds_max) ibs = 32;
+        if ((size_t)2 * G * ((n / 16) * ibs / 2 + 4) * esz + (size_t)(ctab + 64) * esz + (want_twr ? twr_bytes : 0) > lds_max) ibs = 32;
         p.ibs = ibs;
         img = std::max(img, (n / 16) * ibs / 2);
         p.img = (img + 3) / 2 * 2;
@@ -191,12 +195,11 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         // (mode 1 - base twiddles from the global table - is kept for A/B only: the L2 latency per stage cost
         //  n = 4000 float 0.60 -> 0.50 although it doubled the resident workgroups)
         p.twmode = n < 512 ? 0 : 2;
-        p.twr_lds = (real && p.twmode != 1) ? 1 : 0;
-        size_t tot = is_double ? stock_lds<double>(p).total : stock_lds<float>(p).total;
-        if (tot > lds_max && p.twmode != 1) {
-            p.twmode = 1; p.twr_lds = 0;
-            tot = is_double ? stock_lds<double>(p).total : stock_lds<float>(p).total;
-        }
+        p.twr_lds = (want_twr && p.twmode != 1) ? 1 : 0;
+        auto total = [&]() { return is_double ? stock_lds<double>(p).total : stock_lds<float>(p).total; };
+        size_t tot = total();
+        if (tot > lds_max && p.twr_lds) { p.twr_lds = 0; tot = total(); }   // pair-pass twiddles from L2 instead
+        if (tot > lds_max && p.twmode != 1) { p.twmode = 1; tot = total(); }
         if (tot > lds_max) return false;
     }
     *threads_out = threads + 64 * P;

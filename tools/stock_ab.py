@@ -7,7 +7,9 @@ from bench_configs import run
 for v in [int(x) for x in sys.argv[1].split(",")]:
     pa.set_variant(v)
     for spec in sys.argv[2:]:
-        N, tr, o = spec.split(":")
-        N = int(N); trn = pa.COMPLEX if tr == "c" else pa.REAL
-        esz = 8 if tr == "c" else 4
-        run(N, trn, np.float32, (1 << 30) // (N * esz), f"v{v} {tr} N={N} ord={o}", ordered=(o == "1"))
+        f = spec.split(":")
+        N, tr, o = int(f[0]), f[1], f[2]
+        dbl = len(f) > 3 and f[3] == "d"
+        trn = pa.COMPLEX if tr == "c" else pa.REAL
+        esz = (8 if tr == "c" else 4) * (2 if dbl else 1)
+        run(N, trn, np.float64 if dbl else np.float32, (1 << 30) // (N * esz), f"v{v} {tr} N={N} ord={o} {'f64' if dbl else 'f32'}", ordered=(o == "1"))
