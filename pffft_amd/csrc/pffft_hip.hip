@@ -205,7 +205,7 @@ static Setup* new_setup(int N, int transform, int is_double) {
         s->kernel = K_TILED;  // power-of-two sizes: register-tiled kernels (fft_tiled.h)
     // every other size that fits: mixed-radix Stockham kernel (fft_stock.h); the in-place kernel of
     // fft_generic.h keeps the sizes whose two images exceed LDS
-    if (s->kernel != K_BIG && s->n >= 32)
+    if (s->kernel != K_BIG)
     {
         bool wl = false;
         s->sk_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->sk, &s->sk_threads, &wl, false, LDS_MAX);

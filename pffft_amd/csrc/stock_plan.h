@@ -52,6 +52,7 @@ static void sk_search(int rem, int minr, const std::vector<int>& set, std::vecto
     if ((int)cur.size() >= SK_MAX_STAGES) return;
     for (int r : set) {
         if (r < minr || rem % r) continue;
+        if (cur.empty() && r == rem) continue;   // at least two stages (the first one reads the deposit, the last one stores)
         cur.push_back(r);
         sk_search(rem / r, r, set, cur, best);
         cur.pop_back();
