@@ -1,0 +1,165 @@
+// Streaming versions of the spectrum helpers: pffft_zreorder (src/pffft_priv_impl.h:1158-1193) and
+// pffft_zconvolve_accumulate / _no_accu (:1534-1684) on device-resident batches.
+//
+// Both are pure HBM streams.  The first versions (fft_generic.h: grid-stride, one 64-bit division per element,
+// scalar 4-byte gathers straight from global memory for zreorder) measured, on MI355X (tools/aux_bench.py):
+// zconvolve 0.65-0.71 of 8 TB/s = the rate of a plain grid-stride copy, zreorder 0.41-0.61.  Here:
+//   * zreorder goes through an LDS image of the internal layout (the padded block image of fft_stock.h): linear
+//     16-byte chunks on both HBM sides, the permutation is done by 4-byte LDS accesses -> 0.61-0.70;
+//   * zconvolve issues all loads of two pairs per thread before the first product, remainders in 32 bits -> 0.69-0.70;
+//   * both can pull chunks in order from the work counter (SkSched, fft_stock.h) - measured SLOWER here
+//     (0.47-0.62 / 0.57-0.60; with one 16 KiB group per atomic even 0.16: one counter address serves ~80 M atomics/s),
+//     so the launchers assign statically and keep the in-order path for A/B (variant 42).
+#pragma once
+#include "fft_stock.h"
+#include "fft_tiled.h"  // ChunkOps
+
+namespace pf {
+
+constexpr int ZC_THREADS = 512;
+constexpr int ZC_U = 2;                                  // (re, im) group pairs per thread and chunk
+constexpr int ZC_CHUNK = ZC_THREADS * ZC_U;              // pairs per chunk: 32 KiB of a, of b and of ab in float
+
+// One thread handles a (re-group, im-group) pair = 4 complex products.  total = batch * npairs, npairs = n / 4.
+template <typename T, int ACC>
+__global__ void __launch_bounds__(ZC_THREADS)
+zconvolve_stream_kernel(const T* a, const T* b, T* ab, size_t total, unsigned npairs, int is_real, T scaling,
+                        int b_broadcast, unsigned* ctr, unsigned kchunk) {
+    __shared__ unsigned s_next[4];
+    SkSched sch;
+    sch.dyn = ctr != nullptr; sch.ctr = ctr; sch.s_next = s_next; sch.K = kchunk; sch.pend = 0;
+    sch.grab(threadIdx.x == 0);
+    __syncthreads();
+    sch.start();
+    __syncthreads();
+    const vec4<T>* a4 = reinterpret_cast<const vec4<T>*>(a);
+    const vec4<T>* b4 = reinterpret_cast<const vec4<T>*>(b);
+    vec4<T>* ab4 = reinterpret_cast<vec4<T>*>(ab);
+    const bool need_pr = is_real || b_broadcast;
+    const float inv_np = 1.0f / (float)npairs;
+    while ((size_t)sch.gcur * ZC_CHUNK < total) {
+        sch.top(threadIdx.x == 0);
+        const size_t base = (size_t)sch.gcur * ZC_CHUNK;
+        unsigned base_pr = 0;
+        if (need_pr) base_pr = (unsigned)(base % npairs);   // once per chunk; the per-pair remainder is 32-bit
+        vec4<T> ar[ZC_U], ai[ZC_U], br[ZC_U], bi[ZC_U], cr[ZC_U], ci[ZC_U];
+        unsigned pr[ZC_U];
+#pragma unroll
+        for (int u = 0; u < ZC_U; ++u) {
+            const unsigned k = threadIdx.x + ZC_THREADS * u;
+            size_t i = base + k;
+            if (i >= total) i = total - 1;   // clamped, unconditional loads; the store is predicated
+            unsigned x = base_pr + k;        // < npairs + ZC_CHUNK
+            if (need_pr) {
+                if (npairs >= (unsigned)ZC_CHUNK) x = x >= npairs ? x - npairs : x;
+                else x -= (unsigned)fdiv((int)x, (int)npairs, inv_np) * npairs;
+            }
+            pr[u] = x;
+            const size_t ib = b_broadcast ? (size_t)x : i;
+            ar[u] = __builtin_nontemporal_load(a4 + 2 * i); ai[u] = __builtin_nontemporal_load(a4 + 2 * i + 1);
+            br[u] = b_broadcast ? b4[2 * ib] : __builtin_nontemporal_load(b4 + 2 * ib);
+            bi[u] = b_broadcast ? b4[2 * ib + 1] : __builtin_nontemporal_load(b4 + 2 * ib + 1);
+            if (ACC) { cr[u] = __builtin_nontemporal_load(ab4 + 2 * i); ci[u] = __builtin_nontemporal_load(ab4 + 2 * i + 1); }
+        }
+#pragma unroll
+        for (int u = 0; u < ZC_U; ++u) {
+            const size_t i = base + threadIdx.x + ZC_THREADS * u;
+            vec4<T> pre = ar[u] * br[u] - ai[u] * bi[u], pim = ar[u] * bi[u] + ai[u] * br[u];
+            if (is_real && pr[u] == 0) {  // DC and Nyquist are both real: multiply separately (:1626-1629, :1680-1683)
+                pre.x = ar[u].x * br[u].x;
+                pim.x = ai[u].x * bi[u].x;
+            }
+            vec4<T> o0, o1;
+            if (ACC) { o0 = cr[u] + pre * scaling; o1 = ci[u] + pim * scaling; }
+            else { o0 = pre * scaling; o1 = pim * scaling; }
+            if (i < total) {
+                __builtin_nontemporal_store(o0, ab4 + 2 * i);
+                __builtin_nontemporal_store(o1, ab4 + 2 * i + 1);
+            }
+        }
+        __syncthreads();
+        sch.advance();
+    }
+    sch.finish(threadIdx.x == 0);
+}
+
+// zreorder through the padded block image: G vectors per pass.  to_canonical: internal -> canonical (PFFFT_FORWARD).
+constexpr int ZR_THREADS = 256;
+template <typename T>
+__global__ void __launch_bounds__(ZR_THREADS)
+zreorder_lds_kernel(const T* in, T* out, size_t batch, int n, int is_real, int to_canonical, int G, unsigned m_n4,
+                    unsigned m_nchk, unsigned* ctr, unsigned kchunk) {
+    typedef vec4<float> chunk16;
+    constexpr int IBS = SkIbs<T>::v, CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = IBS / CH;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* const lds = reinterpret_cast<T*>(smem_raw);
+    chunk16* const lds16 = reinterpret_cast<chunk16*>(smem_raw);
+    const int nchk = 2 * n / CH;                  // 16-byte chunks per vector
+    const int img16 = (n / 16) * BCH + 1;         // block image per vector, in chunks
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + (size_t)G * img16 * 16);
+    const int n4 = n >> 2, tid = threadIdx.x;
+    SkSched sch;
+    sch.dyn = ctr != nullptr; sch.ctr = ctr; sch.s_next = s_next; sch.K = kchunk; sch.pend = 0;
+    sch.grab(tid == 0);
+    __syncthreads();
+    sch.start();
+    __syncthreads();
+    const chunk16* in16 = reinterpret_cast<const chunk16*>(in);
+    chunk16* out16 = reinterpret_cast<chunk16*>(out);
+    // scalar index inside a vector's block image of scalar e of canonical chunk cc
+    auto ipos_of = [&](int cc, int e) -> int {
+        const int s = cc * CH + e, bin = s >> 1, part = s & 1;
+        const int ip = is_real ? sk_iposr<T>(bin, n4, m_n4, IBS)
+                               : (IBS * ((bin - udiv(bin, m_n4) * n4) >> 2) + 8 * udiv(bin, m_n4) + ((bin - udiv(bin, m_n4) * n4) & 3));
+        return ip + 4 * part;
+    };
+    while ((size_t)sch.gcur * G < batch) {
+        sch.top(tid == 0);
+        const size_t t0 = (size_t)sch.gcur * G;
+        const int cnt = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);
+        const int tot = cnt * nchk;
+        const chunk16* src = in16 + t0 * nchk;
+        chunk16* dst = out16 + t0 * nchk;
+        // ---- phase 1: 4 independent 16-byte loads in flight per thread, then into the image
+        for (int c0 = tid; c0 < tot; c0 += 4 * ZR_THREADS) {
+            chunk16 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * ZR_THREADS;
+                v[u] = __builtin_nontemporal_load(src + (c < tot ? c : tot - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * ZR_THREADS;
+                if (c >= tot) continue;
+                const int g = udiv(c, m_nchk), cc = c - g * nchk;
+                if (to_canonical) {
+                    lds16[g * img16 + (cc / CPB) * BCH + (cc % CPB)] = v[u];
+                } else {
+                    T* img = lds + (size_t)g * img16 * CH;
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) img[ipos_of(cc, e)] = ChunkOps<T>::get(v[u], e);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: out of the image, linear 16-byte stores
+        for (int c = tid; c < tot; c += ZR_THREADS) {
+            const int g = udiv(c, m_nchk), cc = c - g * nchk;
+            chunk16 o;
+            if (to_canonical) {
+                const T* img = lds + (size_t)g * img16 * CH;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) ChunkOps<T>::set(o, e, img[ipos_of(cc, e)]);
+            } else {
+                o = lds16[g * img16 + (cc / CPB) * BCH + (cc % CPB)];
+            }
+            __builtin_nontemporal_store(o, dst + c);
+        }
+        __syncthreads();
+        sch.advance();
+    }
+    sch.finish(tid == 0);
+}
+
+}  // namespace pf

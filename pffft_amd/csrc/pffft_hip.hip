@@ -21,6 +21,7 @@
 #include "fft_stock.h"
 #include "stock_plan.h"
 #include "stock_plans_gen.h"
+#include "fft_aux.h"
 
 namespace pf {
 
@@ -611,6 +612,38 @@ template <typename T>
 static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, hipStream_t st) {
     if (!s || s->magic != MAGIC) return (int)hipErrorInvalidHandle;
     if (batch == 0) return 0;
+    // through an LDS image of the internal layout when a vector fits (fft_aux.h); variant 60 = the direct kernel
+    constexpr int CH = 16 / (int)sizeof(T), BCH = SkIbs<T>::v / CH;
+    const size_t vimg = ((size_t)(s->n / 16) * BCH + 1) * 16;   // block image of one vector, bytes
+    if (vimg <= 128 * 1024 && g_variant != 60 && in != out) {
+        int rc = ensure_device<T>(s);
+        if (rc) return rc;
+        int G = (int)(16384 / vimg);
+        if (G < 1) G = 1;
+        const size_t lds = (size_t)G * vimg + 16;
+        auto k = zreorder_lds_kernel<T>;
+        if ((rc = allow_big_lds(k, lds))) return rc;
+        size_t per_cu = LDS_MAX / lds;
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        const size_t groups = (batch + G - 1) / G;
+        size_t grid = (size_t)num_cus() * per_cu;
+        if (grid > groups) grid = groups;
+        // >= 128 KiB per atomic (one counter address serves ~80 M atomics/s), >= 8 chunks per workgroup
+        size_t kc = (131072 + G * vimg - 1) / (G * vimg), cap = groups / (8 * grid);
+        if (kc > cap) kc = cap;
+        if (kc > 64) kc = 64;
+        // static by default: 0.61-0.70 of the roofline against 0.47-0.62 with in-order chunks (variant 42) and
+        // 0.41-0.61 for the direct kernel (tools/aux_bench.py)
+        unsigned* ctr = (kc < 1 || g_variant != 42) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+        if (kc < 1) kc = 1;
+        const int nchk = 2 * s->n / CH;
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(ZR_THREADS), lds, st, in, out, batch, s->n,
+                           (int)(s->transform == PFFFT_REAL), (int)(dir == PFFFT_FORWARD), G, sk_magic(s->n / 4),
+                           sk_magic(nchk), ctr, (unsigned)kc);
+        PF_CHECK(hipGetLastError());
+        return 0;
+    }
     size_t total = batch * (size_t)(s->n / 2);
     size_t grid = (total + 255) / 256;
     if (grid > (size_t)num_cus() * 16) grid = (size_t)num_cus() * 16;
@@ -626,6 +659,29 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
     if (!s || s->magic != MAGIC) return (int)hipErrorInvalidHandle;
     if (batch == 0) return 0;
     size_t total = batch * (size_t)(s->n / 4);
+    // float: streaming kernel, two pairs per thread with all loads issued first (fft_aux.h): 0.69-0.70 against 0.65-0.70
+    // for the grid-stride kernel, which stays for double (0.65 vs 0.41) and as variant 60; in-order chunks (variant 42)
+    // measured 0.57-0.60
+    if (g_variant != 60 && sizeof(T) == 4) {
+        int rc = ensure_device<T>(s);
+        if (rc) return rc;
+        const size_t chunks = (total + ZC_CHUNK - 1) / ZC_CHUNK;
+        size_t grid = (size_t)num_cus() * 4;
+        if (grid > chunks) grid = chunks;
+        size_t kc = 4, cap = chunks / (8 * grid);
+        if (kc > cap) kc = cap;
+        unsigned* ctr = (kc < 1 || g_variant != 42) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+        if (kc < 1) kc = 1;
+        const int real = s->transform == PFFFT_REAL;
+        if (accumulate)
+            hipLaunchKernelGGL((zconvolve_stream_kernel<T, 1>), dim3((unsigned)grid), dim3(ZC_THREADS), 0, st, a, b, ab, total,
+                               (unsigned)(s->n / 4), real, scaling, b_broadcast, ctr, (unsigned)kc);
+        else
+            hipLaunchKernelGGL((zconvolve_stream_kernel<T, 0>), dim3((unsigned)grid), dim3(ZC_THREADS), 0, st, a, b, ab, total,
+                               (unsigned)(s->n / 4), real, scaling, b_broadcast, ctr, (unsigned)kc);
+        PF_CHECK(hipGetLastError());
+        return 0;
+    }
     size_t grid = (total + 255) / 256;
     if (grid > (size_t)num_cus() * 16) grid = (size_t)num_cus() * 16;
     const size_t vs = s->vec_scalars;

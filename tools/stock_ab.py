@@ -12,4 +12,5 @@ for v in [int(x) for x in sys.argv[1].split(",")]:
         dbl = len(f) > 3 and f[3] == "d"
         trn = pa.COMPLEX if tr == "c" else pa.REAL
         esz = (8 if tr == "c" else 4) * (2 if dbl else 1)
-        run(N, trn, np.float64 if dbl else np.float32, (1 << 30) // (N * esz), f"v{v} {tr} N={N} ord={o} {'f64' if dbl else 'f32'}", ordered=(o == "1"))
+        batch = (1 << int(f[4])) if len(f) > 4 else (1 << 30) // (N * esz)
+        run(N, trn, np.float64 if dbl else np.float32, batch, f"v{v} {tr} N={N} ord={o} {'f64' if dbl else 'f32'} b={batch}", ordered=(o == "1"))
