@@ -626,7 +626,9 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
         sk_sync<true>();          // the last phase's LDS reads are done before ...
         deposit(w * c.bufsz);     // ... the next group lands in the free image
         w ^= 1;
-        __syncthreads();          // (also orders the deposit against the next iteration's reads)
+        // orders the deposit against the next iteration's reads; the workgroup barrier is only needed to hand the
+        // next chunk index over (statically scheduled wavefronts never meet inside the loop)
+        if (sch.dyn) __syncthreads(); else sk_sync<true>();
         sch.advance();
     }
     sch.finish(tid == 0);
