@@ -393,3 +393,57 @@ def test_stockham_matches_reference_inplace(ref):
         got = s.transform_batch(_dev(x[:4]), None, pa.FORWARD, False).cpu().numpy()
         assert relerr(got, want) <= 1e-5
         s.close(); rs.close()
+
+
+def test_concurrent_streams_share_a_setup():
+    """One setup used from two streams at once (the reference allows sharing a setup between threads,
+    include/pffft/pffft.h:102-105): launches of the dynamically scheduled kernels take their work counters
+    from a ring, so interleaved launches must not disturb each other."""
+    for N, tr in ((1024, 1), (4096, 1), (480, 1), (16384, 0)):
+        s = pa.Setup(N, tr, np.float32)
+        batch = max(64, (64 << 20) // (s.vec_scalars * 4))
+        g = torch.Generator(device="cuda"); g.manual_seed(N)
+        xa = torch.rand(batch, s.vec_scalars, device="cuda", generator=g) * 2 - 1
+        xb = torch.rand(batch, s.vec_scalars, device="cuda", generator=g) * 2 - 1
+        wa = s.transform_batch(xa, None, pa.FORWARD, False).clone()
+        wb = s.transform_batch(xb, None, pa.FORWARD, False).clone()
+        torch.cuda.synchronize()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        ya, yb = torch.empty_like(xa), torch.empty_like(xb)
+        for _ in range(6):
+            with torch.cuda.stream(sa):
+                s.transform_batch(xa, ya, pa.FORWARD, False)
+            with torch.cuda.stream(sb):
+                s.transform_batch(xb, yb, pa.FORWARD, False)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, wa) and torch.equal(yb, wb), (N, tr)
+        s.close()
+
+
+@pytest.mark.parametrize("variant", [0, 42, 60])
+def test_spectrum_helpers_paths(ref, variant):
+    """zreorder / zconvolve: LDS-image + streaming kernels (0), their in-order chunk scheduler (42), the direct
+    grid-stride kernels (60) - against the reference on ragged batches."""
+    pa.set_variant(variant)
+    try:
+        for dt in ("f32", "f64"):
+            dtype = _dt(dt)
+            for N, tr in ((96, 1), (1024, 1), (2400, 0), (16384, 0), (64, 0)):
+                rs, s = ref.setup(N, tr, dtype), pa.Setup(N, tr, dtype)
+                batch = 2051 if N <= 2400 else 131
+                rng = np.random.default_rng(N + variant)
+                a = rng.uniform(-1, 1, (batch, s.vec_scalars)).astype(dtype)
+                b = rng.uniform(-1, 1, (batch, s.vec_scalars)).astype(dtype)
+                c = rng.uniform(-1, 1, (batch, s.vec_scalars)).astype(dtype)
+                can = s.zreorder_batch(_dev(a), None, pa.FORWARD)
+                back = s.zreorder_batch(can, None, pa.BACKWARD)
+                assert torch.equal(back.cpu(), torch.from_numpy(a)), (dt, N, tr, variant)
+                assert np.array_equal(can[:3].cpu().numpy(), np.stack([rs.zreorder(a[i], 0) for i in range(3)]))
+                for acc in (True, False):
+                    got = s.zconvolve_batch(_dev(a), _dev(b), _dev(c), 0.37, accumulate=acc).cpu().numpy()
+                    for i in (0, batch // 2, batch - 1):
+                        want = rs.zconvolve(a[i], b[i], c[i], 0.37, acc)
+                        assert relerr(got[i], want) <= tol_for(dt, N), (dt, N, tr, variant, acc, i)
+                s.close(); rs.close()
+    finally:
+        pa.set_variant(0)
