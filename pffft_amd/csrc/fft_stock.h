@@ -61,6 +61,8 @@ struct StockPlan {
     int twr_lds;     // W_N^k table of the real pair pass in LDS
     int C, P;        // compute threads, producer wavefronts (blockDim = C + 64 P)
     unsigned m_n4, m_per, m_nchk;  // magic multipliers for n/4, n/2 + 1, 16-byte chunks per vector
+    int sym, sym_items; unsigned m_sym; // real transforms: symmetric spectrum-side stage (pairs in registers) with (nb + 1) / 2
+                                   // work items - or, sym == 0, a separate pair phase over a natural image
     StockStage st[SK_MAX_STAGES];
 };
 
@@ -99,6 +101,8 @@ template <typename T> struct SkArgs {
     int src_off, dst_off, tab_off;   // source image, destination image, W_n^j table (complex points)
     cx<T>* gdst;                 // vector 0 of the group (stride n)
     const cx<T>* twg;            // global W_n^j table (twmode 1; in twmode 2 the kernel is handed the compact table)
+    // real transforms: W_N^k of the pair pass (LDS copy at twr_off, or the global table), work items of the symmetric stage
+    const cx<T>* twrg; int twr_off; bool twr_lds; int sym_items; unsigned m_sym; int cnt, maxcnt;
 };
 
 __device__ __forceinline__ int tpad(int i) { return i + (i >> 5); }
@@ -195,6 +199,190 @@ __device__ __forceinline__ void sk_stage(const StockStage& st, const SkArgs<T>& 
     }
 }
 
+// scalar index (real part; imaginary part + 4) of half-complex bin k of a REAL transform inside the
+// internal-layout image: odd quarters run backwards (bin_of, fft_generic.h)
+template <typename T> __device__ __forceinline__ int sk_iposr(int k, int n4, unsigned m_n4, int ibs) {
+    const int qq = udiv(k, m_n4), r = k - qq * n4;
+    const int tt = (qq & 1) ? (r ? n4 - r : 0) : r;
+    return ibs * (tt >> 2) + 8 * qq + (tt & 3);
+}
+
+// operands of butterfly j of a stage whose source is an LDS image, twiddled and transformed (the body of sk_stage)
+template <typename T, int R>
+__device__ __forceinline__ void sk_bfly(const StockStage& st, const SkArgs<T>& a, int g, int j, cx<T> (&v)[R]) {
+    typedef cx<T> CX;
+    int jd = j, jm = 0;
+    if (st.Ns > 1) { jd = udiv(j, st.m_Ns); jm = j - jd * st.Ns; }
+    const CX* p = a.lds + a.src_off + g * a.img + j + jd * st.rpad;
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = p[q * st.rstride];
+    if (st.Ns > 1) {
+        const int k = jm * st.twstep;
+        if (a.twmode == 0) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) v[q] = cmul(v[q], a.lds[a.tab_off + tpad(q * k)]);
+        } else {
+            CX p1;
+            if (a.twmode == 2) p1 = a.lds[a.tab_off + st.tw_off + jm];
+            else { p1 = a.twg[k]; asm volatile(""); }
+            // w^q = (w^4)^(q div 4) w^(q mod 4): five live values instead of R (two butterflies' worth of registers
+            // are in use here), every power at most 5 products deep
+            const CX w2 = cmul(p1, p1), w3 = cmul(w2, p1), w4 = cmul(w2, w2);
+            CX blk = w4;
+#pragma unroll
+            for (int q = 1; q < R; ++q) {
+                const int aa = q >> 2, b = q & 3;
+                const CX wb = b == 1 ? p1 : (b == 2 ? w2 : w3);
+                CX t;
+                if (aa == 0) t = wb;
+                else t = b == 0 ? blk : cmul(blk, wb);
+                v[q] = cmul(v[q], t);
+                if (aa >= 1 && b == 3) blk = cmul(blk, w4);
+            }
+        }
+    }
+    dftR<R, FWD>(v);
+}
+
+template <typename T> __device__ __forceinline__ cx<T> sk_wN(const SkArgs<T>& a, int k) {   // W_N^k, 0 < k < n, N = 2n
+    const int kk = 2 * k <= a.n ? k : a.n - k;
+    cx<T> w;
+    if (a.twr_lds) w = a.lds[a.twr_off + kk];
+    else { w = a.twrg[kk]; asm volatile(""); }
+    return 2 * k <= a.n ? w : mk<T>(-w.x, w.y);   // W_N^k = -conj(W_N^(n-k))
+}
+
+// Real forward, last stage, SYMMETRIC assignment: a work item owns butterflies j and nb - j (item 0: butterfly 0 and,
+// when nb is even, nb/2), i.e. bin k = j + d nb together with its mirror n - k = (nb - j) + (R-1-d) nb, so the pair pass
+//   X[k] = S + D, X[n-k] = conj(S - D), S = (A+B)/2, D = -(i/2) W_N^k (A-B), A = Z[k], B = conj Z[n-k]
+// runs on registers and the half-complex spectrum goes straight to its destination (HBM, or the internal-layout
+// image) - no natural image, no separate pair phase, one barrier less.
+template <typename T, int R, int DST>
+__device__ __forceinline__ void sk_last_real(const StockStage& st, const SkArgs<T>& a) {
+    typedef cx<T> CX;
+    const int n = a.n, nb = st.nb, n4 = n >> 2, items = a.sym_items;
+    auto pairf = [&](CX A, CX Bn, int k, CX& Xa, CX& Xb) {
+        const CX B = conj(Bn), wk = sk_wN<T>(a, k);
+        const CX S = (A + B) * (T)0.5, Dm = cmul((A - B) * (T)0.5, wk);
+        const CX D = mk<T>(Dm.y, -Dm.x);
+        Xa = S + D;
+        Xb = conj(S - D);
+    };
+#pragma unroll
+    for (int i0 = 0; i0 < a.maxcnt * items; i0 += a.nthr) {
+        const int i = i0 + a.tid;
+        if (i >= a.cnt * items) continue;
+        const int gl = udiv(i, a.m_sym), it = i - gl * items, g = a.slot0 + gl;
+        const bool even = (nb & 1) == 0;
+        const int j1 = it, j2 = it ? nb - it : (even ? nb >> 1 : 0);
+        CX v1[R], v2[R];
+        sk_bfly<T, R>(st, a, g, j1, v1);
+        sk_bfly<T, R>(st, a, g, j2, v2);
+        auto put = [&](int k, CX X) {
+            if constexpr (DST == SK_G) {
+                __builtin_nontemporal_store(X, a.gdst + (size_t)g * n + k);
+            } else {
+                T* pd = reinterpret_cast<T*>(a.lds + a.dst_off + g * a.img);
+                const int ip = sk_iposr<T>(k, n4, a.m_n4, a.ibs);
+                pd[ip] = X.x; pd[ip + 4] = X.y;
+            }
+        };
+        if (it) {
+#pragma unroll
+            for (int d = 0; d < R; ++d) {
+                const int k = j1 + d * nb;
+                CX Xa, Xb;
+                pairf(v1[d], v2[R - 1 - d], k, Xa, Xb);
+                put(k, Xa);
+                put(n - k, Xb);
+            }
+        } else {
+            put(0, mk<T>(v1[0].x + v1[0].y, v1[0].x - v1[0].y));   // (DC, Nyquist): include/pffft/pffft.h:144-152
+#pragma unroll
+            for (int d = 1; 2 * d < R; ++d) {
+                CX Xa, Xb;
+                pairf(v1[d], v1[R - d], d * nb, Xa, Xb);
+                put(d * nb, Xa);
+                put(n - d * nb, Xb);
+            }
+            if constexpr (R % 2 == 0) put(n >> 1, conj(v1[R / 2]));
+            if (even) {
+#pragma unroll
+                for (int d = 0; 2 * d < R - 1; ++d) {
+                    const int k = (nb >> 1) + d * nb;
+                    CX Xa, Xb;
+                    pairf(v2[d], v2[R - 1 - d], k, Xa, Xb);
+                    put(k, Xa);
+                    put(n - k, Xb);
+                }
+                if constexpr (R % 2 == 1) put(n >> 1, conj(v2[(R - 1) / 2]));
+            }
+        }
+    }
+}
+
+// Real backward, first stage, symmetric assignment: the operands of butterflies j and nb - j are the mirror pairs
+//   Z'[k] = S + D, Z'[n-k] = conj(S - D), S = A + B, D = i conj(W_N^k) (A - B), A = X[k], B = conj X[n-k]
+// built in registers from the deposited half-complex spectrum (natural or internal-layout image), conjugated because
+// the stages run a forward transform (the store conjugates back).
+template <typename T, int R, int SRC>
+__device__ __forceinline__ void sk_first_real(const StockStage& st, const SkArgs<T>& a) {
+    typedef cx<T> CX;
+    const int n = a.n, nb = st.nb, n4 = n >> 2, items = a.sym_items;
+#pragma unroll
+    for (int i0 = 0; i0 < a.maxcnt * items; i0 += a.nthr) {
+        const int i = i0 + a.tid;
+        if (i >= a.cnt * items) continue;
+        const int gl = udiv(i, a.m_sym), it = i - gl * items, g = a.slot0 + gl;
+        const bool even = (nb & 1) == 0;
+        const int j1 = it, j2 = it ? nb - it : (even ? nb >> 1 : 0);
+        auto get = [&](int k) -> CX {
+            if constexpr (SRC == SK_L) {
+                return a.lds[a.src_off + g * a.img + k];
+            } else {
+                const T* ps = reinterpret_cast<const T*>(a.lds + a.src_off + g * a.img);
+                const int ip = sk_iposr<T>(k, n4, a.m_n4, a.ibs);
+                return mk<T>(ps[ip], ps[ip + 4]);
+            }
+        };
+        // conj Z'[k] -> za, conj Z'[n-k] -> zb
+        auto pairb = [&](int k, CX& za, CX& zb) {
+            const CX A = get(k), B = conj(get(n - k)), wk = sk_wN<T>(a, k);
+            const CX S = A + B, Dm = cmulc(A - B, wk);
+            const CX D = mk<T>(-Dm.y, Dm.x);
+            za = conj(S + D);
+            zb = S - D;
+        };
+        CX v1[R], v2[R];
+        if (it) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) pairb(j1 + q * nb, v1[q], v2[R - 1 - q]);
+        } else {
+            { const CX A = get(0); v1[0] = mk<T>(A.x + A.y, -(A.x - A.y)); }
+#pragma unroll
+            for (int q = 1; 2 * q < R; ++q) pairb(q * nb, v1[q], v1[R - q]);
+            if constexpr (R % 2 == 0) { const CX A = get(n >> 1); v1[R / 2] = mk<T>((T)2 * A.x, (T)2 * A.y); }
+#pragma unroll
+            for (int q = 0; q < R; ++q) v2[q] = v1[q];   // (nb odd: butterfly 0 twice, the second copy is not stored)
+            if (even) {
+#pragma unroll
+                for (int q = 0; 2 * q < R - 1; ++q) pairb((nb >> 1) + q * nb, v2[q], v2[R - 1 - q]);
+                if constexpr (R % 2 == 1) { const CX A = get(n >> 1); v2[(R - 1) / 2] = mk<T>((T)2 * A.x, (T)2 * A.y); }
+            }
+        }
+        dftR<R, FWD>(v1);
+        dftR<R, FWD>(v2);
+        CX* p1 = a.lds + a.dst_off + g * a.img + j1 * st.wblk;   // first stage: Ns = 1
+#pragma unroll
+        for (int d = 0; d < R; ++d) p1[d] = v1[d];
+        if (it || even) {
+            CX* p2 = a.lds + a.dst_off + g * a.img + j2 * st.wblk;
+#pragma unroll
+            for (int d = 0; d < R; ++d) p2[d] = v2[d];
+        }
+    }
+}
+
 template <typename T, int SRC, int DST>
 __device__ __forceinline__ void sk_run(const StockStage& st, const SkArgs<T>& a) {
     switch (st.R) {
@@ -214,12 +402,42 @@ __device__ __forceinline__ void sk_run(const StockStage& st, const SkArgs<T>& a)
     }
 }
 
-// scalar index (real part; imaginary part + 4) of half-complex bin k of a REAL transform inside the
-// internal-layout image: odd quarters run backwards (bin_of, fft_generic.h)
-template <typename T> __device__ __forceinline__ int sk_iposr(int k, int n4, unsigned m_n4, int ibs) {
-    const int qq = udiv(k, m_n4), r = k - qq * n4;
-    const int tt = (qq & 1) ? (r ? n4 - r : 0) : r;
-    return ibs * (tt >> 2) + 8 * qq + (tt & 3);
+
+template <typename T, int DST>
+__device__ __forceinline__ void sk_run_last_real(const StockStage& st, const SkArgs<T>& a) {
+    switch (st.R) {
+        case 3: sk_last_real<T, 3, DST>(st, a); break;
+        case 4: sk_last_real<T, 4, DST>(st, a); break;
+        case 5: sk_last_real<T, 5, DST>(st, a); break;
+        case 6: sk_last_real<T, 6, DST>(st, a); break;
+        case 8: sk_last_real<T, 8, DST>(st, a); break;
+        case 10: sk_last_real<T, 10, DST>(st, a); break;
+        case 12: sk_last_real<T, 12, DST>(st, a); break;
+        default:
+            if constexpr (sizeof(T) == 4) {
+                if (st.R == 15) sk_last_real<T, 15, DST>(st, a);
+                else sk_last_real<T, 16, DST>(st, a);
+            }
+            break;
+    }
+}
+template <typename T, int SRC>
+__device__ __forceinline__ void sk_run_first_real(const StockStage& st, const SkArgs<T>& a) {
+    switch (st.R) {
+        case 3: sk_first_real<T, 3, SRC>(st, a); break;
+        case 4: sk_first_real<T, 4, SRC>(st, a); break;
+        case 5: sk_first_real<T, 5, SRC>(st, a); break;
+        case 6: sk_first_real<T, 6, SRC>(st, a); break;
+        case 8: sk_first_real<T, 8, SRC>(st, a); break;
+        case 10: sk_first_real<T, 10, SRC>(st, a); break;
+        case 12: sk_first_real<T, 12, SRC>(st, a); break;
+        default:
+            if constexpr (sizeof(T) == 4) {
+                if (st.R == 15) sk_first_real<T, 15, SRC>(st, a);
+                else sk_first_real<T, 16, SRC>(st, a);
+            }
+            break;
+    }
 }
 
 // One pass of the compute side over `cnt` vectors (image slots slot0 .. slot0 + cnt - 1) whose input sits in
@@ -258,7 +476,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
     // ---- real backward: half-complex spectrum X -> conj of the packed spectrum Z' (the stages then run
     //      a forward transform; the final conjugation happens on the store):
     //      Z'[k] = S + D, Z'[n-k] = conj(S - D), S = A + B, D = i conj(W_N^k) (A - B), A = X[k], B = conj X[n-k]
-    if (real && bwd) {
+    if (real && bwd && !p.sym) {
 #pragma unroll
         for (int id0 = 0; id0 < maxcnt * per; id0 += wn) {
             const int id = id0 + wtid;
@@ -303,21 +521,30 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
         a.tid = wtid; a.nthr = wn; a.slot0 = slot0; a.n = n; a.m_n4 = p.m_n4; a.img = p.img; a.twmode = p.twmode; a.ibs = p.ibs;
         a.lds = lds; a.tab_off = c.tab_off; a.gdst = gout; a.twg = c.twg;
         a.cj_out = bwd;
+        a.twrg = c.twrg; a.twr_off = c.twr_off; a.twr_lds = c.twr_lds; a.sym_items = p.sym_items; a.m_sym = p.m_sym;
+        a.cnt = cnt; a.maxcnt = maxcnt;
 #pragma unroll
         for (int s = 0; s < SK_MAX_STAGES; ++s) {
             if (s < ns) {
                 const StockStage& st = s == 0 ? st0 : s == 1 ? st1 : s == 2 ? st2 : st3;
                 a.total = cnt * st.nb; a.maxtotal = maxcnt * st.nb;
                 a.src_off = (w ^ 1) * bufsz; a.dst_off = w * bufsz;
-                a.cj_in = (s == 0) && bwd && !real;   // real backward: the pair pass already conjugated
+                a.cj_in = (s == 0) && bwd && !real;   // real backward: the pair pass / symmetric first stage conjugates
                 if (s < ns - 1) {
-                    if (s == 0 && in_int && !real) sk_run<T, SK_I, SK_L>(st, a);
+                    if (s == 0 && real && bwd && p.sym) {   // half-complex spectrum -> first butterflies, pairs in registers
+                        if (in_int) sk_run_first_real<T, SK_I>(st, a); else sk_run_first_real<T, SK_L>(st, a);
+                    }
+                    else if (s == 0 && in_int && !real) sk_run<T, SK_I, SK_L>(st, a);
                     else sk_run<T, SK_L, SK_L>(st, a);
                     w ^= 1;
                     sk_sync<WL>();
+                } else if (real && !bwd && p.sym) {    // last butterflies -> half-complex spectrum, pairs in registers
+                    if (out_int) { sk_run_last_real<T, SK_I>(st, a); w ^= 1; sk_sync<WL>(); }
+                    else sk_run_last_real<T, SK_G>(st, a);
+                } else if (real && !bwd) {             // natural image for the pair phase below
+                    sk_run<T, SK_L, SK_L>(st, a); w ^= 1; sk_sync<WL>();
                 } else {
-                    if (real && !bwd) { sk_run<T, SK_L, SK_L>(st, a); w ^= 1; sk_sync<WL>(); }
-                    else if (out_int) { sk_run<T, SK_L, SK_I>(st, a); w ^= 1; sk_sync<WL>(); }
+                    if (out_int) { sk_run<T, SK_L, SK_I>(st, a); w ^= 1; sk_sync<WL>(); }
                     else sk_run<T, SK_L, SK_G>(st, a);
                 }
             }
@@ -325,7 +552,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
     }
     // ---- real forward: packed spectrum Z (natural image) -> half-complex spectrum X:
     //      X[k] = S + D, X[n-k] = conj(S - D), S = (A+B)/2, D = -(i/2) W_N^k (A-B), A = Z[k], B = conj Z[n-k]
-    if (real && !bwd) {
+    if (real && !bwd && !p.sym) {
 #pragma unroll
         for (int id0 = 0; id0 < maxcnt * per; id0 += wn) {
             const int id = id0 + wtid;
@@ -464,8 +691,9 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
     const int nchk = (int)((size_t)n * sizeof(CX) / 16);
     const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);
     // LDS-writing compute phases per iteration (each followed by one barrier); + the closing barrier
-    const int last_lds = (c.real && !c.bwd) || c.out_int;
-    const int Fc = ((c.real && c.bwd) ? 1 : 0) + (ns - 1) + (last_lds ? 1 : 0) + ((c.real && !c.bwd && c.out_int) ? 1 : 0);
+    const int Fc = p.sym ? (ns - 1) + (c.out_int ? 1 : 0)
+                         : ((c.real && c.bwd) ? 1 : 0) + (ns - 1) + (((c.real && !c.bwd) || c.out_int) ? 1 : 0) +
+                               ((c.real && !c.bwd && c.out_int) ? 1 : 0);
 
     SkSched sch;
     sch.dyn = ctr != nullptr; sch.ctr = ctr; sch.s_next = s_next; sch.K = kchunk; sch.pend = 0;

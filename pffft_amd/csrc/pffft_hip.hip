@@ -588,14 +588,14 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         // power-of-two sizes where the Stockham kernel instantiated on its compile-time plan measured faster than
         // the register-tiled one (float, 1 GiB of vectors, tools/stock_ab.py; variant 54 = always tiled):
         //   complex n = 16: 0.46 vs 0.26, 32: 0.70 vs 0.59, 64: 0.70 vs 0.65, 4096 unordered: 0.67 vs 0.62,
-        //   8192: 0.68/0.73 vs 0.62/0.70;  real N = 32: 0.38 vs 0.26, 64: 0.66 vs 0.60, 16384 unordered: 0.58 vs 0.52
+        //   8192: 0.68/0.73 vs 0.62/0.70;  real N = 32: 0.38 vs 0.26, 64: 0.66 vs 0.60, 16384: 0.61-0.68 vs 0.51-0.60 (symmetric spectrum-side stage)
         //   double: complex n = 16: 0.50 vs 0.26, 32: 0.70 vs 0.48, 64: 0.69 vs 0.47, 2048: 0.65 vs 0.53, 4096: 0.73 vs 0.51;
         //   real N = 32: 0.42 vs 0.29, 64: 0.66 vs 0.55, 4096: 0.63 vs 0.45, 8192: 0.67 vs 0.44; a tie from 128 to 1024
         bool stock = false;
         if (s->sk_ok && g_variant != 54) {
             const int n = s->n;
             const bool cplx = s->transform == PFFFT_COMPLEX;
-            if (sizeof(T) == 4) stock = cplx ? (n <= 64 || (n == 4096 && !ordered) || n == 8192) : (n <= 32 || (n == 8192 && !ordered));
+            if (sizeof(T) == 4) stock = cplx ? (n <= 64 || (n == 4096 && !ordered) || n == 8192) : (n <= 32 || n == 8192);
             else stock = cplx ? (n <= 64 || n >= 2048) : (n <= 32 || n >= 2048);
         }
         if (!stock) return launch_tiled<T>(s, in, out, batch, dir, ordered, st);

@@ -61,7 +61,7 @@ static void sk_search(int rem, int minr, const std::vector<int>& set, std::vecto
 
 // stage order: the HBM-side stages get the large radices (more loads in flight per thread); the stage next
 // to an internal-layout image (last one forward, first one backward) a multiple of 4 (compile-time quarter split)
-static std::vector<int> sk_order(std::vector<int> r, bool bwd) {
+static std::vector<int> sk_order(std::vector<int> r, bool bwd, bool real) {
     std::sort(r.begin(), r.end());
     auto take = [&](bool want4) -> int {
         int pick = -1;
@@ -71,7 +71,16 @@ static std::vector<int> sk_order(std::vector<int> r, bool bwd) {
         r.erase(r.begin() + pick);
         return v;
     };
-    const int layout_side = take(true);
+    // real transforms: a work item of the spectrum-side stage holds TWO butterflies (mirror pairs in registers):
+    // give that stage the smallest multiple of 4 that is >= 8 (else any multiple of 4) instead of the largest
+    int layout_side = -1;
+    if (real) {
+        int pick = -1;
+        for (int i = 0; i < (int)r.size(); ++i) if (r[i] % 4 == 0 && r[i] >= 8) { pick = i; break; }
+        if (pick < 0) for (int i = 0; i < (int)r.size(); ++i) if (r[i] % 4 == 0) { pick = i; break; }
+        if (pick >= 0) { layout_side = r[pick]; r.erase(r.begin() + pick); }
+    }
+    if (layout_side < 0) layout_side = take(true);
     const int other_side = r.empty() ? 0 : take(false);
     std::vector<int> o;
     o.push_back(bwd ? layout_side : other_side);
@@ -154,7 +163,11 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
     for (int dir = 0; dir < 2; ++dir) {
         StockPlan& p = out[dir];
         memset(&p, 0, sizeof p);
-        const std::vector<int> r = sk_order(best, dir == 1);
+        // symmetric spectrum-side stage (mirror pairs in registers instead of a pair phase): pays only for the largest
+        // real transforms (N = 16384 float: 0.57 -> 0.67; below, the two butterflies per work item cost occupancy and,
+        // for small n/R, the coalescing of the stores: N = 96 .. 12000 measured 0.06 - 0.58 against 0.52 - 0.67)
+        const bool sym = real && (size_t)n * esz >= 64 * 1024;
+        const std::vector<int> r = sk_order(best, dir == 1, sym);
         p.n = n; p.ns = (int)r.size(); p.G = G; p.C = threads; p.P = P;
         int Ns = 1, img = n, prevpad = 0, ctab = 0;
         // what is left of LDS after two unpadded images, ~n/6 twiddles and slack; the pair-pass table (real) stays
@@ -183,6 +196,10 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
             Ns *= R;
         }
         p.ctab = ctab;
+        {   // symmetric spectrum-side stage of real transforms: last stage forward, first stage backward
+            const int nbs = n / r[dir == 1 ? 0 : p.ns - 1];
+            p.sym = sym ? 1 : 0; p.sym_items = (nbs + 1) / 2; p.m_sym = sk_magic(p.sym_items);
+        }
         p.m_n4 = sk_magic(n / 4); p.m_per = sk_magic(n / 2 + 1); p.m_nchk = sk_magic(nchk);
         // internal-layout image: 32-scalar blocks padded to 36 (float) / 34 (double) scalars, unpadded if that
         // alone would push the two images out of LDS
