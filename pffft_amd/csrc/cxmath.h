@@ -140,6 +140,46 @@ template <int DIR, typename V> __device__ __forceinline__ void dft16(V (&a)[16])
 
 template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a)[R]);
 
+// in-place radix-32, natural-order output: four interleaved radix-8 transforms, constant twiddles W32^(q0 k1),
+// eight radix-4 transforms across them
+template <int DIR, typename V> __device__ __forceinline__ void dft32(V (&a)[32]) {
+    typedef sc<V> T;
+    // cos / sin of 2 pi m / 32, m = 0 .. 8 (one octant + 1; the other angles by symmetry)
+    constexpr long double C32[9] = {1.0L, 0.98078528040323044912618223613424L, 0.92387953251128675612818318939679L,
+                                    0.83146961230254523707878837761791L, 0.70710678118654752440084436210485L,
+                                    0.55557023301960222474283081394853L, 0.38268343236508977172845998403040L,
+                                    0.19509032201612826784828486847702L, 0.0L};
+    V b[4][8];
+#pragma unroll
+    for (int q0 = 0; q0 < 4; ++q0) {
+        V t[8];
+#pragma unroll
+        for (int q1 = 0; q1 < 8; ++q1) t[q1] = a[4 * q1 + q0];
+        dft8<DIR>(t);
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) {
+            const int m = q0 * k1;   // 0 .. 21: W32^m = exp(-2 pi i m / 32)
+            if (m == 0) { b[q0][k1] = t[k1]; continue; }
+            // cos(2 pi m/32) and sin(2 pi m/32) from the first-octant table
+            const int mm = m % 32;
+            const int r = mm % 8, oct = mm / 8;   // angle = oct * 90deg/... (8 steps = 90 degrees)
+            const T c0 = (T)C32[r], s0 = (T)C32[8 - r];   // cos, sin of r * (2 pi / 32)
+            T cs, sn;
+            if (oct == 0) { cs = c0; sn = s0; }
+            else if (oct == 1) { cs = -s0; sn = c0; }
+            else if (oct == 2) { cs = -c0; sn = -s0; }
+            else { cs = s0; sn = -c0; }
+            b[q0][k1] = twmul<DIR>(t[k1], mk<T>(cs, -sn));
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+        dft4<DIR>(b[0][k1], b[1][k1], b[2][k1], b[3][k1]);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) a[k1 + 8 * k2] = b[k2][k1];
+    }
+}
+
 // Radix P*Q with coprime P, Q as a P x Q two-dimensional DFT (Good-Thomas index maps): no twiddles between
 // the two passes, the input / output permutations are compile-time register renamings.
 //   input  i(a, b)   = (Q a + P b) mod R        output k(ka, kb) = (ka Q (Q^-1 mod P) + kb P (P^-1 mod Q)) mod R
@@ -181,6 +221,7 @@ template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a
     else if constexpr (R == 12) dft_pfa<4, 3, DIR>(a);
     else if constexpr (R == 15) dft_pfa<3, 5, DIR>(a);
     else if constexpr (R == 16) dft16<DIR>(a);
+    else if constexpr (R == 32) dft32<DIR>(a);
 }
 
 // 16-byte (float) / 32-byte (double) global access unit: 4 scalars

@@ -146,6 +146,23 @@ __device__ __forceinline__ void sk_stage(const StockStage& st, const SkArgs<T>& 
             if (a.twmode == 0) {
 #pragma unroll
                 for (int q = 1; q < R; ++q) v[q] = cmul(v[q], a.lds[a.tab_off + tpad(q * k)]);
+            } else if constexpr (R > 16) {
+                // radix 32: w^q = (w^4)^(q div 4) w^(q mod 4), five live values instead of R
+                CX p1;
+                if (a.twmode == 2) p1 = a.lds[a.tab_off + st.tw_off + jm];
+                else { p1 = a.twg[k]; asm volatile(""); }
+                const CX w2 = cmul(p1, p1), w3 = cmul(w2, p1), w4 = cmul(w2, w2);
+                CX blk = w4;
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    const int aa = q >> 2, b = q & 3;
+                    const CX wb = b == 1 ? p1 : (b == 2 ? w2 : w3);
+                    CX t;
+                    if (aa == 0) t = wb;
+                    else t = b == 0 ? blk : cmul(blk, wb);
+                    v[q] = cmul(v[q], t);
+                    if (aa >= 1 && b == 3) blk = cmul(blk, w4);
+                }
             } else {
                 CX p[R < 4 ? 4 : R];
                 // (the empty asm keeps the two loads in separate blocks: merged into one load through a selected
@@ -396,6 +413,7 @@ __device__ __forceinline__ void sk_run(const StockStage& st, const SkArgs<T>& a)
         default:
             if constexpr (sizeof(T) == 4) {  // double stops at radix 12 (register budget)
                 if (st.R == 15) sk_stage<T, 15, SRC, DST>(st, a);
+                else if (st.R == 32) sk_stage<T, 32, SRC, DST>(st, a);
                 else sk_stage<T, 16, SRC, DST>(st, a);
             }
             break;

@@ -134,6 +134,15 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
     static const std::vector<int> setd = {12, 10, 8, 6, 5, 4, 3};
     std::vector<int> cur, best;
     sk_search(n, 0, is_double ? setd : setf, cur, best);
+    if (!is_double && !real && n >= 8192 && best.size() > 3) {
+        // radix 32 (64 registers per butterfly) where it saves a whole stage: n = 8192 -> 16 16 32 (complex float
+        // 0.64-0.68 -> 0.69-0.72).  Not for real transforms: next to the two-butterfly symmetric stage it spills
+        // (N = 16384 real: 0.68 -> 0.50), and n = 4608 measured 0.52-0.57 against 0.59-0.65
+        static const std::vector<int> setf32 = {32, 16, 15, 12, 10, 8, 6, 5, 4, 3};
+        std::vector<int> cur2, best2;
+        sk_search(n, 0, setf32, cur2, best2);
+        if (!best2.empty() && best2.size() < best.size()) best = best2;
+    }
     if (best.size() < 2 || best.size() > SK_MAX_STAGES) return false;
     const int nchk = n * esz / 16;
     // small n: wave-local kernel, 4 wavefronts per workgroup, each owning Gw vectors (<= 4 KiB, or one vector)
