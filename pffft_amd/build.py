@@ -9,7 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpffft_hip.so")
-SOURCES = ["pffft_hip.hip"]
+SOURCES = ["pffft_hip.hip", "stock_ct_f32c_gen.hip", "stock_ct_f32r_gen.hip", "stock_ct_f64c_gen.hip", "stock_ct_f64r_gen.hip"]
+OBJDIR = os.path.join(HERE, "..", "build", "obj")
 
 
 def _deps():
@@ -29,11 +30,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-ffp-contract=off", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
+             "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+    os.makedirs(OBJDIR, exist_ok=True)
+    # one hipcc per translation unit, in parallel (the generated Stockham units hold ~600 kernel instantiations)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + flags + ["-c", "-o", obj, os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC)))
+    objs = []
+    for cmd, obj, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        objs.append(obj)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print(" ".join(link))
+    subprocess.run(link, check=True, cwd=CSRC)
     return LIB
 
 

@@ -20,7 +20,7 @@
 #include "fft_big.h"
 #include "fft_stock.h"
 #include "stock_plan.h"
-#include "stock_plans_gen.h"
+#include "stock_ct.h"
 #include "fft_aux.h"
 
 namespace pf {
