@@ -117,6 +117,15 @@ int pffftd_hip_zreorder_batch(PFFFTD_Setup *, const double *in, double *out, siz
 int pffftd_hip_zconvolve_batch(PFFFTD_Setup *, const double *a, const double *b, double *ab, double scaling,
                                size_t batch, int accumulate, int b_broadcast, void *stream);
 
+/* Frequency shift fused into the forward transform (the mixers themselves:
+ * include/pfdsp_hip.h, reference src/pf_mixer.cpp:142-165).  `in` is ONE stream of batch*N interleaved
+ * complex samples; sample g is multiplied by exp(j*(phase_rad + 2*pi*rate*g)) — shift_math_cc's
+ * function with an exactly reduced phase — and every N consecutive shifted samples are forward-
+ * transformed as pffft_hip_transform_batch would (ordered as there).  Complex float setups only.
+ * N = 1024 runs as one kernel (the shift costs no HBM traffic); other N as mixer + in-place transform. */
+int pffft_hip_shift_transform_batch(PFFFT_Setup *, const float *in, float *out, size_t batch, int ordered,
+                                    double rate, double phase_rad, void *stream);
+
 /* Overlap-save FIR on device-resident signal/output (same block schedule as pffastconv_apply,
  * src/pffastconv.c:204-261): returns the number of output samples written, or -1 on error. */
 int pffastconv_hip_apply_device(PFFASTCONV_Setup *, const float *d_input, int inputLen, float *d_output,

@@ -31,7 +31,8 @@ def build(force: bool = False) -> bool:
     """Compile oracle/_ref from /root/reference when the sources are present.
     Returns True when the .so exists afterwards.  On the GPU box /root/reference is
     absent and the prebuilt object shipped with the snapshot is used as is."""
-    if os.path.isdir(os.path.join(REFERENCE_ROOT, "src")) and (force or not os.path.exists(REF_SO)):
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "src")) and (force or not os.path.exists(REF_SO)
+                                                              or not os.path.exists(os.path.join(_HERE, "_ref", "libpfdsp_ref.so"))):
         subprocess.run(["make", "-C", _HERE, f"REF={REFERENCE_ROOT}"], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return os.path.exists(REF_SO)

@@ -85,6 +85,9 @@ def lib():
     L.pffastconv_hip_apply_device.restype = C.c_int
     L.pffastconv_hip_apply_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.pffastconv_simd_size.restype = C.c_int
+    L.pffft_hip_shift_transform_batch.restype = C.c_int
+    L.pffft_hip_shift_transform_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double,
+                                                  C.c_double, C.c_void_p]
     L.pffft_hip_kernel_name.restype = C.c_char_p; L.pffft_hip_kernel_name.argtypes = [C.c_void_p]
     L.pffft_hip_last_error.restype = C.c_char_p
     L.pffft_hip_device_count.restype = C.c_int
@@ -200,6 +203,19 @@ class Setup:
         fn = getattr(self._L, f"{self._pfx}_hip_transform_batch")
         _check(fn(self.handle, x.data_ptr(), out.data_ptr(), batch, direction, int(bool(ordered)), self._stream()),
                "hip_transform_batch")
+        return out
+
+    def shift_transform_batch(self, x, rate, phase_rad=0.0, out=None, ordered=False):
+        """pffft_hip_shift_transform_batch: x is ONE stream of batch*N complex samples; sample g is multiplied by
+        exp(j (phase_rad + 2 pi rate g)) (src/pf_mixer.cpp:142-165) and every N samples are forward-transformed."""
+        import torch
+        assert self.transform_type == COMPLEX and self.dtype == np.float32
+        batch = self._tcheck(x)
+        if out is None:
+            out = torch.empty_like(x)
+        _check(self._L.pffft_hip_shift_transform_batch(self.handle, x.data_ptr(), out.data_ptr(), batch,
+                                                       int(bool(ordered)), float(rate), float(phase_rad), self._stream()),
+               "hip_shift_transform_batch")
         return out
 
     def zreorder_batch(self, x, out=None, direction=FORWARD):

@@ -11,10 +11,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpffft_hip.so")
 SOURCES = ["pffft_hip.hip", "stock_ct_f32c_gen.hip", "stock_ct_f32r_gen.hip", "stock_ct_f64c_gen.hip", "stock_ct_f64r_gen.hip"]
 OBJDIR = os.path.join(HERE, "..", "build", "obj")
+# the PFDSP mixers are their own library, like the reference's PFDSP target (CMakeLists.txt:206)
+DSP_LIB = os.path.join(HERE, "libpfdsp_hip.so")
+DSP_SRC = os.path.join(CSRC, "pfdsp_hip.hip")
+DSP_DEPS = [DSP_SRC, os.path.join(CSRC, "pfdsp_mix.h"), os.path.join(HERE, "..", "include", "pfdsp_hip.h")]
 
 
 def _deps():
-    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "pfdsp_hip.hip"]
     out.append(os.path.join(HERE, "..", "include", "pffft_hip.h"))
     return out
 
@@ -26,7 +30,19 @@ def needs_build() -> bool:
     return any(os.path.getmtime(f) > t for f in _deps())
 
 
+def _build_dsp(force: bool, verbose: bool) -> None:
+    if not force and os.path.exists(DSP_LIB) and all(os.path.getmtime(f) <= os.path.getmtime(DSP_LIB) for f in DSP_DEPS):
+        return
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
+           "-shared", "-o", DSP_LIB, DSP_SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    _build_dsp(force, verbose)
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

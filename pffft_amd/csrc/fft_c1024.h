@@ -59,9 +59,27 @@ __device__ __forceinline__ void c1024_load(C1024V4 (&raw)[8], const float* in, s
 }
 
 // part A: consume the 8 loaded float4, S1, write the X1 image.  After it `raw` is dead.
-template <int DIR, int IN_INTERNAL>
+// MIX (forward, canonical input only): the batch is one stream of samples that is frequency-shifted before the
+// transform, x'[g] = x[g] exp(j 2 pi (phase0 + step g)), g = 1024 t + 128 j + 2L + e (the mixer
+// fused into the load stage).  The phasor factors into  F(t) * G[j] * R[L,e]:  R does not depend on j, commutes
+// with the radix-8 over j and is folded into the S1 twiddles (w1 *= R, plus `r0` for the k1 = 0 output);
+// G[j] = exp(j 2 pi step 128 j) is a kernel argument (scalar registers); F(t) is one sincos per transform.
+struct C1024Mix {
+    double step;       // turns per sample
+    double phase0;     // turns at sample 0 of the batch
+    float g[7][2];     // G[1..7], computed in double on the host
+};
+
+struct C1024NoMix {};
+template <int MIX> struct C1024MixArg { typedef C1024NoMix type; };
+template <> struct C1024MixArg<1> { typedef C1024Mix type; };
+// per-wave state of the fused mixer: R[L,e] (registers, set once) and F(t) (per transform)
+struct C1024MixState { cx<float> r0[2]; cx<float> f0; };
+
+template <int DIR, int IN_INTERNAL, int MIX = 0>
 __device__ __forceinline__ void c1024_part_a(const C1024V4 (&raw)[8], cx<float>* wl, float* wf,
-                                             const cx<float> (&w1)[7][2], int L) {
+                                             const cx<float> (&w1)[7][2], int L,
+                                             const C1024MixState* ms = nullptr, const C1024Mix* mix = nullptr) {
     typedef cx<float> C;
     typedef C1024V4 V4;
     C a[8][2];
@@ -70,6 +88,14 @@ __device__ __forceinline__ void c1024_part_a(const C1024V4 (&raw)[8], cx<float>*
         for (int j = 0; j < 8; ++j) {
             a[j][0] = mk<float>(raw[j].x, raw[j].y);
             a[j][1] = mk<float>(raw[j].z, raw[j].w);
+        }
+        if (MIX) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const C fj = j == 0 ? ms->f0 : cmul(ms->f0, mk<float>(mix->g[j - 1][0], mix->g[j - 1][1]));
+                a[j][0] = cmul(a[j][0], fj);
+                a[j][1] = cmul(a[j][1], fj);
+            }
         }
     } else {
         // X0: the internal layout arrives in linear order; scatter into re/im planes, read back canonical
@@ -96,7 +122,7 @@ __device__ __forceinline__ void c1024_part_a(const C1024V4 (&raw)[8], cx<float>*
 #pragma unroll
         for (int j = 0; j < 8; ++j) b[j] = a[j][e];
         dft8<DIR>(b);
-        a[0][e] = b[0];
+        if (MIX) a[0][e] = cmul(b[0], ms->r0[e]); else a[0][e] = b[0];
 #pragma unroll
         for (int k1 = 1; k1 < 8; ++k1) a[k1][e] = twmul<DIR>(b[k1], w1[k1 - 1][e]);
     }
@@ -201,10 +227,19 @@ __device__ __forceinline__ void c1024_load_twiddles(const cx<float>* __restrict_
 
 // ---- dynamic in-order distribution + prefetch (default) ----
 // ctr[0] = next group of 8 transforms, ctr[1] = workgroups finished (the last one re-arms both)
-template <int DIR, int IN_INTERNAL, int OUT_INTERNAL>
-__global__ void __launch_bounds__(C1024_WAVES * 64, 2)
-fft_c1024_f32_dyn_kernel(const float* in, float* out, unsigned batch, const cx<float>* __restrict__ twg,
-                         unsigned* ctr) {
+// exp(j 2 pi frac(turns)): the reduction in double, the residue of the float conversion as a first-order rotation
+__device__ __forceinline__ cx<float> c1024_unit(double turns) {
+    turns -= rint(turns);
+    const float th = (float)turns;
+    const float d = 6.28318530717958647692f * (float)(turns - (double)th);
+    float sn, cs;
+    sincospif(2.0f * th, &sn, &cs);
+    return mk<float>(cs - sn * d, sn + cs * d);
+}
+
+template <int DIR, int IN_INTERNAL, int OUT_INTERNAL, int MIX>
+__device__ __forceinline__ void c1024_dyn_body(const float* in, float* out, unsigned batch, const cx<float>* __restrict__ twg,
+                                               unsigned* ctr, const typename C1024MixArg<MIX>::type& mix) {
     typedef cx<float> C;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
@@ -215,6 +250,15 @@ fft_c1024_f32_dyn_kernel(const float* in, float* out, unsigned batch, const cx<f
 
     C w1[7][2], w2[15];
     c1024_load_twiddles(twg, L, w1, w2);
+    C1024MixState ms;
+    if constexpr (MIX != 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            ms.r0[e] = c1024_unit(mix.step * (double)(2 * L + e));
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) w1[k1 - 1][e] = cmul(w1[k1 - 1][e], ms.r0[e]);
+        }
+    }
     unsigned pend = 0;
     if (threadIdx.x == 0) {
         s_next[0] = atomicAdd(&ctr[0], 1u);
@@ -235,7 +279,12 @@ fft_c1024_f32_dyn_kernel(const float* in, float* out, unsigned batch, const cx<f
         }
         const size_t t = (size_t)g * C1024_WAVES + wave;
         const bool active = t < batch;  // wave-uniform
-        c1024_part_a<DIR, IN_INTERNAL>(raw, wl, wf, w1, L);
+        if constexpr (MIX != 0) {
+            ms.f0 = c1024_unit(mix.phase0 + mix.step * (double)(1024ull * (unsigned long long)(active ? t : 0)));
+            c1024_part_a<DIR, IN_INTERNAL, 1>(raw, wl, wf, w1, L, &ms, &mix);
+        } else {
+            c1024_part_a<DIR, IN_INTERNAL>(raw, wl, wf, w1, L);
+        }
         __syncthreads();
         const unsigned gn = s_next[(it + 1) & 1];
         const size_t tn = (size_t)gn * C1024_WAVES + wave;
@@ -248,6 +297,21 @@ fft_c1024_f32_dyn_kernel(const float* in, float* out, unsigned batch, const cx<f
         unsigned d = atomicAdd(&ctr[1], 1u);
         if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
     }
+}
+
+template <int DIR, int IN_INTERNAL, int OUT_INTERNAL>
+__global__ void __launch_bounds__(C1024_WAVES * 64, 2)
+fft_c1024_f32_dyn_kernel(const float* in, float* out, unsigned batch, const cx<float>* __restrict__ twg,
+                         unsigned* ctr) {
+    c1024_dyn_body<DIR, IN_INTERNAL, OUT_INTERNAL, 0>(in, out, batch, twg, ctr, C1024NoMix());
+}
+
+// forward transform of the frequency-shifted stream (C1024Mix above)
+template <int OUT_INTERNAL>
+__global__ void __launch_bounds__(C1024_WAVES * 64, 2)
+fft_c1024_f32_mix_kernel(const float* in, float* out, unsigned batch, const cx<float>* __restrict__ twg,
+                         unsigned* ctr, C1024Mix mix) {
+    c1024_dyn_body<FWD, 0, OUT_INTERNAL, 1>(in, out, batch, twg, ctr, mix);
 }
 
 // ---- static persistent assignment (variant 2, kept for A/B measurements) ----

@@ -22,6 +22,7 @@
 #include "stock_plan.h"
 #include "stock_ct.h"
 #include "fft_aux.h"
+#include "pfdsp_mix.h"
 
 namespace pf {
 
@@ -382,6 +383,43 @@ static int launch_c1024(Setup* s, const float* in, float* out, size_t batch, int
     return 0;
 }
 
+// forward transform of the frequency-shifted stream (fused mixer, fft_c1024.h C1024Mix)
+static int launch_c1024_mix(Setup* s, const float* in, float* out, size_t batch, int ordered, double step_turns,
+                            double phase_turns, hipStream_t st) {
+    const unsigned wgs_needed = (unsigned)((batch + C1024_WAVES - 1) / C1024_WAVES);
+    unsigned grid = (unsigned)num_cus();
+    if (grid > wgs_needed) grid = wgs_needed;
+    const dim3 blk(C1024_WAVES * 64);
+    const size_t lds = C1024_LDS_BYTES;
+    const cx<float>* tw = (const cx<float>*)s->d_tw;
+    const unsigned b = (unsigned)batch;
+    unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    C1024Mix mix;
+    step_turns -= std::rint(step_turns);
+    phase_turns -= std::rint(phase_turns);
+    mix.step = step_turns;
+    mix.phase0 = phase_turns;
+    for (int j = 1; j < 8; ++j) {
+        double a = step_turns * 128.0 * j;
+        a -= std::rint(a);
+        mix.g[j - 1][0] = (float)std::cos(pfmix::MIX_TWO_PI * a);
+        mix.g[j - 1][1] = (float)std::sin(pfmix::MIX_TWO_PI * a);
+    }
+    if (ordered) {
+        auto k = fft_c1024_f32_mix_kernel<0>;
+        int rc = allow_big_lds(k, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), blk, lds, st, in, out, b, tw, ctr, mix);
+    } else {
+        auto k = fft_c1024_f32_mix_kernel<1>;
+        int rc = allow_big_lds(k, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), blk, lds, st, in, out, b, tw, ctr, mix);
+    }
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 struct TiledEntry {
     void (*fn)(const T*, T*, unsigned, int, const cx<T>*, const cx<T>*, unsigned*);
@@ -606,6 +644,29 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
     if (s->sk_ok && ((s->kernel == K_GENERIC && g_variant != 1 && g_variant != 51) || g_variant == 50))
         return launch_stock<T>(s, in, out, batch, dir, ordered, st);
     return launch_generic<T>(s, in, out, batch, dir, ordered, st);
+}
+
+// frequency shift (src/pf_mixer.cpp) immediately followed by the forward FFT, the usual SDR
+// chain.  The batch is ONE stream of batch*N complex samples, sample g gets exp(j (phase_rad + 2 pi rate g)).
+// N = 1024: fused into the load stage of the headline kernel (one pass over HBM); other sizes: mixer kernel
+// into `out`, then the transform in place (two passes).
+static int shift_transform_batch(Setup* s, const float* in, float* out, size_t batch, int ordered, double rate,
+                                 double phase_rad, hipStream_t st) {
+    if (!s || s->magic != MAGIC || s->is_double || s->transform != PFFFT_COMPLEX) {
+        g_last_error = "pffft_hip: shift_transform_batch needs a complex single-precision setup";
+        return (int)hipErrorInvalidHandle;
+    }
+    if (batch == 0) return 0;
+    int rc = ensure_device<float>(s);
+    if (rc) return rc;
+    const double phase_turns = phase_rad / pfmix::MIX_TWO_PI;
+    if (s->kernel == K_C1024_F32 && g_variant != 60 && batch < (1ull << 32))   // variant 60: the two-pass composition (A/B)
+        return launch_c1024_mix(s, in, out, batch, ordered, rate, phase_turns, st);
+    const double S[1][2] = {{std::cos(phase_rad), std::sin(phase_rad)}};
+    rc = pfmix::launch_mix(reinterpret_cast<const float2*>(in), reinterpret_cast<float2*>(out), batch * (size_t)s->N, 1, S,
+                           rate, false, st);
+    if (rc) { g_last_error = pfmix::last_error; return rc; }
+    return transform_batch<float>(s, out, out, batch, PFFFT_FORWARD, ordered, st);
 }
 
 template <typename T>
@@ -871,6 +932,12 @@ struct PFFFTD_Setup : pf::Setup {};
 
 PF_DEFINE_API(pffft, PFFFT_Setup, float, 0, "HIP-gfx950")
 PF_DEFINE_API(pffftd, PFFFTD_Setup, double, 1, "HIP-gfx950")
+
+PF_EXPORT int pffft_hip_shift_transform_batch(PFFFT_Setup* s, const float* in, float* out, size_t batch, int ordered,
+                                              double rate, double phase_rad, void* stream) {
+    return pf::shift_transform_batch(reinterpret_cast<pf::Setup*>(s), in, out, batch, ordered, rate, phase_rad,
+                                     (hipStream_t)stream);
+}
 
 PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
     const pf::Setup* s = static_cast<const pf::Setup*>(setup);
