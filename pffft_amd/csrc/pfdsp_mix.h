@@ -8,13 +8,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <mutex>
 #include <string>
 
 namespace pfmix {
 
 static thread_local std::string last_error;
+static bool mix_force_static() {   // PFDSP_HIP_STATIC=1: never use the streaming kernel (A/B measurements)
+    static const bool v = [] { const char* e = getenv("PFDSP_HIP_STATIC"); return e && e[0] == '1'; }();
+    return v;
+}
 
 static int mix_fail(hipError_t e, const char* what) {
     last_error = std::string("pfdsp mix kernel: ") + what + " failed: " + hipGetErrorString(e);
@@ -32,6 +39,7 @@ struct MixArgs {
     float2 S[8];     // lane phasors
     double step;     // turns per block of LANES samples
     float2 rot1;     // LANES == 1: rotation by one sample (second sample of a pair)
+    float2 rowrot[7];  // streaming kernel: rotation between rows of a wave chunk, exp(j 2 pi step (128 / LANES) r), r = 1..7
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: nontemporal 16-byte accesses
@@ -58,8 +66,10 @@ constexpr int MIX_UNROLL = 4;  // 16-byte accesses per thread: a workgroup strea
 // two samples (16 bytes) per access; mix_single_kernel below takes pointers that are only 8-byte aligned and odd tails
 template <int LANES, bool GEN>
 __global__ void __launch_bounds__(MIX_THREADS)
-mix_pairs_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, unsigned long long npairs, MixArgs a) {
-    const unsigned long long base = (unsigned long long)blockIdx.x * (MIX_THREADS * MIX_UNROLL) + threadIdx.x;
+mix_pairs_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, unsigned long long first,
+                 unsigned long long npairs, MixArgs a) {
+    // `first` is a multiple of 512 pairs, so the lane phasor rule below still holds
+    const unsigned long long base = first + (unsigned long long)blockIdx.x * (MIX_THREADS * MIX_UNROLL) + threadIdx.x;
     // 2p mod LANES depends on the thread only (every other term of p is a multiple of 256): lane phasors once
     const int l0 = (2 * (int)threadIdx.x) % LANES;
     const float2 s0 = a.S[l0], s1 = a.S[LANES == 1 ? 0 : l0 + 1];
@@ -91,6 +101,87 @@ mix_pairs_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, unsigned
     }
 }
 
+// Streaming kernel for long streams: the work distribution of the headline FFT kernel (fft_c1024.h, tools/membench.hip):
+// persistent workgroups of 8 wavefronts pull groups of 8 consecutive 8 KiB chunks from an atomic counter, so the chip
+// sweeps the stream in order (a copy with this pattern: 6.9 TB/s; hardware dispatch order: 5.5-6.0).  A wave moves 8 rows
+// of 1 KiB (one 16-byte access per lane and row); the phase is reduced once per chunk and lane, the other rows follow by
+// constant rotations.  ctr[0] = next group, ctr[1] = workgroups finished (the last one re-arms the pair).
+constexpr int MIX_DYN_WAVES = 8;
+constexpr int MIX_DYN_ROWS = 8;
+constexpr unsigned long long MIX_CHUNK_PAIRS = 64ull * MIX_DYN_ROWS;   // 512 pairs = 1024 samples = 8 KiB
+
+template <int LANES, bool GEN>
+__global__ void __launch_bounds__(MIX_DYN_WAVES * 64)
+mix_dyn_kernel(const f32x4* in, f32x4* out, unsigned nchunks, MixArgs a, unsigned* ctr) {
+    __shared__ unsigned s_next[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l0 = (2 * lane) % LANES;
+    const float2 s0 = a.S[l0], s1 = a.S[LANES == 1 ? 0 : l0 + 1];
+    unsigned pend = 0;
+    if (threadIdx.x == 0) {
+        s_next[0] = atomicAdd(&ctr[0], 1u);
+        pend = atomicAdd(&ctr[0], 1u);
+    }
+    __syncthreads();
+    unsigned g = s_next[0];
+    for (unsigned it = 0; (unsigned long long)g * MIX_DYN_WAVES < nchunks; ++it) {
+        if (threadIdx.x == 0) {   // publish the group of iteration it+1, grab the one of it+2 (latency never exposed)
+            s_next[(it + 1) & 1] = pend;
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        const unsigned long long c = (unsigned long long)g * MIX_DYN_WAVES + wave;
+        if (c < nchunks) {
+            const unsigned long long p0 = c * MIX_CHUNK_PAIRS + lane;
+            f32x4 x[MIX_DYN_ROWS];
+#pragma unroll
+            for (int r = 0; r < MIX_DYN_ROWS; ++r)
+                x[r] = GEN ? f32x4{1.f, 0.f, 1.f, 0.f} : __builtin_nontemporal_load(in + p0 + 64 * r);
+            const float2 rb = rot_of(a.step, (2 * p0) / LANES);
+            const float2 b0 = cmulf(s0, rb);
+            const float2 b1 = LANES == 1 ? cmulf(b0, a.rot1) : cmulf(s1, rb);
+#pragma unroll
+            for (int r = 0; r < MIX_DYN_ROWS; ++r) {
+                const float2 w0 = r ? cmulf(b0, a.rowrot[r - 1]) : b0;
+                const float2 w1 = r ? cmulf(b1, a.rowrot[r - 1]) : b1;
+                const float2 y0 = cmulf(make_float2(x[r].x, x[r].y), w0);
+                const float2 y1 = cmulf(make_float2(x[r].z, x[r].w), w1);
+                __builtin_nontemporal_store(f32x4{y0.x, y0.y, y1.x, y1.y}, out + p0 + 64 * r);
+            }
+        }
+        __syncthreads();
+        g = s_next[(it + 1) & 1];
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned d = atomicAdd(&ctr[1], 1u);
+        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+}
+
+// one ring of {next, done} counter pairs per device, created at the first long stream
+constexpr unsigned MIX_CTR_RING = 1024;
+static unsigned* mix_counters(int* cus_out) {
+    static std::mutex mu;
+    static unsigned* ring[64] = {};
+    static int cus[64] = {};
+    static std::atomic<unsigned> slot{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!ring[dev]) {
+            unsigned* p = nullptr;
+            if (hipMalloc((void**)&p, sizeof(unsigned) * 2 * MIX_CTR_RING) != hipSuccess ||
+                hipMemset(p, 0, sizeof(unsigned) * 2 * MIX_CTR_RING) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            hipDeviceProp_t prop;
+            cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            ring[dev] = p;
+        }
+    }
+    *cus_out = cus[dev];
+    return ring[dev] + 2 * (slot.fetch_add(1) % MIX_CTR_RING);
+}
+
 template <int LANES, bool GEN>
 __global__ void __launch_bounds__(MIX_THREADS)
 mix_single_kernel(const float2* __restrict__ in, float2* __restrict__ out, unsigned long long first,
@@ -109,12 +200,25 @@ static int launch_mix_t(const float2* in, float2* out, size_t n, const MixArgs& 
     size_t done = 0;
     if (aligned && n >= 2) {
         const unsigned long long npairs = n / 2;
-        const unsigned long long per_block = MIX_THREADS * MIX_UNROLL;
-        const unsigned long long blocks = (npairs + per_block - 1) / per_block;
-        if (blocks > 0x7fffffffULL) { last_error = "pfdsp_hip: stream too long for one launch"; return (int)hipErrorInvalidValue; }
-        hipLaunchKernelGGL((mix_pairs_kernel<LANES, GEN>), dim3((unsigned)blocks), dim3(MIX_THREADS), 0, st,
-                           reinterpret_cast<const f32x4*>(in), reinterpret_cast<f32x4*>(out), npairs, a);
-        PFMIX_CHECK(hipGetLastError());
+        unsigned long long first = 0;
+        // long streams (>= 4 rounds of the whole chip): the in-order streaming kernel over the full 8 KiB chunks
+        const unsigned long long nchunks = npairs / MIX_CHUNK_PAIRS;
+        int cus = 0;
+        unsigned* ctr = nullptr;
+        if (!mix_force_static() && nchunks >= 8192 && nchunks < 0xffffffffULL && (ctr = mix_counters(&cus)) != nullptr) {
+            hipLaunchKernelGGL((mix_dyn_kernel<LANES, GEN>), dim3((unsigned)cus), dim3(MIX_DYN_WAVES * 64), 0, st,
+                               reinterpret_cast<const f32x4*>(in), reinterpret_cast<f32x4*>(out), (unsigned)nchunks, a, ctr);
+            PFMIX_CHECK(hipGetLastError());
+            first = nchunks * MIX_CHUNK_PAIRS;
+        }
+        if (first < npairs) {
+            const unsigned long long per_block = MIX_THREADS * MIX_UNROLL;
+            const unsigned long long blocks = (npairs - first + per_block - 1) / per_block;
+            if (blocks > 0x7fffffffULL) { last_error = "pfdsp_hip: stream too long for one launch"; return (int)hipErrorInvalidValue; }
+            hipLaunchKernelGGL((mix_pairs_kernel<LANES, GEN>), dim3((unsigned)blocks), dim3(MIX_THREADS), 0, st,
+                               reinterpret_cast<const f32x4*>(in), reinterpret_cast<f32x4*>(out), first, npairs, a);
+            PFMIX_CHECK(hipGetLastError());
+        }
         done = 2 * (size_t)npairs;
     }
     if (done < n) {
@@ -136,6 +240,11 @@ static int launch_mix(const float2* in, float2* out, size_t n, int lanes, const 
     step_turns -= std::rint(step_turns);
     a.step = step_turns;
     a.rot1 = make_float2((float)std::cos(MIX_TWO_PI * step_turns), (float)std::sin(MIX_TWO_PI * step_turns));
+    for (int r = 1; r < 8; ++r) {
+        double t = step_turns * (128.0 / lanes) * r;
+        t -= std::rint(t);
+        a.rowrot[r - 1] = make_float2((float)std::cos(MIX_TWO_PI * t), (float)std::sin(MIX_TWO_PI * t));
+    }
     switch (lanes * 2 + (gen ? 1 : 0)) {
         case 2: return launch_mix_t<1, false>(in, out, n, a, st);
         case 3: return launch_mix_t<1, true>(in, out, n, a, st);

@@ -72,3 +72,19 @@ def test_pffastconv_program(args):
 def test_examples(prog):
     rc, out = _run(prog)
     assert rc == 0, out[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_mixers_program():
+    """benchmarks/bench_mixers.cpp — the reference's only program over pf_mixer.h — built from its source against
+    libpfdsp_hip.so: the ten benches its source enables (shift_math_cc, gen_recursive_osc_c as signal generator, every
+    in-place algorithm C..J, state structs by value / by pointer) run 1 MSample in 64 Ki blocks through the legacy
+    host-pointer entries.  The program reports rates only (from clock(), i.e. host CPU time: meaningless here); values
+    are checked in tests/test_pfdsp.py."""
+    rc, out = _run("bench_mixers", "65536", "1", timeout=600)
+    assert rc == 0, out[-3000:]
+    for name in ("shift_math_cc", "shift_addfast_inp_c", "shift_unroll_inp_c", "shift_limited_unroll_inp_c",
+                 "shift_limited_unroll_A_sse_inp_c", "shift_limited_unroll_B_sse_inp_c", "shift_limited_unroll_C_sse_inp_c",
+                 "shift_recursive_osc_cc", "shift_recursive_osc_sse_c"):
+        assert f"starting bench of {name}" in out, name
+    assert out.count("processed 0.983040 Msamples") == 10, out[-3000:]

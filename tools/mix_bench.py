@@ -21,6 +21,8 @@ t = timed(lambda: m(x, inplace=True))
 print(f"shift_recursive_osc_inp_c (8 lanes), device pointer, incl. host state math + sync: {t*1e3:8.3f} ms {16*n/t/1e9:8.1f} GB/s")
 del x, y; torch.cuda.empty_cache()
 
+if "mixonly" in sys.argv:
+    sys.exit(0)
 N, batch = 1024, 1 << 20
 s = pa.Setup(N, pa.COMPLEX, np.float32)
 x = torch.rand(batch, 2 * N, device="cuda") * 2 - 1
