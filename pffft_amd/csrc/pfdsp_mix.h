@@ -124,18 +124,31 @@ mix_dyn_kernel(const f32x4* in, f32x4* out, unsigned nchunks, MixArgs a, unsigne
     }
     __syncthreads();
     unsigned g = s_next[0];
+    const unsigned long long lastc = (unsigned long long)nchunks - 1;
+    f32x4 x[MIX_DYN_ROWS];
+    {   // clamped: always a valid address, so the loads are unconditional
+        const unsigned long long c0 = (unsigned long long)g * MIX_DYN_WAVES + wave;
+        const f32x4* src = in + (c0 < lastc ? c0 : lastc) * MIX_CHUNK_PAIRS + lane;
+#pragma unroll
+        for (int r = 0; r < MIX_DYN_ROWS; ++r) x[r] = GEN ? f32x4{1.f, 0.f, 1.f, 0.f} : __builtin_nontemporal_load(src + 64 * r);
+    }
     for (unsigned it = 0; (unsigned long long)g * MIX_DYN_WAVES < nchunks; ++it) {
         if (threadIdx.x == 0) {   // publish the group of iteration it+1, grab the one of it+2 (latency never exposed)
             s_next[(it + 1) & 1] = pend;
             pend = atomicAdd(&ctr[0], 1u);
         }
+        __syncthreads();
+        const unsigned gn = s_next[(it + 1) & 1];
         const unsigned long long c = (unsigned long long)g * MIX_DYN_WAVES + wave;
+        const unsigned long long cn = (unsigned long long)gn * MIX_DYN_WAVES + wave;
+        f32x4 xn[MIX_DYN_ROWS];
+        {   // the next chunk is in flight while this one is rotated and stored
+            const f32x4* src = in + (cn < lastc ? cn : lastc) * MIX_CHUNK_PAIRS + lane;
+#pragma unroll
+            for (int r = 0; r < MIX_DYN_ROWS; ++r) xn[r] = GEN ? f32x4{1.f, 0.f, 1.f, 0.f} : __builtin_nontemporal_load(src + 64 * r);
+        }
         if (c < nchunks) {
             const unsigned long long p0 = c * MIX_CHUNK_PAIRS + lane;
-            f32x4 x[MIX_DYN_ROWS];
-#pragma unroll
-            for (int r = 0; r < MIX_DYN_ROWS; ++r)
-                x[r] = GEN ? f32x4{1.f, 0.f, 1.f, 0.f} : __builtin_nontemporal_load(in + p0 + 64 * r);
             const float2 rb = rot_of(a.step, (2 * p0) / LANES);
             const float2 b0 = cmulf(s0, rb);
             const float2 b1 = LANES == 1 ? cmulf(b0, a.rot1) : cmulf(s1, rb);
@@ -148,8 +161,9 @@ mix_dyn_kernel(const f32x4* in, f32x4* out, unsigned nchunks, MixArgs a, unsigne
                 __builtin_nontemporal_store(f32x4{y0.x, y0.y, y1.x, y1.y}, out + p0 + 64 * r);
             }
         }
-        __syncthreads();
-        g = s_next[(it + 1) & 1];
+#pragma unroll
+        for (int r = 0; r < MIX_DYN_ROWS; ++r) x[r] = xn[r];
+        g = gn;
     }
     if (threadIdx.x == 0) {
         __threadfence();
@@ -206,7 +220,8 @@ static int launch_mix_t(const float2* in, float2* out, size_t n, const MixArgs& 
         int cus = 0;
         unsigned* ctr = nullptr;
         if (!mix_force_static() && nchunks >= 8192 && nchunks < 0xffffffffULL && (ctr = mix_counters(&cus)) != nullptr) {
-            hipLaunchKernelGGL((mix_dyn_kernel<LANES, GEN>), dim3((unsigned)cus), dim3(MIX_DYN_WAVES * 64), 0, st,
+            static const int wgs_per_cu = [] { const char* e = getenv("PFDSP_HIP_WGS"); return e ? atoi(e) : 1; }();
+            hipLaunchKernelGGL((mix_dyn_kernel<LANES, GEN>), dim3((unsigned)(cus * wgs_per_cu)), dim3(MIX_DYN_WAVES * 64), 0, st,
                                reinterpret_cast<const f32x4*>(in), reinterpret_cast<f32x4*>(out), (unsigned)nchunks, a, ctr);
             PFMIX_CHECK(hipGetLastError());
             first = nchunks * MIX_CHUNK_PAIRS;
