@@ -35,11 +35,13 @@ static int mix_fail(hipError_t e, const char* what) {
 
 constexpr double MIX_TWO_PI = 6.28318530717958647692528676655900577;
 
+constexpr int MIX_DYN_ROWS = 8;   // rows of 1 KiB per wave chunk of the streaming kernel
+
 struct MixArgs {
     float2 S[8];     // lane phasors
     double step;     // turns per block of LANES samples
     float2 rot1;     // LANES == 1: rotation by one sample (second sample of a pair)
-    float2 rowrot[7];  // streaming kernel: rotation between rows of a wave chunk, exp(j 2 pi step (128 / LANES) r), r = 1..7
+    float2 rowrot[MIX_DYN_ROWS - 1];  // streaming kernel: rotation between rows of a wave chunk, exp(j 2 pi step (128 / LANES) r), r = 1..7
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: nontemporal 16-byte accesses
@@ -107,7 +109,6 @@ mix_pairs_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, unsigned
 // of 1 KiB (one 16-byte access per lane and row); the phase is reduced once per chunk and lane, the other rows follow by
 // constant rotations.  ctr[0] = next group, ctr[1] = workgroups finished (the last one re-arms the pair).
 constexpr int MIX_DYN_WAVES = 8;
-constexpr int MIX_DYN_ROWS = 8;
 constexpr unsigned long long MIX_CHUNK_PAIRS = 64ull * MIX_DYN_ROWS;   // 512 pairs = 1024 samples = 8 KiB
 
 template <int LANES, bool GEN>
@@ -255,7 +256,7 @@ static int launch_mix(const float2* in, float2* out, size_t n, int lanes, const 
     step_turns -= std::rint(step_turns);
     a.step = step_turns;
     a.rot1 = make_float2((float)std::cos(MIX_TWO_PI * step_turns), (float)std::sin(MIX_TWO_PI * step_turns));
-    for (int r = 1; r < 8; ++r) {
+    for (int r = 1; r < MIX_DYN_ROWS; ++r) {
         double t = step_turns * (128.0 / lanes) * r;
         t -= std::rint(t);
         a.rowrot[r - 1] = make_float2((float)std::cos(MIX_TWO_PI * t), (float)std::sin(MIX_TWO_PI * t));
