@@ -83,6 +83,117 @@ zconvolve_stream_kernel(const T* a, const T* b, T* ab, size_t total, unsigned np
     sch.finish(threadIdx.x == 0);
 }
 
+// ---- zconvolve for long batches: the streaming organisation of the mixer kernel (pfdsp_mix.h) -----------------
+// Persistent workgroups of 8 wavefronts pull groups of 8 consecutive chunks from an atomic counter (grabbed two
+// iterations ahead), a wave moves 8 rows of 64 x 16 bytes of EVERY stream per chunk — every global access is a fully
+// coalesced 1 KiB (float) wave instruction — and the loads of the next chunk are in flight while the current one is
+// multiplied and stored.  In the internal layout 4-scalar re-groups and im-groups alternate, so with one 16-byte unit
+// per lane the two halves of a complex product sit in neighbouring lanes: they are exchanged with DPP quad swaps
+// (even lane: re-group, odd lane: im-group):
+//     P = A*B (own), X = A*B_partner;   even: out = P - P_partner (Re),   odd: out = X + X_partner (Im)
+// q = 16-byte unit index over the whole batch, nq = units per vector (n/2); DC/Nyquist of a real spectrum are the .x
+// of units 0 and 1 of a vector and multiply as reals (src/pffft_priv_impl.h:1626-1629, :1680-1683): out.x = P.x.
+constexpr int ZD_WAVES = 8;
+template <typename T> struct Zd {
+    static constexpr int ROWS = sizeof(T) == 4 ? 8 : 4;      // 8 KiB of every stream per wave chunk in both precisions
+    static constexpr unsigned CHUNK = 64 * ROWS;             // units per wave chunk
+};
+
+template <typename T> __device__ __forceinline__ T dpp_swap1(T v);
+template <> __device__ __forceinline__ float dpp_swap1<float>(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+template <> __device__ __forceinline__ double dpp_swap1<double>(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, 0xB1, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), 0xB1, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename T> __device__ __forceinline__ vec4<T> dpp_swap(vec4<T> v) {
+    vec4<T> o; o.x = dpp_swap1<T>(v.x); o.y = dpp_swap1<T>(v.y); o.z = dpp_swap1<T>(v.z); o.w = dpp_swap1<T>(v.w);
+    return o;
+}
+
+template <typename T, int ACC, int BCAST>
+__global__ void __launch_bounds__(ZD_WAVES * 64)
+zconvolve_dyn_kernel(const T* a, const T* b, T* ab, unsigned long long Q, unsigned nq, int is_real, T scaling, unsigned* ctr) {
+    typedef vec4<T> V;
+    constexpr int ZD_ROWS = Zd<T>::ROWS;
+    constexpr unsigned ZD_CHUNK = Zd<T>::CHUNK;
+    __shared__ unsigned s_next[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool odd = lane & 1;
+    const V* a4 = reinterpret_cast<const V*>(a);
+    const V* b4 = reinterpret_cast<const V*>(b);
+    V* c4 = reinterpret_cast<V*>(ab);
+    const unsigned long long nchunks = (Q + ZD_CHUNK - 1) / ZD_CHUNK;
+    const bool need_rem = BCAST || is_real;
+    unsigned pend = 0;
+    if (threadIdx.x == 0) {
+        s_next[0] = atomicAdd(&ctr[0], 1u);
+        pend = atomicAdd(&ctr[0], 1u);
+    }
+    __syncthreads();
+    unsigned g = s_next[0];
+    V xa[ZD_ROWS], xb[ZD_ROWS], xc[ZD_ROWS];
+    unsigned rem[ZD_ROWS];
+    // all loads of one chunk; indices clamped to the last unit so that they are unconditional
+    auto load_chunk = [&](unsigned long long c, V (&la)[ZD_ROWS], V (&lb)[ZD_ROWS], V (&lc)[ZD_ROWS], unsigned (&lr)[ZD_ROWS]) {
+        if (c >= nchunks) c = nchunks - 1;
+        const unsigned long long q0 = c * ZD_CHUNK + lane;
+        unsigned r0 = 0;
+        if (need_rem) r0 = (unsigned)((c * ZD_CHUNK) % nq);          // wave-uniform, once per chunk
+#pragma unroll
+        for (int r = 0; r < ZD_ROWS; ++r) {
+            unsigned long long q = q0 + 64 * r;
+            if (q >= Q) q = Q - 1;
+            unsigned x = 0;
+            if (need_rem) x = (r0 + (unsigned)(64 * r + lane)) % nq;   // 32-bit
+            lr[r] = x;
+            la[r] = __builtin_nontemporal_load(a4 + q);
+            lb[r] = BCAST ? b4[x] : __builtin_nontemporal_load(b4 + q);
+            if (ACC) lc[r] = __builtin_nontemporal_load(c4 + q);
+        }
+    };
+    load_chunk((unsigned long long)g * ZD_WAVES + wave, xa, xb, xc, rem);
+    for (unsigned it = 0; (unsigned long long)g * ZD_WAVES < nchunks; ++it) {
+        if (threadIdx.x == 0) {
+            s_next[(it + 1) & 1] = pend;
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        __syncthreads();
+        const unsigned gn = s_next[(it + 1) & 1];
+        const unsigned long long c = (unsigned long long)g * ZD_WAVES + wave;
+        V na[ZD_ROWS], nb[ZD_ROWS], nc[ZD_ROWS];
+        unsigned nrem[ZD_ROWS];
+        load_chunk((unsigned long long)gn * ZD_WAVES + wave, na, nb, nc, nrem);
+        if (c < nchunks) {
+            const unsigned long long q0 = c * ZD_CHUNK + lane;
+#pragma unroll
+            for (int r = 0; r < ZD_ROWS; ++r) {
+                const V A = xa[r], B = xb[r];
+                const V Bp = dpp_swap<T>(B);
+                const V P = A * B, X = A * Bp;
+                const V S = odd ? P : X;            // what the partner needs
+                const V R = dpp_swap<T>(S);
+                V o = odd ? X + R : P - R;
+                if (is_real && rem[r] < 2) o.x = P.x;
+                if (ACC) o = xc[r] + o * scaling; else o = o * scaling;
+                const unsigned long long q = q0 + 64 * r;
+                if (q < Q) __builtin_nontemporal_store(o, c4 + q);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ZD_ROWS; ++r) { xa[r] = na[r]; xb[r] = nb[r]; if (ACC) xc[r] = nc[r]; rem[r] = nrem[r]; }
+        g = gn;
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned d = atomicAdd(&ctr[1], 1u);
+        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+}
+
 // zreorder through the padded block image: G vectors per pass.  to_canonical: internal -> canonical (PFFFT_FORWARD).
 constexpr int ZR_THREADS = 256;
 template <typename T>

@@ -723,6 +723,25 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
     // float: streaming kernel, two pairs per thread with all loads issued first (fft_aux.h): 0.69-0.70 against 0.65-0.70
     // for the grid-stride kernel, which stays for double (0.65 vs 0.41) and as variant 60; in-order chunks (variant 42)
     // measured 0.57-0.60
+    // long batches (>= 64 MiB per stream): in-order streaming kernel with DPP pair exchange (fft_aux.h); variant 61 = off
+    {
+        const unsigned long long Q = 2ull * total;
+        if (g_variant != 60 && g_variant != 61 && g_variant != 42 && Q / Zd<T>::CHUNK >= 8192u &&
+            Q / Zd<T>::CHUNK < 0xffffffffull) {
+            int rc = ensure_device<T>(s);
+            if (rc) return rc;
+            unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+            const int real = s->transform == PFFFT_REAL;
+            const dim3 grid((unsigned)num_cus()), blk(ZD_WAVES * 64);
+            const unsigned nq = (unsigned)(s->n / 2);
+#define PF_ZD(ACC, BC) hipLaunchKernelGGL((zconvolve_dyn_kernel<T, ACC, BC>), grid, blk, 0, st, a, b, ab, Q, nq, real, scaling, ctr)
+            if (accumulate) { if (b_broadcast) PF_ZD(1, 1); else PF_ZD(1, 0); }
+            else { if (b_broadcast) PF_ZD(0, 1); else PF_ZD(0, 0); }
+#undef PF_ZD
+            PF_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     if (g_variant != 60 && sizeof(T) == 4) {
         int rc = ensure_device<T>(s);
         if (rc) return rc;

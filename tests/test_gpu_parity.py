@@ -447,3 +447,44 @@ def test_spectrum_helpers_paths(ref, variant):
                 s.close(); rs.close()
     finally:
         pa.set_variant(0)
+
+
+@pytest.mark.parametrize("dt,N,tr", [("f32", 1024, 1), ("f32", 96, 1), ("f32", 2048, 0), ("f32", 32, 0), ("f64", 1024, 1),
+                                     ("f64", 96, 0)])
+def test_zconvolve_long_batches(ref, dt, N, tr):
+    """zconvolve on batches long enough (> 64 MiB per stream) for the in-order streaming kernel with the DPP pair
+    exchange (fft_aux.h zconvolve_dyn_kernel): accumulate / no_accu, one b per vector / one b for all (the FIR case,
+    src/pffastconv.c:238), ragged last chunk, aliased output — against the reference on sampled vectors and,
+    bit for bit, against the grid-stride kernel (variant 60) on the whole batch."""
+    dtype = _dt(dt)
+    rs, s = ref.setup(N, tr, dtype), pa.Setup(N, tr, dtype)
+    vb = s.vec_scalars * np.dtype(dtype).itemsize
+    batch = (68 << 20) // vb + 3
+    g = torch.Generator(device="cuda").manual_seed(N)
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    a = torch.rand(batch, s.vec_scalars, device="cuda", dtype=tdt, generator=g) * 2 - 1
+    b = torch.rand(batch, s.vec_scalars, device="cuda", dtype=tdt, generator=g) * 2 - 1
+    c0 = torch.rand(batch, s.vec_scalars, device="cuda", dtype=tdt, generator=g) * 2 - 1
+    sel = [0, 1, batch // 3, batch - 2, batch - 1]
+    ah, bh, ch = a[sel].cpu().numpy(), b[sel].cpu().numpy(), c0[sel].cpu().numpy()
+    for acc in (True, False):
+        for bc in (False, True):
+            bb = b[:1].contiguous() if bc else b
+            got = s.zconvolve_batch(a, bb, c0.clone(), 0.37, accumulate=acc, b_broadcast=bc)
+            pa.set_variant(60)
+            try:
+                want_all = s.zconvolve_batch(a, bb, c0.clone(), 0.37, accumulate=acc, b_broadcast=bc)
+            finally:
+                pa.set_variant(0)
+            # same products, same order of operations: identical up to the contraction-free rounding of both kernels
+            assert torch.allclose(got, want_all, rtol=0, atol=(1e-6 if dt == "f32" else 1e-14)), (acc, bc)
+            gh = got[sel].cpu().numpy()
+            for k, i in enumerate(sel):
+                want = rs.zconvolve(ah[k], bh[0] if bc else bh[k], ch[k], 0.37, acc)
+                assert relerr(gh[k], want) <= tol_for(dt, N), (dt, N, tr, acc, bc, i)
+    # output aliased with an input (include/pffft/pffft.h:194)
+    a2 = a.clone()
+    s.zconvolve_batch(a2, b, a2, 0.5, accumulate=False)
+    want = rs.zconvolve(ah[2], bh[2], np.zeros_like(ah[2]), 0.5, False)
+    assert relerr(a2[sel[2]].cpu().numpy(), want) <= tol_for(dt, N)
+    s.close(); rs.close()
