@@ -179,6 +179,17 @@ def main():
             extras[name + "_Mtps"] = round(batch / ts / 1e6, 2)
         ts = t_of(lambda: y.copy_(x))
         extras["torch_copy_GBps"] = round(batch * BYTES_PER_TRANSFORM / ts / 1e9, 1)
+        # the PFDSP mixer fused into the load stage of the same transform, and the mixer alone
+        ts = t_of(lambda: setup.shift_transform_batch(x, 0.0137, 0.4, out=y, ordered=False))
+        extras["shift_fused_fwd_Mtps"] = round(batch / ts / 1e6, 2)
+        try:
+            from pffft_amd import pfdsp
+            xc, yc = x.view(torch.complex64).reshape(-1), y.view(torch.complex64).reshape(-1)
+            ts = t_of(lambda: pfdsp.shift_device(xc, 0.0137, 0.4, out=yc))
+            extras["mixer_GBps"] = round(xc.numel() * 16 / ts / 1e9, 1)
+        except Exception as e:  # the mixer library is its own .so; its absence must not hide the headline
+            extras["mixer_GBps"] = None
+            extras["mixer_error"] = str(e)[:200]
 
     if rank == 0:
         tps = total * args.steps / elapsed

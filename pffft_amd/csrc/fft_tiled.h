@@ -660,6 +660,29 @@ struct TiledAltF32 {
     typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 0, 256, 4> C4096;
     typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 0, 512, 4> C8192;
 };
+// Double-precision alternatives measured against TiledPick<double> (tools/c5_ab.py, variants 70 / 71 / 72):
+//   A: one base twiddle per butterfly in registers, powers recomputed (no LDS twiddle table)
+//   B: LDS table + register prefetch of the next vector          C: both
+// n = 1024 (BASELINE configs[4], fraction of 8 TB/s, fwd internal / bwd internal / fwd canonical / bwd canonical):
+//   pick 0.70 / 0.72 / 0.71 / 0.72,  A 0.75 / 0.75 / 0.76 / 0.76,  B 0.77 / 0.78 / 0.80 / 0.80,  C 0.82 / 0.80 / 0.79 / 0.79
+//   real N = 2048: pick 0.63 / 0.62 / 0.70 / 0.63,  A 0.70 / 0.68 / 0.73 / 0.71,  B 0.60 / 0.73 / 0.74 / 0.76,  C 0.57 / 0.75 / 0.69 / 0.78
+// n = 512: complex pick 0.73-0.77, C 0.80-0.82; real N = 1024 backward pick 0.66-0.68, C 0.81-0.83
+// n = 256 / 128: the gains are in the real backward transforms (N = 512: 0.58-0.64 -> 0.77-0.81, N = 256: 0.62-0.64 -> 0.78-0.80)
+// The launcher's table (pffft_hip.hip tiled_lookup) picks per size, layout and direction.
+struct TiledAltF64 {
+    typedef TiledCfg<double, 10, 64, 3, 8, 16, 8, 1, 4, 0, 3, 0> A1024;
+    typedef TiledCfg<double, 10, 64, 3, 8, 16, 8, 1, 4, 0, 1, 1> B1024;
+    typedef TiledCfg<double, 10, 64, 3, 8, 16, 8, 1, 4, 0, 3, 1> C1024;
+    typedef TiledCfg<double, 9, 32, 3, 8, 8, 8, 1, 4, 0, 3, 0> A512;
+    typedef TiledCfg<double, 9, 32, 3, 8, 8, 8, 1, 4, 0, 1, 1> B512;
+    typedef TiledCfg<double, 9, 32, 3, 8, 8, 8, 1, 4, 0, 3, 1> C512;
+    typedef TiledCfg<double, 8, 16, 3, 8, 4, 8, 1, 2, 0, 3, 0, 256> A256;
+    typedef TiledCfg<double, 8, 16, 3, 8, 4, 8, 1, 2, 0, 0, 1, 256> B256;
+    typedef TiledCfg<double, 8, 16, 3, 8, 4, 8, 1, 2, 0, 3, 1, 256> C256;
+    typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 3, 0, 256> A128;
+    typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 0, 1, 256> B128;
+    typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 3, 1, 256> C128;
+};
 template <> struct TiledPick<double> {
     typedef TiledCfg<double, 4, 2, 2, 4, 4, 1, 1, 1, 0, 0, 0, 256> C16;
     typedef TiledCfg<double, 5, 4, 3, 4, 2, 4, 1, 1, 0, 0, 0, 256> C32;

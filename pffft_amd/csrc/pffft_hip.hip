@@ -447,6 +447,28 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
             }
         }
     }
+    if constexpr (sizeof(T) == 8) {
+        // alt: 0 = TiledPick, 1 = A (register base twiddles), 2 = B (prefetch), 3 = C (both); fft_tiled.h TiledAltF64
+        int alt = (g_variant >= 70 && g_variant <= 72) ? g_variant - 69 : 0;
+        if (g_variant == 0) {
+            // Selection from tools/c5_ab.py on MI355X (gpurun_out/c5_ab*.log).  Constraint: both layouts of one direction
+            // must share the twiddle arithmetic (A and C recompute powers, pick and B read tables), because
+            // transform_ordered == zreorder(transform) holds bit for bit (benchmarks/bench_pffft.c:343-349).
+            const bool fwd = dir == PFFFT_FORWARD;
+            if (n == 1024) alt = (real && fwd) ? 1 : 3;
+            else if (n == 512) alt = (real && fwd && !ordered) ? 1 : 3;
+            else if (n == 256) alt = !real ? (fwd ? 1 : 3) : (fwd ? 0 : 3);
+            else if (n == 128) alt = (real && !fwd) ? 3 : 0;
+        }
+#define PF_ALT64(N)                                                                   \
+        case N:                                                                       \
+            if (alt == 1) { *e = tiled_entry<T, TiledAltF64::A##N>(dir, real); return true; } \
+            if (alt == 2) { *e = tiled_entry<T, TiledAltF64::B##N>(dir, real); return true; } \
+            if (alt == 3) { *e = tiled_entry<T, TiledAltF64::C##N>(dir, real); return true; } \
+            break;
+        switch (n) { PF_ALT64(128) PF_ALT64(256) PF_ALT64(512) PF_ALT64(1024) }
+#undef PF_ALT64
+    }
     switch (n) {
         case 16: *e = tiled_entry<T, typename TiledPick<T>::C16>(dir, real); return true;
         case 32: *e = tiled_entry<T, typename TiledPick<T>::C32>(dir, real); return true;
