@@ -668,6 +668,7 @@ struct TiledAltF32 {
 //   real N = 2048: pick 0.63 / 0.62 / 0.70 / 0.63,  A 0.70 / 0.68 / 0.73 / 0.71,  B 0.60 / 0.73 / 0.74 / 0.76,  C 0.57 / 0.75 / 0.69 / 0.78
 // n = 512: complex pick 0.73-0.77, C 0.80-0.82; real N = 1024 backward pick 0.66-0.68, C 0.81-0.83
 // n = 256 / 128: the gains are in the real backward transforms (N = 512: 0.58-0.64 -> 0.77-0.81, N = 256: 0.62-0.64 -> 0.78-0.80)
+// n = 2048 / 4096 (were on the Stockham kernel at 0.65-0.73): complex C 0.76-0.80; real N = 4096 A/C 0.70-0.76, N = 8192 forward 0.70-0.73
 // The launcher's table (pffft_hip.hip tiled_lookup) picks per size, layout and direction.
 struct TiledAltF64 {
     typedef TiledCfg<double, 10, 64, 3, 8, 16, 8, 1, 4, 0, 3, 0> A1024;
@@ -679,6 +680,12 @@ struct TiledAltF64 {
     typedef TiledCfg<double, 8, 16, 3, 8, 4, 8, 1, 2, 0, 3, 0, 256> A256;
     typedef TiledCfg<double, 8, 16, 3, 8, 4, 8, 1, 2, 0, 0, 1, 256> B256;
     typedef TiledCfg<double, 8, 16, 3, 8, 4, 8, 1, 2, 0, 3, 1, 256> C256;
+    typedef TiledCfg<double, 11, 128, 4, 8, 4, 8, 8, 4, 0, 3, 0, 256> A2048;
+    typedef TiledCfg<double, 11, 128, 4, 8, 4, 8, 8, 4, 0, 1, 1, 256> B2048;
+    typedef TiledCfg<double, 11, 128, 4, 8, 4, 8, 8, 4, 0, 3, 1, 256> C2048;
+    typedef TiledCfg<double, 12, 256, 4, 8, 8, 8, 8, 4, 0, 3, 0, 256> A4096;
+    typedef TiledCfg<double, 12, 256, 4, 8, 8, 8, 8, 4, 0, 1, 1, 256> B4096;
+    typedef TiledCfg<double, 12, 256, 4, 8, 8, 8, 8, 4, 0, 3, 1, 256> C4096;
     typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 3, 0, 256> A128;
     typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 0, 1, 256> B128;
     typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 3, 1, 256> C128;

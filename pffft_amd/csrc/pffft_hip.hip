@@ -459,6 +459,9 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
             else if (n == 512) alt = (real && fwd && !ordered) ? 1 : 3;
             else if (n == 256) alt = !real ? (fwd ? 1 : 3) : (fwd ? 0 : 3);
             else if (n == 128) alt = (real && !fwd) ? 3 : 0;
+            // 2048 / 4096: these variants beat the Stockham kernel that had taken double >= 2048 over (0.65-0.73 -> 0.70-0.80)
+            else if (n == 2048) alt = (real && fwd && !ordered) ? 1 : 3;
+            else if (n == 4096) alt = !real ? ((!fwd && ordered) ? 1 : 3) : ((fwd && !ordered) ? 1 : 3);
         }
 #define PF_ALT64(N)                                                                   \
         case N:                                                                       \
@@ -466,7 +469,7 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
             if (alt == 2) { *e = tiled_entry<T, TiledAltF64::B##N>(dir, real); return true; } \
             if (alt == 3) { *e = tiled_entry<T, TiledAltF64::C##N>(dir, real); return true; } \
             break;
-        switch (n) { PF_ALT64(128) PF_ALT64(256) PF_ALT64(512) PF_ALT64(1024) }
+        switch (n) { PF_ALT64(128) PF_ALT64(256) PF_ALT64(512) PF_ALT64(1024) PF_ALT64(2048) PF_ALT64(4096) }
 #undef PF_ALT64
     }
     switch (n) {
@@ -651,12 +654,14 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         //   8192: 0.68/0.73 vs 0.62/0.70;  real N = 32: 0.38 vs 0.26, 64: 0.66 vs 0.60, 16384: 0.61-0.68 vs 0.51-0.60 (symmetric spectrum-side stage)
         //   double: complex n = 16: 0.50 vs 0.26, 32: 0.70 vs 0.48, 64: 0.69 vs 0.47, 2048: 0.65 vs 0.53, 4096: 0.73 vs 0.51;
         //   real N = 32: 0.42 vs 0.29, 64: 0.66 vs 0.55, 4096: 0.63 vs 0.45, 8192: 0.67 vs 0.44; a tie from 128 to 1024
+        //   (double n = 2048 / 4096 went back to the tiled family with its TiledAltF64 variants: 0.75-0.80 vs 0.65-0.73;
+        //    only the real backward N = 8192 stays here: 0.70 / 0.73 vs 0.68 / 0.76)
         bool stock = false;
-        if (s->sk_ok && g_variant != 54) {
+        if (s->sk_ok && g_variant != 54 && !(g_variant >= 70 && g_variant <= 72)) {
             const int n = s->n;
             const bool cplx = s->transform == PFFFT_COMPLEX;
             if (sizeof(T) == 4) stock = cplx ? (n <= 64 || (n == 4096 && !ordered) || n == 8192) : (n <= 32 || n == 8192);
-            else stock = cplx ? (n <= 64 || n >= 2048) : (n <= 32 || n >= 2048);
+            else stock = cplx ? (n <= 64 || n >= 8192) : (n <= 32 || n >= 8192 || (n == 4096 && dir == PFFFT_BACKWARD));
         }
         if (!stock) return launch_tiled<T>(s, in, out, batch, dir, ordered, st);
         return launch_stock<T>(s, in, out, batch, dir, ordered, st);
