@@ -67,6 +67,12 @@ static std::mutex g_stage_mu;
 static void* g_stage = nullptr;
 static size_t g_stage_bytes = 0;
 
+// blocks up to ZC_LIMIT on host pointers: CPU memcpy into one pinned host image, the kernel rotates it in place over
+// PCIe, one synchronisation, CPU memcpy out — no DMA copies (same scheme as the legacy FFT entries, pffft_hip.hip)
+constexpr size_t ZC_LIMIT = 256 * 1024;
+static void* g_pinned = nullptr;
+static size_t g_pinned_bytes = 0;
+
 static int legacy_mix(const complexf* in, complexf* out, size_t n, int lanes, const double (*S)[2], double step_turns,
                       bool gen) {
     if (n == 0) return 0;
@@ -74,6 +80,23 @@ static int legacy_mix(const complexf* in, complexf* out, size_t n, int lanes, co
     const bool out_dev = is_device_ptr(out);
     const bool in_dev = gen || is_device_ptr(in);
     std::unique_lock<std::mutex> lk(g_stage_mu, std::defer_lock);
+    static const bool zc_on = [] { const char* e = getenv("PFFFT_HIP_NO_ZEROCOPY"); return !(e && e[0] == '1'); }();
+    if (zc_on && bytes <= ZC_LIMIT && !out_dev && (gen || !is_device_ptr(in))) {
+        lk.lock();
+        if (g_pinned_bytes < bytes) {
+            if (g_pinned) (void)hipHostFree(g_pinned);
+            g_pinned = nullptr; g_pinned_bytes = 0;
+            PD_CHECK(hipHostMalloc(&g_pinned, ZC_LIMIT, hipHostMallocDefault));
+            g_pinned_bytes = ZC_LIMIT;
+        }
+        float2* img = reinterpret_cast<float2*>(g_pinned);
+        if (!gen) memcpy(img, in, bytes);
+        int rc = launch_mix(gen ? nullptr : img, img, n, lanes, S, step_turns, gen, nullptr);
+        if (rc) { g_last_error = pfmix::last_error; return rc; }
+        PD_CHECK(hipStreamSynchronize(nullptr));
+        memcpy(out, img, bytes);
+        return 0;
+    }
     const float2* d_in = reinterpret_cast<const float2*>(in);
     float2* d_out = reinterpret_cast<float2*>(out);
     if (!out_dev || !in_dev) {

@@ -137,6 +137,8 @@ struct Setup {
     size_t big_bytes[2] = {0, 0};
     void* d_stage[3] = {nullptr, nullptr, nullptr};  // staging for host-pointer legacy calls
     size_t stage_bytes[3] = {0, 0, 0};
+    void* h_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned host images the kernels read / write directly (small vectors)
+    size_t hstage_bytes[4] = {0, 0, 0, 0};
 };
 constexpr uint32_t MAGIC = 0x50464654u;  // "PFFT"
 
@@ -227,6 +229,7 @@ static void destroy_setup(Setup* s) {
     for (void* p : s->d_bigtw) if (p) (void)hipFree(p);
     for (void* p : s->d_big) if (p) (void)hipFree(p);
     for (void* p : s->d_stage) if (p) (void)hipFree(p);
+    for (void* p : s->h_stage) if (p) (void)hipHostFree(p);
     s->magic = 0;
     delete s;
 }
@@ -824,6 +827,28 @@ static int stage_buf(Setup* s, int slot, size_t bytes, void** out) {
     return 0;
 }
 
+static int pinned_buf(Setup* s, int slot, size_t bytes, void** out) {
+    if (s->hstage_bytes[slot] < bytes) {
+        if (s->h_stage[slot]) (void)hipHostFree(s->h_stage[slot]);
+        s->h_stage[slot] = nullptr; s->hstage_bytes[slot] = 0;
+        PF_CHECK(hipHostMalloc(&s->h_stage[slot], bytes, hipHostMallocDefault));
+        s->hstage_bytes[slot] = bytes;
+    }
+    *out = s->h_stage[slot];
+    return 0;
+}
+
+// Host-pointer calls on small vectors: no DMA copies at all.  The vector is copied (CPU memcpy, < 1 us) into a pinned host
+// image that the kernel reads over PCIe directly, the kernel writes its result into another pinned image, one stream
+// synchronisation, CPU memcpy out: one launch + one sync per call instead of two synchronous hipMemcpy around them
+// (measured: tools/legacy_bench.py).  Vectors above ZC_LIMIT keep the device staging (kernels there may sweep `out`
+// more than once).  PFFFT_HIP_NO_ZEROCOPY=1 switches it off (A/B).
+constexpr size_t ZC_LIMIT = 256 * 1024;
+static bool zero_copy_enabled() {
+    static const bool v = [] { const char* e = getenv("PFFFT_HIP_NO_ZEROCOPY"); return !(e && e[0] == '1'); }();
+    return v;
+}
+
 // run `fn(d_in..., d_out)` with up to 3 inputs + 1 output vector of `bytes` bytes each
 template <typename T, typename F>
 static int legacy_run(Setup* s, const T* const* ins, int nin, T* out, bool out_is_inout, F&& fn) {
@@ -835,6 +860,32 @@ static int legacy_run(Setup* s, const T* const* ins, int nin, T* out, bool out_i
     // the staging buffers belong to the setup; the mutex keeps concurrent callers correct
     // (the reference allows a setup to be shared between threads, include/pffft/pffft.h:102-105)
     std::lock_guard<std::mutex> lk(s->stage_mu);
+    if (bytes <= ZC_LIMIT && zero_copy_enabled() && s->kernel != K_BIG) {
+        bool any_dev = is_device_ptr(out);
+        for (int i = 0; i < nin && !any_dev; ++i) any_dev = is_device_ptr(ins[i]);
+        if (!any_dev) {
+            const T* h_in[3] = {nullptr, nullptr, nullptr};
+            void* po; int rc = pinned_buf(s, 0, bytes, &po); if (rc) return rc;
+            T* h_out = (T*)po;
+            bool out_loaded = false;
+            if (out_is_inout) { memcpy(h_out, out, bytes); out_loaded = true; }
+            int slot = 1;
+            for (int i = 0; i < nin; ++i) {
+                if (ins[i] == out) { if (!out_loaded) { memcpy(h_out, out, bytes); out_loaded = true; } h_in[i] = h_out; continue; }
+                bool dup = false;
+                for (int j = 0; j < i; ++j) if (ins[j] == ins[i]) { h_in[i] = h_in[j]; dup = true; break; }
+                if (dup) continue;
+                void* p; rc = pinned_buf(s, slot++, bytes, &p); if (rc) return rc;
+                memcpy(p, ins[i], bytes);
+                h_in[i] = (const T*)p;
+            }
+            rc = fn(h_in, h_out);
+            if (rc) return rc;
+            PF_CHECK(hipStreamSynchronize(nullptr));
+            memcpy(out, h_out, bytes);
+            return 0;
+        }
+    }
     const T* d_in[3] = {nullptr, nullptr, nullptr};
     T* d_out = nullptr;
     const bool out_dev = is_device_ptr(out);
