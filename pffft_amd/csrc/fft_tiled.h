@@ -204,7 +204,7 @@ struct Tiled {
 #pragma unroll
             for (int q = 0; q < R; ++q) a[q] = v[u * R + q];
             if constexpr (S > 0 && C::TWMODE == 3) {
-                CX p[R];  // p[q] = w^q, every power at most 4 products away from the table value
+                CX p[R < 16 ? R : 16];  // p[q] = w^q, every power at most 4 products away from the table value
                 p[1] = w.r[C::tw_off(S) + u];
                 // opaque per iteration: otherwise the powers are hoisted out of the persistent loop and
                 // pinned in registers again (which is TWMODE 0 and spills)
@@ -216,7 +216,13 @@ struct Tiled {
                     p[12] = cmul(p[6], p[6]); p[13] = cmul(p[8], p[5]); p[14] = cmul(p[7], p[7]); p[15] = cmul(p[8], p[7]);
                 }
 #pragma unroll
-                for (int q = 1; q < R; ++q) a[q] = twmul<DIR>(a[q], p[q]);
+                for (int q = 1; q < (R < 16 ? R : 16); ++q) a[q] = twmul<DIR>(a[q], p[q]);
+                if constexpr (R > 16) {   // radix 32: w^16 and w^(16+k) = w^16 w^k, five products deep
+                    const CX p16 = cmul(p[8], p[8]);
+                    a[16] = twmul<DIR>(a[16], p16);
+#pragma unroll
+                    for (int q = 1; q < 16; ++q) a[16 + q] = twmul<DIR>(a[16 + q], cmul(p16, p[q]));
+                }
             } else if constexpr (S > 0) {
 #pragma unroll
                 for (int q = 1; q < R; ++q) a[q] = twmul<DIR>(a[q], stage_tw<S>(w, t, u, q, tab));
@@ -689,6 +695,21 @@ struct TiledAltF64 {
     typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 3, 0, 256> A128;
     typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 0, 1, 256> B128;
     typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 3, 1, 256> C128;
+};
+// float n = 64 real forward (N = 128): base twiddle + recomputed powers measured 0.70-0.71 against 0.62-0.65 for the
+// all-in-registers table; for every other float size <= 512 the TiledPick entries won the A/B (variants 73 / 74 of r01:
+// recomputed powers 0.55-0.83, no prefetch 0.59-0.76, pick 0.62-0.83)
+struct TiledAltF32b {
+    typedef TiledCfg<float, 6, 4, 2, 8, 8, 1, 1, 1, 0, 3, 1> A64;
+    // n = 8192 in THREE stages, 16 x 32 x 16 with 32 points per thread: one exchange less than 8 x 8 x 16 x 8 (LDS cycles
+    // of the exchanges 2304 -> 1536, conflict-free with PAD0 = 2, PADN = 0: tools/tiled_lds_search.py); variants 75 / 76
+    typedef TiledCfg<float, 13, 256, 3, 16, 32, 16, 1, 2, 0, 3, 1, 256, 2> T8192;
+    typedef TiledCfg<float, 13, 256, 3, 16, 32, 16, 1, 2, 0, 3, 0, 256, 2> T8192np;
+    // the same idea one and two sizes down: 32 points per thread, three stages (variants 77 prefetch / 78 none)
+    typedef TiledCfg<float, 11, 64, 3, 16, 8, 16, 1, 2, 0, 3, 1> T2048;            // ONE wavefront per transform
+    typedef TiledCfg<float, 11, 64, 3, 16, 8, 16, 1, 2, 0, 3, 0> T2048np;
+    typedef TiledCfg<float, 12, 128, 3, 16, 16, 16, 1, 2, 0, 3, 1, 256, 2> T4096;
+    typedef TiledCfg<float, 12, 128, 3, 16, 16, 16, 1, 2, 0, 3, 0, 256, 2> T4096np;
 };
 template <> struct TiledPick<double> {
     typedef TiledCfg<double, 4, 2, 2, 4, 4, 1, 1, 1, 0, 0, 0, 256> C16;

@@ -442,13 +442,43 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
     if constexpr (sizeof(T) == 4) {
         // the no-prefetch / two-workgroups-per-CU variants only win for canonical-layout real transforms of
         // 8192 points (0.65 vs 0.57 of the roofline, gpurun_out/tiled7.log); everything else prefetches
-        if ((real && ordered && n == 8192 && g_variant != 22) || g_variant == 20) {
+        if ((real && ordered && n == 8192 && dir == PFFFT_BACKWARD && g_variant != 22 && g_variant != 75 && g_variant != 76) || g_variant == 20) {
             switch (n) {
                 case 2048: *e = tiled_entry<T, TiledAltF32::C2048>(dir, real); return true;
                 case 4096: *e = tiled_entry<T, TiledAltF32::C4096>(dir, real); return true;
                 case 8192: *e = tiled_entry<T, TiledAltF32::C8192>(dir, real); return true;
             }
         }
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (n == 64 && real && dir == PFFFT_FORWARD && g_variant == 0) { *e = tiled_entry<T, TiledAltF32b::A64>(dir, real); return true; }
+        // three-stage n = 8192 (tools/c3_ab.py): complex 0.65-0.71 (Stockham) -> 0.71-0.76; real N = 16384 forward 0.57-0.60 -> 0.62
+        if (n == 8192 && g_variant == 0 && (!real || dir == PFFFT_FORWARD)) {
+            if (!real && dir == PFFFT_FORWARD) *e = tiled_entry<T, TiledAltF32b::T8192>(dir, real);
+            else *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real);
+            return true;
+        }
+        // three-stage, 32 points per thread (tools/c3_ab.py, gpurun_out/c3_ab3.log; fraction of 8 TB/s, before -> now):
+        //   N = 2048 complex 0.58-0.72 -> 0.71-0.76 (one wavefront per transform), N = 4096 real 0.58-0.62 -> 0.64-0.66,
+        //   N = 4096 complex 0.62-0.68 -> 0.68-0.77, N = 8192 real 0.53-0.57 -> 0.59-0.69
+        // prefetch where it does not spill (forward transforms into the internal layout do)
+        if (g_variant == 0 && n == 2048) {
+            const bool pf = !real || (dir == PFFFT_BACKWARD && !ordered);
+            *e = pf ? tiled_entry<T, TiledAltF32b::T2048>(dir, real) : tiled_entry<T, TiledAltF32b::T2048np>(dir, real);
+            return true;
+        }
+        if (g_variant == 0 && n == 4096) {
+            const bool pf = dir == PFFFT_BACKWARD || (!real && ordered);
+            *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real);
+            return true;
+        }
+        if (g_variant == 77 || g_variant == 78) {
+            const bool pf = g_variant == 77;
+            if (n == 2048) { *e = pf ? tiled_entry<T, TiledAltF32b::T2048>(dir, real) : tiled_entry<T, TiledAltF32b::T2048np>(dir, real); return true; }
+            if (n == 4096) { *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real); return true; }
+        }
+        if (n == 8192 && g_variant == 75) { *e = tiled_entry<T, TiledAltF32b::T8192>(dir, real); return true; }
+        if (n == 8192 && g_variant == 76) { *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real); return true; }
     }
     if constexpr (sizeof(T) == 8) {
         // alt: 0 = TiledPick, 1 = A (register base twiddles), 2 = B (prefetch), 3 = C (both); fft_tiled.h TiledAltF64
@@ -660,10 +690,10 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         //   (double n = 2048 / 4096 went back to the tiled family with its TiledAltF64 variants: 0.75-0.80 vs 0.65-0.73;
         //    only the real backward N = 8192 stays here: 0.70 / 0.73 vs 0.68 / 0.76)
         bool stock = false;
-        if (s->sk_ok && g_variant != 54 && !(g_variant >= 70 && g_variant <= 72)) {
+        if (s->sk_ok && g_variant != 54 && !(g_variant >= 70 && g_variant <= 78)) {
             const int n = s->n;
             const bool cplx = s->transform == PFFFT_COMPLEX;
-            if (sizeof(T) == 4) stock = cplx ? (n <= 64 || (n == 4096 && !ordered) || n == 8192) : (n <= 32 || n == 8192);
+            if (sizeof(T) == 4) stock = cplx ? (n <= 64) : (n <= 32 || (n == 8192 && dir == PFFFT_BACKWARD));
             else stock = cplx ? (n <= 64 || n >= 8192) : (n <= 32 || n >= 8192 || (n == 4096 && dir == PFFFT_BACKWARD));
         }
         if (!stock) return launch_tiled<T>(s, in, out, batch, dir, ordered, st);

@@ -488,3 +488,25 @@ def test_zconvolve_long_batches(ref, dt, N, tr):
     want = rs.zconvolve(ah[2], bh[2], np.zeros_like(ah[2]), 0.5, False)
     assert relerr(a2[sel[2]].cpu().numpy(), want) <= tol_for(dt, N)
     s.close(); rs.close()
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_ordered_is_reordered_unordered_bit_for_bit(dt):
+    """pffft_transform_ordered == pffft_zreorder(pffft_transform) EXACTLY, both directions, for every power-of-two size
+    and several mixed-radix ones — what the reference's own validation asserts of itself
+    (benchmarks/bench_pffft.c:343-349).  The launcher picks kernels per size, layout and direction: this pins the rule
+    that both layouts of one direction share their arithmetic."""
+    dtype = _dt(dt)
+    for tr in (pa.COMPLEX, pa.REAL):
+        for N in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 96, 480, 2400, 4000, 9216):
+            if dt == "f64" and N * (2 if tr == pa.COMPLEX else 1) * 8 > 128 * 1024:
+                continue
+            s = pa.Setup(N, tr, dtype)
+            x = _dev(np.random.default_rng(N).uniform(-1, 1, (5, s.vec_scalars)).astype(dtype))
+            fu = s.transform_batch(x, None, pa.FORWARD, False)
+            fo = s.transform_batch(x, None, pa.FORWARD, True)
+            assert torch.equal(s.zreorder_batch(fu, None, pa.FORWARD), fo), (dt, tr, N, "forward")
+            bu = s.transform_batch(fu, None, pa.BACKWARD, False)
+            bo = s.transform_batch(fo, None, pa.BACKWARD, True)
+            assert torch.equal(bu, bo), (dt, tr, N, "backward")
+            s.close()
