@@ -171,6 +171,9 @@ __global__ void fastconv_scale_kernel(const float* __restrict__ in, float* __res
 }
 
 // FIR configurations: WG = one block (TPT threads) so that a call with few blocks still spreads over the chip
+// (The three-stage / 32-points-per-thread configurations that won for the plain transforms, fft_tiled.h TiledAltF32b,
+//  were tried here too: with the filter spectrum and both twiddle sets resident they spill ~890 B per lane and the
+//  C4 call goes from 11.4 us to 48 us.  The four-stage ones stay.)
 struct FirCfg {
     typedef TiledCfg<float, 9, 32, 3, 8, 8, 8, 1, 4, 4, 3, 0, 64, 2> C512;
     typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 0, 64, 2> C1024;
