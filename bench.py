@@ -179,6 +179,30 @@ def main():
             extras[name + "_Mtps"] = round(batch / ts / 1e6, 2)
         ts = t_of(lambda: y.copy_(x))
         extras["torch_copy_GBps"] = round(batch * BYTES_PER_TRANSFORM / ts / 1e9, 1)
+        # the other BASELINE.json configs (parity-test cases, reported here as side measurements only): fraction of the
+        # 8 TB/s HBM roofline on algorithmic bytes (2 x vector bytes per transform), and the C4 FIR call time
+        try:
+            del_later = []
+            def side(N, tr, dtype, b):
+                st = pa.Setup(N, tr, dtype)
+                tdt = torch.float32 if dtype == np.float32 else torch.float64
+                xi = torch.rand(b, st.vec_scalars, device=dev, dtype=tdt) * 2 - 1
+                yo = torch.empty_like(xi)
+                tt = t_of(lambda: st.transform_batch(xi, yo, pa.FORWARD, ordered=False))
+                fr = 2 * xi.numel() * xi.element_size() / tt / HBM_PEAK
+                st.close(); del xi, yo
+                return round(fr, 4), round(b / tt / 1e6, 3)
+            extras["c3_real16384_f32_fwd_frac"], extras["c3_Mtps"] = side(16384, pa.REAL, np.float32, 1 << 14)
+            extras["c5_cplx1024_f64_fwd_frac"], extras["c5_Mtps"] = side(1024, pa.COMPLEX, np.float64, 1 << 18)
+            sig = torch.rand(1 << 20, device=dev) * 2 - 1
+            taps = np.random.default_rng(4).uniform(-1, 1, 4096).astype(np.float32)
+            fc = pa.FastConv(taps, 0, 0)
+            yo = torch.empty_like(sig)
+            extras["c4_fir_us_per_call"] = round(t_of(lambda: fc.apply(sig, True, out=yo), reps=50) * 1e6, 2)
+            fc.close(); del sig, yo
+            torch.cuda.empty_cache()
+        except Exception as e:
+            extras["side_configs_error"] = str(e)[:200]
         # the PFDSP mixer fused into the load stage of the same transform, and the mixer alone
         ts = t_of(lambda: setup.shift_transform_batch(x, 0.0137, 0.4, out=y, ordered=False))
         extras["shift_fused_fwd_Mtps"] = round(batch / ts / 1e6, 2)
