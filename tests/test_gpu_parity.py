@@ -510,3 +510,36 @@ def test_ordered_is_reordered_unordered_bit_for_bit(dt):
             bo = s.transform_batch(fo, None, pa.BACKWARD, True)
             assert torch.equal(bu, bo), (dt, tr, N, "backward")
             s.close()
+
+
+def test_partitioned_convolution_with_zconvolve_accumulate():
+    """The use pffft_zconvolve_accumulate exists for (reference README.md:273-275): a uniformly
+    partitioned overlap-save FIR — spectra of the last P input blocks times the P filter-partition spectra, accumulated
+    in the internal layout, ONE inverse transform per output block.  Built only from the drop-in's batched entries
+    (real transforms: exercises the DC/Nyquist rule of zconvolve, src/pffft_priv_impl.h:1626-1629) and checked against
+    a float64 direct convolution with the reference's FIR bar (tests/test_pffastconv.c:685)."""
+    B, P, nblk = 256, 4, 40                       # block = partition length, partitions, signal blocks
+    N = 2 * B
+    rng = np.random.default_rng(5)
+    h = rng.uniform(-1, 1, B * P).astype(np.float32)
+    x = rng.uniform(-1, 1, B * nblk).astype(np.float32)
+    s = pa.Setup(N, pa.REAL, np.float32)
+    # filter partitions, zero padded to N, forward transformed (internal layout), pre-scaled by 1/N
+    hp = np.zeros((P, N), np.float32); hp[:, :B] = h.reshape(P, B)
+    H = s.transform_batch(_dev(hp), None, pa.FORWARD, ordered=False)
+    # overlapping input frames [block b-1 | block b], forward transformed
+    xp = np.concatenate([np.zeros(B, np.float32), x])
+    frames = np.stack([xp[b * B:b * B + N] for b in range(nblk)])
+    X = s.transform_batch(_dev(frames), None, pa.FORWARD, ordered=False)
+    acc = torch.zeros_like(X)
+    for p in range(P):                            # Y_b += X_{b-p} * H_p for every block at once
+        if p == 0:
+            s.zconvolve_batch(X, H[0:1].contiguous(), acc, 1.0 / N, accumulate=True, b_broadcast=True)
+        else:
+            s.zconvolve_batch(X[:nblk - p].contiguous(), H[p:p + 1].contiguous(), acc[p:], 1.0 / N, accumulate=True,
+                              b_broadcast=True)
+    y = s.transform_batch(acc, None, pa.BACKWARD, ordered=False).cpu().numpy()[:, B:]   # the valid half of every frame
+    want = np.convolve(x.astype(np.float64), h.astype(np.float64))[:B * nblk].reshape(nblk, B)
+    lim = (want.max() - want.min()) / 1e5
+    assert np.abs(y - want).max() < lim
+    s.close()
