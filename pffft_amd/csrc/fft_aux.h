@@ -273,4 +273,102 @@ zreorder_lds_kernel(const T* in, T* out, size_t batch, int n, int is_real, int t
     sch.finish(tid == 0);
 }
 
+// ---- zreorder for long batches: the same image, the streaming organisation of the mixer kernel (pfdsp_mix.h) ----
+// One persistent workgroup of 8 wavefronts per CU pulls groups of G vectors (<= 64 KiB) IN ORDER from an atomic counter
+// (grabbed two iterations ahead); the 16-byte loads of the NEXT group sit in registers (8 per thread) while the current
+// group leaves the LDS image.  Same index maps as zreorder_lds_kernel above.
+constexpr int ZRD_THREADS = 512, ZRD_U = 8;
+constexpr size_t ZRD_GROUP_BYTES = (size_t)ZRD_THREADS * ZRD_U * 16;   // 64 KiB
+
+template <typename T>
+__global__ void __launch_bounds__(ZRD_THREADS)
+zreorder_dyn_kernel(const T* in, T* out, size_t batch, int n, int is_real, int to_canonical, int G, unsigned m_n4,
+                    unsigned m_nchk, unsigned* ctr) {
+    typedef vec4<float> chunk16;
+    constexpr int IBS = SkIbs<T>::v, CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = IBS / CH;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* const lds = reinterpret_cast<T*>(smem_raw);
+    chunk16* const lds16 = reinterpret_cast<chunk16*>(smem_raw);
+    const int nchk = 2 * n / CH;                  // 16-byte chunks per vector
+    const int img16 = (n / 16) * BCH + 1;         // block image per vector, in chunks
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + (size_t)G * img16 * 16);
+    const int n4 = n >> 2, tid = threadIdx.x;
+    const chunk16* in16 = reinterpret_cast<const chunk16*>(in);
+    chunk16* out16 = reinterpret_cast<chunk16*>(out);
+    auto ipos_of = [&](int cc, int e) -> int {
+        const int sc = cc * CH + e, bin = sc >> 1, part = sc & 1;
+        const int ip = is_real ? sk_iposr<T>(bin, n4, m_n4, IBS)
+                               : (IBS * ((bin - udiv(bin, m_n4) * n4) >> 2) + 8 * udiv(bin, m_n4) + ((bin - udiv(bin, m_n4) * n4) & 3));
+        return ip + 4 * part;
+    };
+    const size_t ngroups = (batch + G - 1) / G;
+    const size_t last_chunk = batch * (size_t)nchk - 1;
+    const size_t gchunks = (size_t)G * nchk;
+    unsigned pend = 0;
+    if (tid == 0) {
+        s_next[0] = atomicAdd(&ctr[0], 1u);
+        pend = atomicAdd(&ctr[0], 1u);
+    }
+    __syncthreads();
+    unsigned g = s_next[0];
+    chunk16 v[ZRD_U];
+    auto load_group = [&](size_t grp) {           // clamped: unconditional loads
+        if (grp >= ngroups) grp = ngroups - 1;
+        const size_t c0 = grp * gchunks + tid;
+#pragma unroll
+        for (int u = 0; u < ZRD_U; ++u) {
+            size_t c = c0 + (size_t)u * ZRD_THREADS;
+            v[u] = __builtin_nontemporal_load(in16 + (c < last_chunk ? c : last_chunk));
+        }
+    };
+    load_group(g);
+    for (unsigned it = 0; g < ngroups; ++it) {
+        if (tid == 0) {
+            s_next[(it + 1) & 1] = pend;
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        const size_t t0 = (size_t)g * G;
+        const int cnt = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);
+        const int tot = cnt * nchk;
+        // ---- phase 1: the prefetched chunks into the image
+#pragma unroll
+        for (int u = 0; u < ZRD_U; ++u) {
+            const int c = tid + u * ZRD_THREADS;
+            if (c >= tot) continue;
+            const int gg = udiv(c, m_nchk), cc = c - gg * nchk;
+            if (to_canonical) {
+                lds16[gg * img16 + (cc / CPB) * BCH + (cc % CPB)] = v[u];
+            } else {
+                T* img = lds + (size_t)gg * img16 * CH;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) img[ipos_of(cc, e)] = ChunkOps<T>::get(v[u], e);
+            }
+        }
+        __syncthreads();
+        const unsigned gn = s_next[(it + 1) & 1];
+        load_group(gn);                           // in flight during phase 2
+        // ---- phase 2: out of the image, linear 16-byte stores
+        chunk16* dst = out16 + t0 * nchk;
+        for (int c = tid; c < tot; c += ZRD_THREADS) {
+            const int gg = udiv(c, m_nchk), cc = c - gg * nchk;
+            chunk16 o;
+            if (to_canonical) {
+                const T* img = lds + (size_t)gg * img16 * CH;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) ChunkOps<T>::set(o, e, img[ipos_of(cc, e)]);
+            } else {
+                o = lds16[gg * img16 + (cc / CPB) * BCH + (cc % CPB)];
+            }
+            __builtin_nontemporal_store(o, dst + c);
+        }
+        __syncthreads();
+        g = gn;
+    }
+    if (tid == 0) {
+        __threadfence();
+        unsigned d = atomicAdd(&ctr[1], 1u);
+        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+}
+
 }  // namespace pf

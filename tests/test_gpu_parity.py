@@ -543,3 +543,29 @@ def test_partitioned_convolution_with_zconvolve_accumulate():
     lim = (want.max() - want.min()) / 1e5
     assert np.abs(y - want).max() < lim
     s.close()
+
+
+@pytest.mark.parametrize("dt,N,tr", [("f32", 1024, 1), ("f32", 96, 1), ("f32", 16384, 0), ("f32", 32, 0), ("f32", 2400, 0),
+                                     ("f64", 1024, 1), ("f64", 96, 0), ("f64", 4096, 1)])
+def test_zreorder_long_batches(ref, dt, N, tr):
+    """zreorder on batches > 64 MiB: the in-order streaming kernel with next-group prefetch (fft_aux.h zreorder_dyn_kernel)
+    is a pure permutation — bit for bit equal to the direct kernel (variant 60) on the whole ragged batch, to the
+    reference's own pffft_zreorder on sampled vectors, and its own inverse."""
+    dtype = _dt(dt)
+    rs, s = ref.setup(N, tr, dtype), pa.Setup(N, tr, dtype)
+    vb = s.vec_scalars * np.dtype(dtype).itemsize
+    batch = (66 << 20) // vb + 3
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    x = torch.rand(batch, s.vec_scalars, device="cuda", dtype=tdt, generator=torch.Generator(device="cuda").manual_seed(N)) * 2 - 1
+    for d in (pa.FORWARD, pa.BACKWARD):
+        got = s.zreorder_batch(x, None, d)
+        pa.set_variant(60)
+        try:
+            want = s.zreorder_batch(x, None, d)
+        finally:
+            pa.set_variant(0)
+        assert torch.equal(got, want), (dt, N, tr, d)
+        for i in (0, batch // 2, batch - 1):
+            assert np.array_equal(got[i].cpu().numpy(), rs.zreorder(x[i].cpu().numpy(), d)), (dt, N, tr, d, i)
+        assert torch.equal(s.zreorder_batch(got, None, 1 - d), x)
+    s.close(); rs.close()
