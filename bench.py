@@ -164,7 +164,7 @@ def main():
     elapsed, total = combine(elapsed, float(batch), dist, dev)
 
     extras = {}
-    if not args.no_extras and rank == 0:
+    if not args.no_extras and rank == 0 and world == 1:   # side measurements only in the single-GPU run: no rank waits on another
         def t_of(fn, reps=5):
             fn(); torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -248,6 +248,7 @@ def main():
                                                  "sample": "oracle/_ref not present on this box"}
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
