@@ -915,7 +915,11 @@ static int legacy_run(Setup* s, const T* const* ins, int nin, T* out, bool out_i
     if (bytes <= ZC_LIMIT && zero_copy_enabled() && s->kernel != K_BIG) {
         bool any_dev = is_device_ptr(out);
         for (int i = 0; i < nin && !any_dev; ++i) any_dev = is_device_ptr(ins[i]);
-        if (!any_dev) {
+        // the pinned images are allocated up front; if the host cannot pin memory the device staging below still works
+        void* pins[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool pinned_ok = !any_dev;
+        for (int k = 0; k <= nin && pinned_ok; ++k) pinned_ok = pinned_buf(s, k, bytes, &pins[k]) == 0;
+        if (!any_dev && pinned_ok) {
             const T* h_in[3] = {nullptr, nullptr, nullptr};
             void* po; int rc = pinned_buf(s, 0, bytes, &po); if (rc) return rc;
             T* h_out = (T*)po;

@@ -58,7 +58,7 @@ def test_against_golden(golden, dt, tr, N):
 
 # ------------------------------------------------------------------ the real reference, more sizes, batches
 SIZES_C = [16, 32, 48, 64, 80, 96, 128, 160, 192, 240, 256, 288, 384, 480, 512, 576, 640, 800, 864, 1024, 2048,
-           2592, 4000, 4096, 12000, 16384]
+           2592, 4000, 4096, 8192, 12000, 16384]
 SIZES_R = [32, 64, 96, 128, 160, 192, 256, 288, 384, 480, 512, 576, 640, 800, 864, 1024, 2048, 4000, 4096, 8192,
            12000, 16384, 36864]
 
@@ -569,3 +569,33 @@ def test_zreorder_long_batches(ref, dt, N, tr):
             assert np.array_equal(got[i].cpu().numpy(), rs.zreorder(x[i].cpu().numpy(), d)), (dt, N, tr, d, i)
         assert torch.equal(s.zreorder_batch(got, None, 1 - d), x)
     s.close(); rs.close()
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_multiwave_sizes_edge_batches_and_inplace(ref, dt):
+    """The sizes whose kernels are picked per layout and direction (three-stage float 2048..8192, TiledAltF64 double
+    128..4096): batches of 1, 2, 3, 9 and 17 vectors (fewer / more than one workgroup pass), every direction and layout,
+    in place == out of place bit for bit, against the reference."""
+    dtype = _dt(dt)
+    sizes = [(2048, 1), (4096, 1), (8192, 1), (4096, 0), (8192, 0), (16384, 0)] if dt == "f32" else \
+            [(128, 1), (256, 1), (512, 1), (1024, 1), (2048, 1), (4096, 1), (256, 0), (512, 0), (1024, 0), (2048, 0), (4096, 0), (8192, 0)]
+    rng = np.random.default_rng(3)
+    for N, tr in sizes:
+        rs, s = ref.setup(N, tr, dtype), pa.Setup(N, tr, dtype)
+        tol = tol_for(dt, N)
+        for batch in (1, 2, 3, 9, 17):
+            x = rng.uniform(-1, 1, (batch, s.vec_scalars)).astype(dtype)
+            for ordered in (False, True):
+                want = rs.batch(x, 0, ordered)
+                got = s.transform_batch(_dev(x), None, pa.FORWARD, ordered)
+                assert relerr(got.cpu().numpy(), want) <= tol, (dt, tr, N, batch, ordered, "fwd")
+                buf = _dev(x)
+                s.transform_batch(buf, buf, pa.FORWARD, ordered)
+                assert torch.equal(buf, got), (dt, tr, N, batch, ordered, "fwd in place")
+                wb = rs.batch(want, 1, ordered)
+                gb = s.transform_batch(_dev(want), None, pa.BACKWARD, ordered)
+                assert relerr(gb.cpu().numpy(), wb) <= tol, (dt, tr, N, batch, ordered, "bwd")
+                buf = _dev(want)
+                s.transform_batch(buf, buf, pa.BACKWARD, ordered)
+                assert torch.equal(buf, gb), (dt, tr, N, batch, ordered, "bwd in place")
+        s.close(); rs.close()
