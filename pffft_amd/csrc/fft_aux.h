@@ -280,17 +280,35 @@ zreorder_lds_kernel(const T* in, T* out, size_t batch, int n, int is_real, int t
 constexpr int ZRD_THREADS = 512, ZRD_U = 8;
 constexpr size_t ZRD_GROUP_BYTES = (size_t)ZRD_THREADS * ZRD_U * 16;   // 64 KiB
 
-template <typename T>
+// internal -> canonical goes through an image of the CANONICAL vector instead: the re-group and the im-group of the same
+// four bins sit in neighbouring lanes (float: lane ^ 1, double: lane ^ 2), one DPP swap interleaves them into whole
+// (re, im) bins, and each lane writes 16 bytes of canonical spectrum (two 8-byte bins where a real spectrum's odd quarters
+// run backwards) — no scalar LDS access on either side.  Quarter q of the image is shifted by q * ZrdPad chunks so that
+// the four quarters a wave writes at once fall into different banks.
+template <typename T> struct ZrdPad { static constexpr int v = sizeof(T) == 4 ? 2 : 4; };   // 16-byte chunks per quarter
+template <typename T> __host__ __device__ constexpr int zrd_canon_img16(int n) { return 2 * n * (int)sizeof(T) / 16 + 4 * ZrdPad<T>::v; }
+
+__device__ __forceinline__ float dpp_swap2(float v) {   // lane ^ 2 inside every quad
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double dpp_swap2(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, 0x4E, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), 0x4E, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <typename T, int TO_CANON>
 __global__ void __launch_bounds__(ZRD_THREADS)
-zreorder_dyn_kernel(const T* in, T* out, size_t batch, int n, int is_real, int to_canonical, int G, unsigned m_n4,
-                    unsigned m_nchk, unsigned* ctr) {
+zreorder_dyn_kernel(const T* in, T* out, size_t batch, int n, int is_real, int G, unsigned m_n4, unsigned m_nchk,
+                    unsigned* ctr) {
     typedef vec4<float> chunk16;
-    constexpr int IBS = SkIbs<T>::v, CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = IBS / CH;
+    constexpr int IBS = SkIbs<T>::v, CH = 16 / (int)sizeof(T), CPB = 32 / CH, BCH = IBS / CH, PADC = ZrdPad<T>::v;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* const lds = reinterpret_cast<T*>(smem_raw);
     chunk16* const lds16 = reinterpret_cast<chunk16*>(smem_raw);
     const int nchk = 2 * n / CH;                  // 16-byte chunks per vector
-    const int img16 = (n / 16) * BCH + 1;         // block image per vector, in chunks
+    const int img16 = TO_CANON ? zrd_canon_img16<T>(n) : (n / 16) * BCH + 1;   // image per vector, in chunks
     unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + (size_t)G * img16 * 16);
     const int n4 = n >> 2, tid = threadIdx.x;
     const chunk16* in16 = reinterpret_cast<const chunk16*>(in);
@@ -300,6 +318,11 @@ zreorder_dyn_kernel(const T* in, T* out, size_t batch, int n, int is_real, int t
         const int ip = is_real ? sk_iposr<T>(bin, n4, m_n4, IBS)
                                : (IBS * ((bin - udiv(bin, m_n4) * n4) >> 2) + 8 * udiv(bin, m_n4) + ((bin - udiv(bin, m_n4) * n4) & 3));
         return ip + 4 * part;
+    };
+    // canonical bin of element t of quarter q (fft_generic.h bin_of): odd quarters of a real spectrum run backwards
+    auto bin_qt = [&](int q, int t) -> int {
+        if (is_real && (q & 1)) return q * n4 + (t ? n4 - t : 0);
+        return q * n4 + t;
     };
     const size_t ngroups = (batch + G - 1) / G;
     const size_t last_chunk = batch * (size_t)nchk - 1;
@@ -334,11 +357,36 @@ zreorder_dyn_kernel(const T* in, T* out, size_t batch, int n, int is_real, int t
 #pragma unroll
         for (int u = 0; u < ZRD_U; ++u) {
             const int c = tid + u * ZRD_THREADS;
-            if (c >= tot) continue;
             const int gg = udiv(c, m_nchk), cc = c - gg * nchk;
-            if (to_canonical) {
-                lds16[gg * img16 + (cc / CPB) * BCH + (cc % CPB)] = v[u];
+            if constexpr (TO_CANON && sizeof(T) == 4) {
+                // cc = 8 b + 2 q + p: lane pair (p = 0: re-group, p = 1: im-group) of block b, quarter q
+                const bool odd = cc & 1;
+                const vec4<float> x = v[u];
+                const float s0 = dpp_swap1<float>(odd ? x.x : x.z), s1 = dpp_swap1<float>(odd ? x.y : x.w);
+                vec4<float> o;                     // even: bins t0, t0+1 = (re0, im0, re1, im1); odd: (re2, im2, re3, im3)
+                if (odd) { o.x = s0; o.y = x.z; o.z = s1; o.w = x.w; } else { o.x = x.x; o.y = s0; o.z = x.y; o.w = s1; }
+                if (c >= tot) continue;
+                const int b = cc >> 3, q = (cc >> 1) & 3, t = 4 * b + (odd ? 2 : 0);
+                float* img = reinterpret_cast<float*>(lds16 + gg * img16 + PADC * q);
+                if (is_real && (q & 1)) {
+                    vec2<float> lo, hi; lo.x = o.x; lo.y = o.y; hi.x = o.z; hi.y = o.w;
+                    *reinterpret_cast<vec2<float>*>(img + 2 * bin_qt(q, t)) = lo;
+                    *reinterpret_cast<vec2<float>*>(img + 2 * bin_qt(q, t + 1)) = hi;
+                } else {
+                    *reinterpret_cast<vec4<float>*>(img + 2 * (q * n4 + t)) = o;
+                }
+            } else if constexpr (TO_CANON) {
+                // cc = 16 b + 4 q + 2 p + h: lanes (p, h) hold (re|im)_{2h}, (re|im)_{2h+1}; partner = lane ^ 2
+                const int p = (cc >> 1) & 1, h = cc & 1;
+                const vec2<double> x = __builtin_bit_cast(vec2<double>, v[u]);
+                const double r = dpp_swap2(p ? x.x : x.y);
+                vec2<double> o;                    // p = 0: bin 2h = (re, im); p = 1: bin 2h+1
+                if (p) { o.x = r; o.y = x.y; } else { o.x = x.x; o.y = r; }
+                if (c >= tot) continue;
+                const int b = cc >> 4, q = (cc >> 2) & 3, t = 4 * b + 2 * h + p;
+                lds16[gg * img16 + PADC * q + bin_qt(q, t)] = __builtin_bit_cast(chunk16, o);
             } else {
+                if (c >= tot) continue;
                 T* img = lds + (size_t)gg * img16 * CH;
 #pragma unroll
                 for (int e = 0; e < CH; ++e) img[ipos_of(cc, e)] = ChunkOps<T>::get(v[u], e);
@@ -352,13 +400,8 @@ zreorder_dyn_kernel(const T* in, T* out, size_t batch, int n, int is_real, int t
         for (int c = tid; c < tot; c += ZRD_THREADS) {
             const int gg = udiv(c, m_nchk), cc = c - gg * nchk;
             chunk16 o;
-            if (to_canonical) {
-                const T* img = lds + (size_t)gg * img16 * CH;
-#pragma unroll
-                for (int e = 0; e < CH; ++e) ChunkOps<T>::set(o, e, img[ipos_of(cc, e)]);
-            } else {
-                o = lds16[gg * img16 + (cc / CPB) * BCH + (cc % CPB)];
-            }
+            if constexpr (TO_CANON) o = lds16[gg * img16 + cc + PADC * udiv(cc * (CH / 2), m_n4)];
+            else o = lds16[gg * img16 + (cc / CPB) * BCH + (cc % CPB)];
             __builtin_nontemporal_store(o, dst + c);
         }
         __syncthreads();

@@ -738,25 +738,31 @@ static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, 
     const size_t vimg = ((size_t)(s->n / 16) * BCH + 1) * 16;   // block image of one vector, bytes
     const size_t vbytes = s->vec_scalars * sizeof(T);
     // long batches of vectors <= 64 KiB: in-order streaming kernel with next-group prefetch (fft_aux.h); variant 61 = off
-    // measured (tools/aux_bench.py, fraction of 8 TB/s, static -> streaming): canonical -> internal 0.62-0.66 -> 0.78-0.79,
-    // internal -> canonical double 0.69 -> 0.78, float complex 0.61 -> 0.64, float real 0.62 -> 0.58 (the 4-byte LDS gathers
-    // of that direction bound it; it stays on the static kernel)
-    const bool zrd_ok = !(sizeof(T) == 4 && dir == PFFFT_FORWARD && s->transform == PFFFT_REAL);
     if (vbytes <= ZRD_GROUP_BYTES && batch * vbytes >= ((size_t)64 << 20) && g_variant != 60 && g_variant != 61 &&
-        g_variant != 42 && in != out && zrd_ok) {
+        g_variant != 42 && in != out) {
         int rc = ensure_device<T>(s);
         if (rc) return rc;
         const int G = (int)(ZRD_GROUP_BYTES / vbytes);
-        const size_t lds = (size_t)G * vimg + 16;
-        auto k = zreorder_dyn_kernel<T>;
-        if ((rc = allow_big_lds(k, lds))) return rc;
-        unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
-        const int nchk = 2 * s->n / CH;
-        hipLaunchKernelGGL(k, dim3((unsigned)num_cus()), dim3(ZRD_THREADS), lds, st, in, out, batch, s->n,
-                           (int)(s->transform == PFFFT_REAL), (int)(dir == PFFFT_FORWARD), G, sk_magic(s->n / 4),
-                           sk_magic(nchk), ctr);
-        PF_CHECK(hipGetLastError());
-        return 0;
+        const bool to_canon = dir == PFFFT_FORWARD;
+        const size_t img = to_canon ? (size_t)zrd_canon_img16<T>(s->n) * 16 : vimg;
+        const size_t lds = (size_t)G * img + 16;
+        if (lds <= LDS_MAX) {
+            unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+            const int nchk = 2 * s->n / CH;
+            const dim3 grid((unsigned)num_cus()), blk(ZRD_THREADS);
+            const int real = s->transform == PFFFT_REAL;
+            if (to_canon) {
+                auto k = zreorder_dyn_kernel<T, 1>;
+                if ((rc = allow_big_lds(k, lds))) return rc;
+                hipLaunchKernelGGL(k, grid, blk, lds, st, in, out, batch, s->n, real, G, sk_magic(s->n / 4), sk_magic(nchk), ctr);
+            } else {
+                auto k = zreorder_dyn_kernel<T, 0>;
+                if ((rc = allow_big_lds(k, lds))) return rc;
+                hipLaunchKernelGGL(k, grid, blk, lds, st, in, out, batch, s->n, real, G, sk_magic(s->n / 4), sk_magic(nchk), ctr);
+            }
+            PF_CHECK(hipGetLastError());
+            return 0;
+        }
     }
     if (vimg <= 128 * 1024 && g_variant != 60 && in != out) {
         int rc = ensure_device<T>(s);
