@@ -127,4 +127,74 @@ __global__ void real_pair_kernel(cx<T>* data, long long batch, long long n) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// n = R x N2 with R <= 32 and N2 small enough for the LDS-resident batched kernels (complex N up to 32 x 8192): three
+// streaming passes instead of the strided mixed-radix kernel above,
+//   1. big_col_kernel   : x[n1 N2 + n2] -> length-R transform over n1 IN REGISTERS (one column per thread, every access
+//                         coalesced over n2), times W_n^(k1 n2) (one exact sincos per thread, powers by products <= 5 deep)
+//   2. the batched kernel of size N2 on the R * batch rows (fft_tiled.h / fft_stock.h, in place)
+//   3. big_transpose_kernel : B[k1 N2 + k2] -> X[k2 R + k1] through an LDS tile (coalesced on both sides)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ cx<T> big_unit(double turns);   // exp(-2 pi i turns), 0 <= turns < 1
+template <> __device__ __forceinline__ cx<float> big_unit<float>(double turns) {
+    turns -= rint(turns);
+    const float th = (float)turns;
+    const float d = 6.28318530717958647692f * (float)(turns - (double)th);
+    float sn, cs;
+    sincospif(2.0f * th, &sn, &cs);
+    return mk<float>(cs - sn * d, -(sn + cs * d));
+}
+template <> __device__ __forceinline__ cx<double> big_unit<double>(double turns) {
+    double sn, cs;
+    sincospi(2.0 * turns, &sn, &cs);
+    return mk<double>(cs, -sn);
+}
+
+template <typename T, int R, int DIR>
+__global__ void __launch_bounds__(256)
+big_col_kernel(const cx<T>* in, cx<T>* out, long long total, int N2, double inv_n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long b = i / N2;
+    const int n2 = (int)(i - b * N2);
+    const cx<T>* src = in + b * (long long)R * N2 + n2;
+    cx<T>* dst = out + b * (long long)R * N2 + n2;
+    cx<T> a[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) a[q] = src[(long long)q * N2];
+    dftR<R, DIR>(a);
+    cx<T> p[R];                      // p[k] = W_n^(k n2) (forward sign); twmul conjugates it for the backward transform
+    p[1] = big_unit<T>((double)n2 * inv_n);
+#pragma unroll
+    for (int k = 2; k < R; ++k) p[k] = cmul(p[k >> 1], p[k - (k >> 1)]);
+    dst[0] = a[0];
+#pragma unroll
+    for (int k = 1; k < R; ++k) dst[(long long)k * N2] = twmul<DIR>(a[k], p[k]);
+}
+
+// tile of 256 consecutive k2 per workgroup: rows k1 = 0..R-1 in (coalesced over k2), R*256 consecutive outputs out
+template <typename T, int R>
+__global__ void __launch_bounds__(256)
+big_transpose_kernel(const cx<T>* in, cx<T>* out, long long batch, int N2) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cx<T>* tile = reinterpret_cast<cx<T>*>(smem_raw);          // [256][R + 1]
+    const int tiles_per_vec = (N2 + 255) / 256;
+    const long long b = blockIdx.x / tiles_per_vec;
+    const int k20 = (int)(blockIdx.x - b * tiles_per_vec) * 256;
+    const int w = (N2 - k20) < 256 ? (N2 - k20) : 256;          // columns in this tile
+    const cx<T>* src = in + b * (long long)R * N2 + k20;
+    cx<T>* dst = out + b * (long long)R * N2 + (long long)k20 * R;
+    const int t = threadIdx.x;
+    if (t < w) {
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) tile[t * (R + 1) + k1] = src[(long long)k1 * N2 + t];
+    }
+    __syncthreads();
+    const int tot = w * R;
+    for (int j = t; j < tot; j += 256) {
+        const int c = j / R, k1 = j - c * R;
+        dst[j] = tile[c * (R + 1) + k1];
+    }
+}
+
 }  // namespace pf

@@ -129,6 +129,9 @@ struct Setup {
     void* d_twc[2] = {nullptr, nullptr};  // compact per-stage base twiddles of the Stockham plans (forward / backward order)
     unsigned* d_ctr = nullptr;             // ring of {next, done} work counters for the dynamic kernels
     std::atomic<unsigned> ctr_slot{0};
+    // sizes beyond LDS with a small factor (fft_big.h, three streaming passes): n = bigR x sub->n
+    int bigR = 0;
+    Setup* sub = nullptr;
     // sizes beyond LDS (K_BIG): n = bigN[0] x bigN[1], one strided plan + twiddle table per factor
     StridedPlan bigp[2];
     void* d_bigtw[2] = {nullptr, nullptr};
@@ -141,6 +144,8 @@ struct Setup {
     size_t hstage_bytes[4] = {0, 0, 0, 0};
 };
 constexpr uint32_t MAGIC = 0x50464654u;  // "PFFT"
+
+static void destroy_setup(Setup* s);
 
 static Setup* new_setup(int N, int transform, int is_double) {
     // validation: src/pffft_priv_impl.h:1066-1078 and :1105-1109
@@ -177,6 +182,30 @@ static Setup* new_setup(int N, int transform, int is_double) {
     if (s->glds > LDS_MAX) {
         // four-step plan: split the prime factors of n into two balanced products
         s->kernel = K_BIG;
+        // ... unless n = R x N2 with a register-sized R and an N2 the LDS-resident batched kernels take (fft_big.h)
+        for (int R : {2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 32}) {
+            if (s->n % R) continue;
+            const int N2 = s->n / R;
+            if ((size_t)N2 * esz > 64 * 1024 || N2 % (SIMD * SIMD)) continue;
+            Setup* sub = new_setup(N2, PFFFT_COMPLEX, is_double);
+            if (!sub) continue;
+            if (sub->kernel == K_BIG || (sub->kernel == K_GENERIC && !sub->sk_ok)) { destroy_setup(sub); continue; }
+            s->sub = sub; s->bigR = R;
+            break;
+        }
+        // larger still: peel the largest register-sized factor and recurse (n = R x (R' x N2')): five passes, seven, ...
+        if (!s->sub) {
+            for (int R : {32, 16, 15, 12, 10, 8, 6, 5, 4, 3, 2}) {
+                if (s->n % R) continue;
+                const int N2 = s->n / R;
+                if (N2 % (SIMD * SIMD)) continue;
+                Setup* sub = new_setup(N2, PFFFT_COMPLEX, is_double);
+                if (!sub) continue;
+                if (!(sub->kernel == K_BIG && sub->bigR)) { destroy_setup(sub); continue; }
+                s->sub = sub; s->bigR = R;
+                break;
+            }
+        }
         std::vector<int> f;
         int rr = s->n;
         for (int q : {5, 3, 2}) while (rr % q == 0) { f.push_back(q); rr /= q; }
@@ -226,6 +255,7 @@ static void destroy_setup(Setup* s) {
         for (void* q : s->d_twc) if (q) (void)hipFree(q);
         if (s->d_ctr) (void)hipFree(s->d_ctr);
     }
+    if (s->sub) destroy_setup(s->sub);
     for (void* p : s->d_bigtw) if (p) (void)hipFree(p);
     for (void* p : s->d_big) if (p) (void)hipFree(p);
     for (void* p : s->d_stage) if (p) (void)hipFree(p);
@@ -626,6 +656,38 @@ static int launch_strided(Setup* s, int which, const cx<T>* in, cx<T>* out, size
     return 0;
 }
 
+template <typename T> static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st);
+
+// n = R x N2: columns in registers -> batched LDS-resident rows -> tiled transpose (fft_big.h)
+template <typename T>
+static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, int dir, hipStream_t st) {
+    const int R = s->bigR, N2 = s->sub->n;
+    const long long total = (long long)batch * N2;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    const double inv_n = 1.0 / (double)s->n;
+    const unsigned tgrid = (unsigned)(batch * (size_t)((N2 + 255) / 256));
+#define PF_BIG_R(RR)                                                                                               \
+    case RR: {                                                                                                     \
+        if (dir == PFFFT_FORWARD) hipLaunchKernelGGL((big_col_kernel<T, RR, FWD>), dim3(grid), dim3(256), 0, st, in, work, total, N2, inv_n); \
+        else hipLaunchKernelGGL((big_col_kernel<T, RR, BWD>), dim3(grid), dim3(256), 0, st, in, work, total, N2, inv_n);  \
+        PF_CHECK(hipGetLastError());                                                                               \
+        int rc = transform_batch<T>(s->sub, (const T*)work, (T*)work, batch * (size_t)RR, dir, 1, st);             \
+        if (rc) return rc;                                                                                         \
+        auto k = big_transpose_kernel<T, RR>;                                                                      \
+        const size_t lds = (size_t)256 * (RR + 1) * sizeof(cx<T>);                                                 \
+        if ((rc = allow_big_lds(k, lds))) return rc;                                                               \
+        hipLaunchKernelGGL(k, dim3(tgrid), dim3(256), lds, st, (const cx<T>*)work, out, (long long)batch, N2);     \
+        PF_CHECK(hipGetLastError());                                                                               \
+        return 0;                                                                                                  \
+    }
+    switch (R) {
+        PF_BIG_R(2) PF_BIG_R(3) PF_BIG_R(4) PF_BIG_R(5) PF_BIG_R(6) PF_BIG_R(8) PF_BIG_R(10) PF_BIG_R(12) PF_BIG_R(15) PF_BIG_R(16) PF_BIG_R(32)
+    }
+#undef PF_BIG_R
+    g_last_error = "pffft_hip: unsupported small factor";
+    return (int)hipErrorInvalidValue;
+}
+
 // n beyond LDS: canonical complex four-step through two HBM work buffers, with the real pair pass and the
 // internal layout composed around it (fft_big.h)
 template <typename T>
@@ -655,9 +717,13 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
         hipLaunchKernelGGL((real_pair_kernel<T, BWD>), dim3(egrid), dim3(256), 0, st, bufA, (long long)batch, (long long)s->n);
         PF_CHECK(hipGetLastError());
     }
-    if ((rc = launch_strided<T>(s, 0, cur, bufB, batch, dir, st))) return rc;
     cx<T>* dest = (fwd && !ordered) ? bufA : (cx<T>*)out;
-    if ((rc = launch_strided<T>(s, 1, bufB, dest, batch, dir, st))) return rc;
+    if (s->bigR && g_variant != 80) {   // three streaming passes (fft_big.h); variant 80 = the strided kernels (A/B)
+        if ((rc = big_small_factor<T>(s, cur, bufB, dest, batch, dir, st))) return rc;
+    } else {
+        if ((rc = launch_strided<T>(s, 0, cur, bufB, batch, dir, st))) return rc;
+        if ((rc = launch_strided<T>(s, 1, bufB, dest, batch, dir, st))) return rc;
+    }
     if (fwd && real) {
         hipLaunchKernelGGL((real_pair_kernel<T, FWD>), dim3(egrid), dim3(256), 0, st, dest, (long long)batch, (long long)s->n);
         PF_CHECK(hipGetLastError());

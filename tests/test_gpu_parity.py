@@ -312,7 +312,12 @@ def test_c4_fir_config(ref):
 # ------------------------------------------------------------------ sizes beyond LDS (four-step path)
 @pytest.mark.parametrize("dt,tr,N", [("f32", 1, 32768), ("f32", 1, 65536), ("f32", 0, 65536), ("f32", 0, 131072),
                                      ("f32", 1, 30000), ("f32", 0, 120000), ("f64", 1, 16384), ("f64", 1, 65536),
-                                     ("f64", 0, 65536), ("f32", 1, 1 << 20)])
+                                     ("f64", 0, 65536), ("f32", 1, 1 << 20),
+                                     # n = R x N2 for every register-sized factor R (fft_big.h big_col_kernel<R>): 3, 5, 6, 10, 12, 15, 32,
+                                     # and the recursive plans (2^21 = 32 x (8 x 8192))
+                                     ("f32", 1, 24576), ("f32", 1, 40960), ("f32", 1, 49152), ("f32", 1, 81920), ("f32", 1, 98304),
+                                     ("f32", 1, 122880), ("f32", 1, 262144), ("f32", 0, 491520), ("f32", 1, 1 << 21),
+                                     ("f64", 1, 12288), ("f64", 1, 131072), ("f64", 0, 1 << 20)])
 def test_large_sizes_against_reference(ref, dt, tr, N):
     dtype = _dt(dt)
     rng = np.random.default_rng(N)
