@@ -28,6 +28,14 @@ def DRIFT(n):
     return 1e-6 + 2e-7 * n
 
 
+def RETURN_BAR(n, inc):
+    """Bound on the error of the phase algorithms C and D RETURN after n samples: they form it as the float product n*inc
+    and wrap it with a float 2*pi, one rounded subtraction per turn (src/pf_mixer.cpp:280-283) — a chained call starts
+    from that value, so its whole block is off by as much."""
+    tot = abs(n * float(inc))
+    return 1e-6 + (2 + tot / (2 * math.pi)) * float(np.spacing(np.float32(tot)))
+
+
 def _sinf(x):
     return f32(math.sin(float(x)))
 

@@ -198,3 +198,38 @@ def test_state_builders_match_reference_bit_for_bit(H, R):
     th, tr = H.shift_table_init(512), R.shift_table_init(512)
     assert np.array_equal(np.ctypeslib.as_array(th.table, (512,)), np.ctypeslib.as_array(tr.table, (512,)))
     H.shift_table_deinit(th); R.shift_table_deinit(tr)
+
+
+# ------------------------------------------------------------------ committed fixtures (work without oracle/_ref)
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "pfdsp_golden.npz")))
+
+
+def test_restatement_and_closed_form_against_golden(gold):
+    """tests/golden/pfdsp_golden.npz (made by tests/golden/make_pfdsp_golden.py from the reference's object code):
+    the numpy restatement reproduces the stored reference outputs of two chained 256-sample calls; the float64 closed
+    form stays within DRIFT(512) of them."""
+    x, ph0 = gold["x"], float(gold["ph0"][0])
+    n = x.size
+    for ri, rate in enumerate(gold["rates"]):
+        rate = float(rate)
+        for algo, fn in (("math", mo.shift_math_cc), ("addfast", mo.shift_addfast_cc), ("unroll", mo.shift_unroll_cc)):
+            y0, p = fn(x[:n // 2], rate, ph0)
+            y1, p2 = fn(x[n // 2:], rate, p)
+            assert _maxerr(np.concatenate([y0, y1]), gold[f"{algo}_r{ri}_y"]) <= 6e-7, (algo, rate)
+            assert abs(float(p) - gold[f"{algo}_r{ri}_state_mid"][0]) <= 2e-6
+        y0, st = mo.shift_limited_unroll_cc(x[:n // 2], rate, (np.cos(np.float32(ph0)), np.sin(np.float32(ph0))))
+        y1, st = mo.shift_limited_unroll_cc(x[n // 2:], rate, st)
+        assert _maxerr(np.concatenate([y0, y1]), gold[f"limited_unroll_r{ri}_y"]) <= 6e-7
+        for lanes, algo in ((8, "recursive_osc"), (4, "recursive_osc_sse")):
+            conf, st = mo.recursive_osc_init(rate, ph0, lanes)
+            y0, st = mo.recursive_osc_run(x[:n // 2], conf, st, lanes)
+            y1, st = mo.recursive_osc_run(x[n // 2:], conf, st, lanes)
+            assert _maxerr(np.concatenate([y0, y1]), gold[f"{algo}_r{ri}_y"]) <= 3e-6, (algo, rate)
+        inc = mo.increment(rate)
+        chained = 1.5 * mo.RETURN_BAR(n // 2, inc)     # C, D: the second call starts from the phase the first one returned
+        for algo in ("math", "unroll", "limited_unroll", "limited_unroll_A_sse", "limited_unroll_B_sse", "limited_unroll_C_sse"):
+            bar = mo.DRIFT(n) + (chained if algo == "unroll" else 0)
+            assert _maxerr(gold[f"{algo}_r{ri}_y"], mo.exact(x, inc, ph0)) <= bar, (algo, rate)
+        assert _maxerr(gold[f"addfast_r{ri}_y"], mo.exact(x, inc, ph0, first=1)) <= mo.DRIFT(n) + chained
