@@ -22,6 +22,8 @@ struct FastConv {
     std::mutex mu;
     float* d_Hf = nullptr;
     float* d_Hc = nullptr;  // canonical-order filter spectrum * 1/Nfft for the fused kernel
+    std::vector<float> h_td;  // y[m] = sum_i h_td[i] x[m + i]: the filter as the time-domain kernel applies it (zero padded to 8)
+    float* d_td = nullptr;
     float* d_work = nullptr; size_t work_floats = 0;
     float* d_x = nullptr; size_t x_floats = 0;
     float* d_y = nullptr; size_t y_floats = 0;
@@ -60,6 +62,58 @@ __global__ void fastconv_scatter_kernel(const float* __restrict__ blocks, float*
         float v = blocks[(size_t)b * Nfft + j];
         if (mode == 0) y[(size_t)tb * step + j] = v;
         else y[2 * ((size_t)tb * step + j) + (b & 1)] = v;
+    }
+}
+
+// ---- short filters: time domain ------------------------------------------------------------------------------------
+// The reference always goes through Nfft = max(32, 2 next_pow2(len - 1)) transforms.  For <= TD_MAX_TAPS taps that is two
+// transforms per (Nfft - len + 1) outputs of a kernel family that is latency-bound at these sizes (64 taps: 36
+// Gsamples/s); the same outputs  y[m] = sum_i c_i x[m + i]  (the circular product of :99-108 and :238-255 written
+// out: c_i = filter[len-1-i], or filter[i] with PFFASTCONV_CORRELATION) cost len FMAs each.  A workgroup stages
+// 2048 + len inputs in LDS, a thread owns 8 consecutive outputs and slides a 16-value register window over them, 8 taps
+// per step (two 16-byte LDS reads for 64 FMAs), the taps come through scalar loads.  The block schedule the caller can
+// observe (how many samples a call produces, src/pffastconv.c:156-166,204-210) is computed as before.
+constexpr int TD_THREADS = 256, TD_PER = 8, TD_TILE = TD_THREADS * TD_PER, TD_MAX_TAPS = 256;
+
+__global__ void __launch_bounds__(TD_THREADS)
+fastconv_td_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ c, int flen8, int produced,
+                   int inputLen) {
+    extern __shared__ __attribute__((aligned(16))) float sx[];
+    const int tid = threadIdx.x;
+    const long o0 = (long)blockIdx.x * TD_TILE;
+    const int outs = (produced - o0) < TD_TILE ? (int)(produced - o0) : TD_TILE;
+    const int need = outs + flen8 - 1;                 // produced + len - 1 <= inputLen (fc_schedule); the zero taps of the
+    for (int i = tid; i < TD_TILE + flen8 + 8; i += TD_THREADS)   // padding may point past the input: guarded
+        sx[i] = (i < need && o0 + i < inputLen) ? x[o0 + i] : 0.f;
+    __syncthreads();
+    const float* w = sx + tid * TD_PER;
+    float acc[TD_PER];
+#pragma unroll
+    for (int k = 0; k < TD_PER; ++k) acc[k] = 0.f;
+    vec4<float> lo0 = *reinterpret_cast<const vec4<float>*>(w), lo1 = *reinterpret_cast<const vec4<float>*>(w + 4);
+    for (int j = 0; j < flen8; j += 8) {
+        const vec4<float> hi0 = *reinterpret_cast<const vec4<float>*>(w + j + 8);
+        const vec4<float> hi1 = *reinterpret_cast<const vec4<float>*>(w + j + 12);
+        const float win[16] = {lo0.x, lo0.y, lo0.z, lo0.w, lo1.x, lo1.y, lo1.z, lo1.w,
+                               hi0.x, hi0.y, hi0.z, hi0.w, hi1.x, hi1.y, hi1.z, hi1.w};
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float cj = c[j + jj];                // wave-uniform: scalar load
+#pragma unroll
+            for (int k = 0; k < TD_PER; ++k) acc[k] = __builtin_fmaf(cj, win[jj + k], acc[k]);
+        }
+        lo0 = hi0; lo1 = hi1;
+    }
+    const int m0 = tid * TD_PER;
+    float* dst = y + o0 + m0;
+    if (m0 + TD_PER <= outs && (((uintptr_t)dst) & 15) == 0) {
+        vec4<float> a, b;
+        a.x = acc[0]; a.y = acc[1]; a.z = acc[2]; a.w = acc[3]; b.x = acc[4]; b.y = acc[5]; b.z = acc[6]; b.w = acc[7];
+        *reinterpret_cast<vec4<float>*>(dst) = a;
+        *reinterpret_cast<vec4<float>*>(dst + 4) = b;
+    } else {
+#pragma unroll
+        for (int k = 0; k < TD_PER; ++k) if (m0 + k < outs) dst[k] = acc[k];
     }
 }
 
@@ -114,6 +168,17 @@ static int fc_schedule(const FastConv* s, int inputLen, int flush, int* lastOut,
     const int Nfft = s->Nfft, flen = s->filterLen;
     const int step_full = s->cplxFactor == 2 ? ((Nfft - flen + 1) & ~1) : (Nfft - flen + 1);
     const long maxOff = flush ? ((long)inputLen - flen + 1) : ((long)inputLen - Nfft + 1);
+    if (s->cplxFactor == 1) {
+        // closed form of the loop below (it runs once per block: a million iterations for a short filter on a long signal):
+        // full blocks while off + Nfft <= inputLen, then - flushing only - one partial block with the remaining outputs
+        const long nfull = inputLen >= Nfft ? ((long)inputLen - Nfft) / step_full + 1 : 0;
+        long off = nfull * step_full;
+        int nb = (int)nfull, lst = nfull ? step_full : 0;
+        if (flush && off < maxOff) { lst = (int)(inputLen - off - flen + 1); off += lst; ++nb; }
+        *lastOut = lst;
+        *produced = (int)off;
+        return nb;
+    }
     int nblk = 0, last = 0;
     long off = 0;
     while (off < maxOff) {
@@ -143,6 +208,19 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     const int nblk = mode ? 2 * nbt : nbt;
     const int Nfft = s->Nfft;
     const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
+    if (mode == 0 && s->cplxFactor == 1 && s->filterLen <= TD_MAX_TAPS && g_variant != 30 && g_variant != 81) {
+        // short real filter: time domain (variant 81 = off)
+        if (!s->d_td) {
+            PF_CHECK(hipMalloc((void**)&s->d_td, sizeof(float) * s->h_td.size()));
+            PF_CHECK(hipMemcpy(s->d_td, s->h_td.data(), sizeof(float) * s->h_td.size(), hipMemcpyHostToDevice));
+        }
+        const int flen8 = (int)s->h_td.size();
+        const unsigned grid = (unsigned)(((long)produced + TD_TILE - 1) / TD_TILE);
+        const size_t lds = sizeof(float) * (TD_TILE + flen8 + 8);
+        hipLaunchKernelGGL(fastconv_td_kernel, dim3(grid), dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, produced, inputLen);
+        PF_CHECK(hipGetLastError());
+        return 0;
+    }
     if (mode == 0 && g_variant != 30) {  // one real stream: the fused one-kernel path when Nfft/2 has a tiled kernel
         switch (Nfft / 2) {
             case 512: return fc_launch_fused<FirCfg::C512>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
@@ -196,9 +274,11 @@ PF_EXPORT PFFASTCONV_Setup* pffastconv_new_setup(const float* filterCoeffs, int 
     s->Nfft = Nfft; s->flags = flags; s->cplxFactor = cplxFactor;
     s->scale = (float)(1.0 / Nfft);
     s->h_filter_image.assign(Nfft, 0.f);
+    s->h_td.assign((size_t)(filterLen + 7) / 8 * 8, 0.f);
     for (int i = 0; i < filterLen; ++i) {  // :100-106
         float c = (flags & PFFASTCONV_HIP_CORRELATION) ? filterCoeffs[i] : filterCoeffs[filterLen - 1 - i];
         s->h_filter_image[(Nfft - cplxFactor * i) & (Nfft - 1)] = c;
+        s->h_td[i] = c;
     }
     return s;
 }
@@ -206,7 +286,7 @@ PF_EXPORT PFFASTCONV_Setup* pffastconv_new_setup(const float* filterCoeffs, int 
 PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
     if (!s) return;
     pffft_destroy_setup(s->st);
-    for (float* p : {s->d_Hf, s->d_Hc, s->d_work, s->d_x, s->d_y}) if (p) (void)hipFree(p);
+    for (float* p : {s->d_Hf, s->d_Hc, s->d_td, s->d_work, s->d_x, s->d_y}) if (p) (void)hipFree(p);
     s->magic = 0;
     delete s;
 }

@@ -604,3 +604,33 @@ def test_multiwave_sizes_edge_batches_and_inplace(ref, dt):
                 s.transform_batch(buf, buf, pa.BACKWARD, ordered)
                 assert torch.equal(buf, gb), (dt, tr, N, batch, ordered, "bwd in place")
         s.close(); rs.close()
+
+
+@pytest.mark.parametrize("taps", [1, 2, 7, 8, 9, 31, 64, 100, 255, 256, 257])
+def test_fastconv_short_filters(ref, taps):
+    """pffastconv with short filters (<= 256 taps take the time-domain kernel, 257 the FFT path): same number of samples
+    as the reference for flush / no flush (the block schedule is observable, src/pffastconv.c:156-166,204-210), values
+    against the reference within its own test limit (tests/test_pffastconv.c:685) and against the direct float64 sum
+    y[m] = sum_i x[m+i] hrev[i] (tests/test_pffastconv.c:175-213); convolution and PFFASTCONV_CORRELATION; signal lengths
+    that end inside a tile / a block; device and host pointers."""
+    rng = np.random.default_rng(taps)
+    h = rng.uniform(-1, 1, taps).astype(np.float32)
+    for L in (taps, taps + 5, 2048 + taps - 1, 5000, 70001):
+        x = rng.uniform(-1, 1, L).astype(np.float32)
+        for flags in (0, 64):                       # 64 = PFFASTCONV_CORRELATION
+            for flush in (1, 0):
+                yw, nw, bl = ref.fastconv(x, h, 0, flags, flush)
+                fc = pa.FastConv(h, 0, flags)
+                assert fc.block_len == bl
+                yd, nd = fc.apply(_dev(x), bool(flush))
+                assert nd == nw, (taps, L, flags, flush)
+                if nw:
+                    hrev = h if flags else h[::-1]
+                    truth = np.correlate(x.astype(np.float64), hrev.astype(np.float64), "valid")[:nw]
+                    lim = max((truth.max() - truth.min()) / 1e5, 2e-6 * np.sqrt(taps) * max(1.0, np.abs(truth).max()))
+                    got = yd.cpu().numpy()
+                    assert np.abs(got - truth).max() <= lim, (taps, L, flags, flush)
+                    assert np.abs(got - yw[:nw]).max() <= 2 * lim
+                    yh, nh = fc.apply(x, bool(flush))          # host pointers through pffastconv_apply
+                    assert nh == nw and np.array_equal(yh, got)
+                fc.close()
