@@ -75,15 +75,19 @@ __global__ void fastconv_scatter_kernel(const float* __restrict__ blocks, float*
 // observe (how many samples a call produces, src/pffastconv.c:156-166,204-210) is computed as before.
 constexpr int TD_THREADS = 256, TD_PER = 8, TD_TILE = TD_THREADS * TD_PER, TD_MAX_TAPS = 256;
 
+// STRIDE 2: interleaved complex samples filtered by a real filter = the same sum over every second float,
+// y[f] = sum_i c_i x[f + 2 i] — both complex modes of the reference (two real transforms per block, or one transform with
+// the zero-stuffed filter, src/pffastconv.c:84-106) are this on the float stream; they differ in the block schedule only.
+template <int STRIDE>
 __global__ void __launch_bounds__(TD_THREADS)
-fastconv_td_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ c, int flen8, int produced,
-                   int inputLen) {
+fastconv_td_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ c, int flen8, long produced,
+                   long inputLen) {
     extern __shared__ __attribute__((aligned(16))) float sx[];
     const int tid = threadIdx.x;
     const long o0 = (long)blockIdx.x * TD_TILE;
     const int outs = (produced - o0) < TD_TILE ? (int)(produced - o0) : TD_TILE;
-    const int need = outs + flen8 - 1;                 // produced + len - 1 <= inputLen (fc_schedule); the zero taps of the
-    for (int i = tid; i < TD_TILE + flen8 + 8; i += TD_THREADS)   // padding may point past the input: guarded
+    const int need = outs + STRIDE * (flen8 - 1);      // produced + STRIDE (len - 1) <= inputLen (fc_schedule); the zero taps of
+    for (int i = tid; i < TD_TILE + STRIDE * flen8 + 8; i += TD_THREADS)   // the padding may point past the input: guarded
         sx[i] = (i < need && o0 + i < inputLen) ? x[o0 + i] : 0.f;
     __syncthreads();
     const float* w = sx + tid * TD_PER;
@@ -91,16 +95,17 @@ fastconv_td_kernel(const float* __restrict__ x, float* __restrict__ y, const flo
 #pragma unroll
     for (int k = 0; k < TD_PER; ++k) acc[k] = 0.f;
     vec4<float> lo0 = *reinterpret_cast<const vec4<float>*>(w), lo1 = *reinterpret_cast<const vec4<float>*>(w + 4);
-    for (int j = 0; j < flen8; j += 8) {
-        const vec4<float> hi0 = *reinterpret_cast<const vec4<float>*>(w + j + 8);
-        const vec4<float> hi1 = *reinterpret_cast<const vec4<float>*>(w + j + 12);
+    constexpr int TAPS_PER_STEP = 8 / STRIDE;          // the window advances 8 floats per step
+    for (int j = 0, wo = 8; j < flen8; j += TAPS_PER_STEP, wo += 8) {
+        const vec4<float> hi0 = *reinterpret_cast<const vec4<float>*>(w + wo);
+        const vec4<float> hi1 = *reinterpret_cast<const vec4<float>*>(w + wo + 4);
         const float win[16] = {lo0.x, lo0.y, lo0.z, lo0.w, lo1.x, lo1.y, lo1.z, lo1.w,
                                hi0.x, hi0.y, hi0.z, hi0.w, hi1.x, hi1.y, hi1.z, hi1.w};
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
+        for (int jj = 0; jj < TAPS_PER_STEP; ++jj) {
             const float cj = c[j + jj];                // wave-uniform: scalar load
 #pragma unroll
-            for (int k = 0; k < TD_PER; ++k) acc[k] = __builtin_fmaf(cj, win[jj + k], acc[k]);
+            for (int k = 0; k < TD_PER; ++k) acc[k] = __builtin_fmaf(cj, win[STRIDE * jj + k], acc[k]);
         }
         lo0 = hi0; lo1 = hi1;
     }
@@ -208,16 +213,20 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     const int nblk = mode ? 2 * nbt : nbt;
     const int Nfft = s->Nfft;
     const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
-    if (mode == 0 && s->cplxFactor == 1 && s->filterLen <= TD_MAX_TAPS && g_variant != 30 && g_variant != 81) {
-        // short real filter: time domain (variant 81 = off)
+    const int taps = s->cplxFactor == 2 ? (s->filterLen + 1) / 2 : s->filterLen;   // the caller's filter length
+    if (taps <= TD_MAX_TAPS && g_variant != 30 && g_variant != 81) {
+        // short real filter: time domain (variant 81 = off); the complex modes are the stride-2 sum over the float stream
         if (!s->d_td) {
             PF_CHECK(hipMalloc((void**)&s->d_td, sizeof(float) * s->h_td.size()));
             PF_CHECK(hipMemcpy(s->d_td, s->h_td.data(), sizeof(float) * s->h_td.size(), hipMemcpyHostToDevice));
         }
         const int flen8 = (int)s->h_td.size();
-        const unsigned grid = (unsigned)(((long)produced + TD_TILE - 1) / TD_TILE);
-        const size_t lds = sizeof(float) * (TD_TILE + flen8 + 8);
-        hipLaunchKernelGGL(fastconv_td_kernel, dim3(grid), dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, produced, inputLen);
+        const bool cplx = mode == 1 || s->cplxFactor == 2;
+        const long out_f = mode == 1 ? 2L * produced : produced, in_f = mode == 1 ? 2L * inputLen : inputLen;
+        const unsigned grid = (unsigned)((out_f + TD_TILE - 1) / TD_TILE);
+        const size_t lds = sizeof(float) * (TD_TILE + (cplx ? 2 : 1) * flen8 + 8);
+        if (cplx) hipLaunchKernelGGL(fastconv_td_kernel<2>, dim3(grid), dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, out_f, in_f);
+        else hipLaunchKernelGGL(fastconv_td_kernel<1>, dim3(grid), dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, out_f, in_f);
         PF_CHECK(hipGetLastError());
         return 0;
     }

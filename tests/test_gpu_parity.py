@@ -634,3 +634,30 @@ def test_fastconv_short_filters(ref, taps):
                     yh, nh = fc.apply(x, bool(flush))          # host pointers through pffastconv_apply
                     assert nh == nw and np.array_equal(yh, got)
                 fc.close()
+
+
+@pytest.mark.parametrize("taps", [3, 16, 64, 255])
+@pytest.mark.parametrize("flags", [1, 1 | 16, 1 | 64, 1 | 16 | 64])
+def test_fastconv_short_filters_complex_io(ref, taps, flags):
+    """the complex-I/O modes (PFFASTCONV_CPLX_INP_OUT, with and without CPLX_SINGLE_FFT, with CORRELATION) on short
+    filters: stride-2 time-domain kernel; produced counts and values against the reference (which runs its FFT route)."""
+    rng = np.random.default_rng(taps + flags)
+    h = rng.uniform(-1, 1, taps).astype(np.float32)
+    for L in (taps + 1, 1500, 40000):
+        x = rng.uniform(-1, 1, 2 * L).astype(np.float32)
+        for flush in (1, 0):
+            yw, nw, bl = ref.fastconv(x, h, 0, flags, flush)
+            fc = pa.FastConv(h, 0, flags)
+            assert fc.block_len == bl
+            yd, nd = fc.apply(_dev(x), bool(flush))
+            assert nd == nw, (taps, L, flags, flush)
+            if nw:
+                hrev = h if flags & 64 else h[::-1]
+                xc = x[0::2].astype(np.float64) + 1j * x[1::2]
+                truth = np.correlate(xc, hrev.astype(np.float64), "valid")[:nw]
+                tr = np.empty(2 * nw); tr[0::2], tr[1::2] = truth.real, truth.imag
+                lim = max((tr.max() - tr.min()) / 1e5, 2e-6 * np.sqrt(taps) * max(1.0, np.abs(tr).max()))
+                got = yd.cpu().numpy()
+                assert np.abs(got - tr).max() <= lim, (taps, L, flags, flush)
+                assert np.abs(got - yw[:2 * nw]).max() <= 2 * lim
+            fc.close()
