@@ -68,12 +68,12 @@ __global__ void fastconv_scatter_kernel(const float* __restrict__ blocks, float*
 // ---- short filters: time domain ------------------------------------------------------------------------------------
 // The reference always goes through Nfft = max(32, 2 next_pow2(len - 1)) transforms.  For <= TD_MAX_TAPS taps that is two
 // transforms per (Nfft - len + 1) outputs of a kernel family that is latency-bound at these sizes (64 taps: 36
-// Gsamples/s); the same outputs  y[m] = sum_i c_i x[m + i]  (the circular product of :99-108 and :238-255 written
+// Gsamples/s, 512 taps: 77; this kernel: 378 and 84 - the crossover is near 550 taps); the same outputs  y[m] = sum_i c_i x[m + i]  (the circular product of :99-108 and :238-255 written
 // out: c_i = filter[len-1-i], or filter[i] with PFFASTCONV_CORRELATION) cost len FMAs each.  A workgroup stages
 // 2048 + len inputs in LDS, a thread owns 8 consecutive outputs and slides a 16-value register window over them, 8 taps
 // per step (two 16-byte LDS reads for 64 FMAs), the taps come through scalar loads.  The block schedule the caller can
 // observe (how many samples a call produces, src/pffastconv.c:156-166,204-210) is computed as before.
-constexpr int TD_THREADS = 256, TD_PER = 8, TD_TILE = TD_THREADS * TD_PER, TD_MAX_TAPS = 256;
+constexpr int TD_THREADS = 256, TD_PER = 8, TD_TILE = TD_THREADS * TD_PER, TD_MAX_TAPS = 512;
 
 // STRIDE 2: interleaved complex samples filtered by a real filter = the same sum over every second float,
 // y[f] = sum_i c_i x[f + 2 i] — both complex modes of the reference (two real transforms per block, or one transform with

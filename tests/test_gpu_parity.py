@@ -606,9 +606,9 @@ def test_multiwave_sizes_edge_batches_and_inplace(ref, dt):
         s.close(); rs.close()
 
 
-@pytest.mark.parametrize("taps", [1, 2, 7, 8, 9, 31, 64, 100, 255, 256, 257])
+@pytest.mark.parametrize("taps", [1, 2, 7, 8, 9, 31, 64, 100, 255, 256, 257, 511, 512, 513])
 def test_fastconv_short_filters(ref, taps):
-    """pffastconv with short filters (<= 256 taps take the time-domain kernel, 257 the FFT path): same number of samples
+    """pffastconv with short filters (<= 512 taps take the time-domain kernel, 513 the FFT path): same number of samples
     as the reference for flush / no flush (the block schedule is observable, src/pffastconv.c:156-166,204-210), values
     against the reference within its own test limit (tests/test_pffastconv.c:685) and against the direct float64 sum
     y[m] = sum_i x[m+i] hrev[i] (tests/test_pffastconv.c:175-213); convolution and PFFASTCONV_CORRELATION; signal lengths

@@ -4,7 +4,9 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pffft_amd as pa
 from bench_configs import timed
-for L, taps in ((1 << 26, 4096), (1 << 26, 1024), (1 << 26, 256), (1 << 26, 64)):
+import os
+pa.set_variant(int(os.environ.get('PFV', '0')))
+for L, taps in [(1 << 26, int(t)) for t in os.environ.get('TAPS', '4096,1024,256,64').split(',')]:
     x = torch.rand(L, device="cuda") * 2 - 1
     h = np.random.default_rng(0).uniform(-1, 1, taps).astype(np.float32)
     fc = pa.FastConv(h, 0, 0)
