@@ -22,6 +22,8 @@ struct FastConv {
     std::mutex mu;
     float* d_Hf = nullptr;
     float* d_Hc = nullptr;  // canonical-order filter spectrum * 1/Nfft for the fused kernel
+    // throughput regime (many blocks): the same outputs through LARGER internal blocks (better overlap-save efficiency)
+    PFFFT_Setup* st_big = nullptr; float* d_Hc_big = nullptr; int Nfft_big = 0;
     std::vector<float> h_td;  // y[m] = sum_i h_td[i] x[m + i]: the filter as the time-domain kernel applies it (zero padded to 8)
     float* d_td = nullptr;
     float* d_work = nullptr; size_t work_floats = 0;
@@ -149,7 +151,7 @@ static int fc_ensure_device(FastConv* s) {
 
 template <class C>
 static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
-                           hipStream_t st) {
+                           hipStream_t st, PFFFT_Setup* pst = nullptr, const float* d_Hc = nullptr) {
     auto k = fastconv_fused_kernel<C>;
     int rc = allow_big_lds(k, C::LDS_BYTES);
     if (rc) return rc;
@@ -159,11 +161,57 @@ static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, 
     size_t groups = ((size_t)nblk + C::T_PER_WG - 1) / C::T_PER_WG;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
-    Setup* ps = s->st;
+    Setup* ps = pst ? pst : s->st;
+    if (!d_Hc) d_Hc = s->d_Hc;
     unsigned* ctr = groups <= grid ? nullptr : ps->d_ctr + 2 * (ps->ctr_slot.fetch_add(1) % CTR_RING);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), C::LDS_BYTES, st, d_x, d_y, (const cx<float>*)s->d_Hc,
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), C::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
                        nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, ctr);
     PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Internal block length for the throughput regime.  What a caller can observe of the reference's blocks is only HOW MANY
+// samples a call produces (fc_schedule); the values are those of the exact convolution whatever the block length, so
+// when a call has many blocks the same `produced` outputs are computed with longer internal blocks: overlap-save
+// efficiency (Nfft - len + 1) / Nfft goes from ~0.5 (the reference's Nfft = 2 next_pow2(len-1), src/pffastconv.c:62-63)
+// to 0.75-0.94.  PFFASTCONV_HIP_NFFT=<n> forces a length (A/B), =0 switches this off.
+static int fc_big_nfft(const FastConv* s, long produced) {
+    static const int forced = [] { const char* e = getenv("PFFASTCONV_HIP_NFFT"); return e ? atoi(e) : -1; }();
+    if (forced == 0) return 0;
+    const int taps = s->filterLen;
+    // measured on MI355X (tools/fir_long.py, Gsamples/s on 2^26 samples): 600 taps 102 (reference Nfft 2048) -> 253 (8192),
+    // 1024 taps 77 -> 249, 2048 taps 142 -> 223, 4096 taps 160 -> 193 (16384); the time-domain kernel wins up to ~128 taps
+    const int want = forced > 0 ? forced : (taps <= 2048 ? 8192 : 16384);
+    if (want <= s->Nfft || want > 16384 || (want & (want - 1)) || want < 2 * taps) return 0;
+    if (forced > 0) return want;
+    if (taps <= 128) return 0;
+    const long bblk = (produced + (want - taps)) / (want - taps + 1);
+    return bblk >= num_cus() ? want : 0;                 // fewer blocks: latency regime, one reference-sized block per CU is faster
+}
+
+static int fc_ensure_big(FastConv* s, int Nfft_big) {
+    if (s->Nfft_big == Nfft_big) return 0;
+    if (s->st_big) { pffft_destroy_setup(s->st_big); s->st_big = nullptr; }
+    if (s->d_Hc_big) { (void)hipFree(s->d_Hc_big); s->d_Hc_big = nullptr; }
+    s->Nfft_big = 0;
+    s->st_big = pffft_new_setup(Nfft_big, PFFFT_REAL);
+    if (!s->st_big) { g_last_error = "pffastconv: internal setup failed"; return (int)hipErrorInvalidValue; }
+    std::vector<float> img((size_t)Nfft_big, 0.f);
+    const int flen = s->filterLen;
+    for (int i = 0; i < flen; ++i) img[(Nfft_big - i) & (Nfft_big - 1)] = s->h_td[i];   // :100-106 with the longer block
+    float* d_tmp = nullptr;
+    PF_CHECK(hipMalloc((void**)&d_tmp, sizeof(float) * Nfft_big));
+    PF_CHECK(hipMalloc((void**)&s->d_Hc_big, sizeof(float) * Nfft_big));
+    PF_CHECK(hipMemcpy(d_tmp, img.data(), sizeof(float) * Nfft_big, hipMemcpyHostToDevice));
+    int rc = transform_batch<float>(s->st_big, d_tmp, d_tmp, 1, PFFFT_FORWARD, 0, nullptr);
+    if (!rc) rc = zreorder_batch<float>(s->st_big, d_tmp, s->d_Hc_big, 1, PFFFT_FORWARD, nullptr);
+    if (!rc) {
+        hipLaunchKernelGGL(fastconv_scale_kernel, dim3(64), dim3(256), 0, nullptr, s->d_Hc_big, s->d_Hc_big, Nfft_big, 1.0f / (float)Nfft_big);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) rc = (int)hipErrorUnknown;
+    }
+    (void)hipFree(d_tmp);
+    if (rc) return rc;
+    s->Nfft_big = Nfft_big;
     return 0;
 }
 
@@ -213,6 +261,22 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     const int nblk = mode ? 2 * nbt : nbt;
     const int Nfft = s->Nfft;
     const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
+    if (mode == 0 && s->cplxFactor == 1 && g_variant != 30) {
+        const int nbig = fc_big_nfft(s, produced);
+        if (nbig) {
+            if ((rc = fc_ensure_big(s, nbig))) return rc;
+            const int bstep = nbig - s->filterLen + 1;
+            const int bblk = (int)(((long)produced + bstep - 1) / bstep);
+            const int blast = (int)(produced - (long)(bblk - 1) * bstep);
+            switch (nbig / 2) {
+                case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, s->st_big, s->d_Hc_big);
+                case 2048: return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, s->st_big, s->d_Hc_big);
+                case 4096: return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, s->st_big, s->d_Hc_big);
+                case 8192: return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, s->st_big, s->d_Hc_big);
+                default: break;
+            }
+        }
+    }
     const int taps = s->cplxFactor == 2 ? (s->filterLen + 1) / 2 : s->filterLen;   // the caller's filter length
     if (taps <= TD_MAX_TAPS && g_variant != 30 && g_variant != 81) {
         // short real filter: time domain (variant 81 = off); the complex modes are the stride-2 sum over the float stream
@@ -295,7 +359,8 @@ PF_EXPORT PFFASTCONV_Setup* pffastconv_new_setup(const float* filterCoeffs, int 
 PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
     if (!s) return;
     pffft_destroy_setup(s->st);
-    for (float* p : {s->d_Hf, s->d_Hc, s->d_td, s->d_work, s->d_x, s->d_y}) if (p) (void)hipFree(p);
+    if (s->st_big) pffft_destroy_setup(s->st_big);
+    for (float* p : {s->d_Hf, s->d_Hc, s->d_Hc_big, s->d_td, s->d_work, s->d_x, s->d_y}) if (p) (void)hipFree(p);
     s->magic = 0;
     delete s;
 }

@@ -661,3 +661,30 @@ def test_fastconv_short_filters_complex_io(ref, taps, flags):
                 assert np.abs(got - tr).max() <= lim, (taps, L, flags, flush)
                 assert np.abs(got - yw[:2 * nw]).max() <= 2 * lim
             fc.close()
+
+
+@pytest.mark.parametrize("taps", [129, 600, 1024, 2048, 4096, 5000])
+def test_fastconv_long_signals(ref, taps):
+    """Throughput regime (signals long enough for >= one internal block per CU): the same outputs are computed through
+    longer INTERNAL blocks (Nfft 8192 / 16384, pffastconv_impl.h fc_big_nfft) while the number of samples a call produces
+    follows the reference's block schedule exactly — flush and no flush — and the values meet the reference's FIR bar
+    against a float64 direct convolution (sampled windows) and against the reference on the whole signal."""
+    L = (1 << 22) + 12345
+    rng = np.random.default_rng(taps)
+    x = rng.uniform(-1, 1, L).astype(np.float32)
+    h = rng.uniform(-1, 1, taps).astype(np.float32)
+    fc = pa.FastConv(h, 0, 0)
+    xd = _dev(x)
+    for flush in (1, 0):
+        yw, nw, bl = ref.fastconv(x, h, 0, 0, flush)
+        assert fc.block_len == bl
+        yd, nd = fc.apply(xd, bool(flush))
+        assert nd == nw, (taps, flush)
+        got = yd.cpu().numpy()
+        lim = max((yw.max() - yw.min()) / 1e5, 2e-6 * np.sqrt(taps) * np.abs(yw).max())
+        assert np.abs(got - yw[:nw]).max() <= 2 * lim
+        for m0 in (0, 7000, nw // 2, nw - 3000):
+            seg = x[m0:m0 + 3000 + taps - 1].astype(np.float64)
+            truth = np.correlate(seg, h[::-1].astype(np.float64), "valid")[:3000]
+            assert np.abs(got[m0:m0 + 3000] - truth).max() <= lim, (taps, flush, m0)
+    fc.close()
