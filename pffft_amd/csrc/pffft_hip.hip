@@ -22,6 +22,7 @@
 #include "stock_plan.h"
 #include "stock_ct.h"
 #include "fft_aux.h"
+#include "fft_tiny.h"
 #include "pfdsp_mix.h"
 
 namespace pf {
@@ -733,6 +734,37 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     return 0;
 }
 
+// n = 16 / 32: one thread per transform (fft_tiny.h)
+template <typename T, int n>
+static int launch_tiny(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    constexpr int CPV = 2 * n * (int)sizeof(T) / 16;
+    const int waves = CPV >= 32 ? 2 : 4;
+    const size_t lds = (size_t)waves * 64 * (CPV + 1) * 16;
+    const size_t groups = (batch + 63) / 64;
+    size_t grid = (groups + waves - 1) / waves;
+    const size_t cap = (size_t)num_cus() * (LDS_MAX / lds > 8 ? 8 : LDS_MAX / lds);
+    if (grid > cap) grid = cap;
+    const bool real = s->transform == PFFFT_REAL, fwd = dir == PFFFT_FORWARD;
+    const cx<T>* twr = (const cx<T>*)s->d_twr;
+#define PF_TINY(D, R, I, O)                                                                                        \
+    do {                                                                                                           \
+        auto k = fft_tiny_kernel<T, n, D, R, I, O>;                                                                \
+        int rc = allow_big_lds(k, lds);                                                                            \
+        if (rc) return rc;                                                                                         \
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves * 64), lds, st, in, out, batch, twr);               \
+    } while (0)
+    if (!real) {
+        if (fwd) { if (ordered) PF_TINY(FWD, 0, 0, 0); else PF_TINY(FWD, 0, 0, 1); }
+        else { if (ordered) PF_TINY(BWD, 0, 0, 0); else PF_TINY(BWD, 0, 1, 0); }
+    } else {
+        if (fwd) { if (ordered) PF_TINY(FWD, 1, 0, 0); else PF_TINY(FWD, 1, 0, 1); }
+        else { if (ordered) PF_TINY(BWD, 1, 0, 0); else PF_TINY(BWD, 1, 1, 0); }
+    }
+#undef PF_TINY
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     if (!s || s->magic != MAGIC || s->is_double != (sizeof(T) == 8)) {
@@ -742,6 +774,10 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
     if (batch == 0) return 0;
     int rc = ensure_device<T>(s);
     if (rc) return rc;
+    if (g_variant != 91 && g_variant != 1) {   // one thread per transform for the minimum sizes (fft_tiny.h); variant 91 = off
+        if (s->n == 16) return launch_tiny<T, 16>(s, in, out, batch, dir, ordered, st);
+        if constexpr (sizeof(T) == 4) { if (s->n == 32) return launch_tiny<T, 32>(s, in, out, batch, dir, ordered, st); }
+    }
     if constexpr (sizeof(T) == 4) {
         if (s->kernel == K_C1024_F32 && g_variant != 1 && g_variant != 50 && batch < (1ull << 32))
             return launch_c1024(s, in, out, batch, dir, ordered, st);
