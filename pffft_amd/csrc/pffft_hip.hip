@@ -1204,6 +1204,7 @@ PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
     const pf::Setup* s = static_cast<const pf::Setup*>(setup);
     if (!s || s->magic != pf::MAGIC) return "invalid";
     if (pf::g_variant == 1) return "generic";
+    if (pf::g_variant != 91 && (s->n == 16 || (s->n == 32 && !s->is_double))) return "tiny";
     switch (s->kernel) {
         case pf::K_C1024_F32: return "c1024_f32";
         case pf::K_TILED: return "tiled";
