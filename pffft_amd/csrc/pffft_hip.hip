@@ -743,7 +743,9 @@ static int launch_tiny(Setup* s, const T* in, T* out, size_t batch, int dir, int
     const size_t groups = (batch + 63) / 64;
     size_t grid = (groups + waves - 1) / waves;
     const size_t cap = (size_t)num_cus() * (LDS_MAX / lds > 8 ? 8 : LDS_MAX / lds);
-    if (grid > cap) grid = cap;
+    // one group of 64 vectors per wavefront in hardware dispatch order measured faster than persistent waves with a static
+    // stride (256-byte vectors: 0.75-0.78 against 0.67-0.72; 128-byte vectors: equal); variant 93 = persistent (A/B)
+    if (grid > cap && g_variant == 93) grid = cap;
     const bool real = s->transform == PFFFT_REAL, fwd = dir == PFFFT_FORWARD;
     const cx<T>* twr = (const cx<T>*)s->d_twr;
 #define PF_TINY(D, R, I, O)                                                                                        \
