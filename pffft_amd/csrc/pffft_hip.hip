@@ -612,7 +612,19 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
             if (g_variant > 10 && g_variant < 20 && per_cu > g_variant - 10) per_cu = g_variant - 10;  // A/B: cap WGs per CU
             if (g_variant > 20 && g_variant < 30) per_cu = g_variant - 20;                             // A/B: force WGs per CU
             size_t grid = (size_t)num_cus() * per_cu;
+            // Small vectors: a grid of 8x (<= 20 KiB per vector) or 16x (<= 4 KiB) the resident workgroups - still a static
+            // stride, the later workgroups start as the first ones retire - measured (tools/stock_bench2.py, fraction of
+            // 8 TB/s, 1x -> 8x / 16x): N = 96 .. 480 complex float 0.63-0.69 -> 0.71-0.77, N = 640 .. 2400 0.60-0.64 ->
+            // 0.65-0.70, real and double alike; vectors above 20 KiB lose (N = 4000: 0.62 -> 0.60) and keep exactly the
+            // resident set.  One group per workgroup (variant 94) is slower (0.32-0.66).
+            // PFFFT_HIP_STOCK_GRIDMUL=<m> overrides the factor (A/B).
+            static const int gridmul_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_GRIDMUL"); return e ? atoi(e) : 0; }();
+            if (g_variant == 94) grid = groups;
+            else if (gridmul_env > 0) grid *= (size_t)gridmul_env;
+            else if ((size_t)sp.n * sizeof(cx<T>) <= 4096) grid *= 16;
+            else if ((size_t)sp.n * sizeof(cx<T>) <= 20480) grid *= 8;
             if (grid > groups) grid = groups;
+            if (grid > 0x7fffffffu) grid = 0x7fffffffu;
             unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
             hipLaunchKernelGGL(cf, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch, twp,
                                (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
