@@ -18,7 +18,8 @@ DSP_DEPS = [DSP_SRC, os.path.join(CSRC, "pfdsp_mix.h"), os.path.join(HERE, "..",
 
 
 def _deps():
-    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "pfdsp_hip.hip"]
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+           if f.endswith((".h", ".hip")) and f != "pfdsp_hip.hip"]
     out.append(os.path.join(HERE, "..", "include", "pffft_hip.h"))
     return out
 
