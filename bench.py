@@ -6,17 +6,25 @@ complex-float forward FFTs — configs[1] ("N=1024 complex float fwd+inv, batch=
 A "step" is one pass of the hot path (pffft_transform semantics, internal-layout spectrum) over the
 whole device-resident batch = ONE kernel launch through the C ABI (pffft_hip_transform_batch).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scaling weak|strong]
 
-Multi-GPU: the batch shards across ranks with no data-path collective; every rank
-transforms its own 2^20 vectors (weak scaling); RCCL is used only to combine the final number
-(all_reduce MAX of elapsed, SUM of transforms), bracketed by barriers.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU
+over RCCL; it fails loudly when fewer than N GPUs are visible or when WORLD_SIZE disagrees with --gpus.
 
-Prints ONE JSON line on rank 0.  `value` = whole-job M transforms/s with inputs resident in HBM.
-`roofline` prices the kernel's ALGORITHMIC bytes (16 KiB per transform: 8 KiB read + 8 KiB written,
-SURVEY.md §8d) against 8 TB/s.  `cpu_baseline` times the real reference (oracle/_ref) on the host
-cores of this box on a bounded sample of the same workload (test infrastructure, never the product).
+Multi-GPU: the batch shards across ranks with no data-path collective; RCCL only
+combines the final number (all_reduce MAX of elapsed, SUM of transforms), bracketed by barriers.
+  --scaling weak   (default) every rank transforms the config's per-GPU batch
+  --scaling strong the config's TOTAL batch (c5: 2^23, BASELINE configs[4]) is split over the ranks and
+                   transformed IN PLACE (in == out is legal, include/pffft/pffft.h:157): at 1 GPU 2^23
+                   complex-double vectors are 128 GiB, out of place would need 256 GiB of the 288 GB
+
+Prints ONE JSON line on rank 0.  `value` = whole-job throughput with inputs resident in HBM.
+`roofline` prices the dominant kernel's ALGORITHMIC bytes (2 x vector bytes per transform,
+8 B per FIR output sample) against 8 TB/s.  `cpu_baseline` times the real reference (oracle/_ref) on the
+host cores of this box on a bounded sample of the same workload (test infrastructure, never the product).
+At N = 1 the default line also carries `configs`: every other BASELINE config at its stated size, each with
+its own `roofline` and `cpu_baseline`; at N > 1 it carries the C5 sharded config, weak and strong.
 """
 from __future__ import annotations
 
@@ -24,6 +32,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,218 +42,460 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_FFT = 1024
-BYTES_PER_TRANSFORM = 2 * N_FFT * 2 * 4      # 8 KiB in + 8 KiB out (algorithmic, twiddles not counted)
-FLOPS_PER_TRANSFORM = 5 * N_FFT * 10         # 5 N log2 N (benchmarks/bench_pffft.c:606 convention)
 HBM_PEAK = 8.0e12                            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+REAL, COMPLEX = 0, 1
+
+# BASELINE.json configs; bytes/flops per unit from SURVEY.md §8(d) (5 N log2 N complex, 2.5 N log2 N real:
+# benchmarks/bench_pffft.c:606)
+CONFIGS = {
+    "c2": dict(N=1024, tr=COMPLEX, dtype="f32", batch_log2=20, total_log2=23, bytes=16384, flops=51200,
+               name="BASELINE configs[1]: N=1024 complex float forward"),
+    "c3": dict(N=16384, tr=REAL, dtype="f32", batch_log2=16, total_log2=19, bytes=131072, flops=573440,
+               name="BASELINE configs[2]: N=16384 real float forward"),
+    "c5": dict(N=1024, tr=COMPLEX, dtype="f64", batch_log2=20, total_log2=23, bytes=32768, flops=51200,
+               name="BASELINE configs[4]: N=1024 complex double forward"),
+}
+FIR = dict(signal_log2=20, taps=4096, long_log2=26,
+           name="BASELINE configs[3]: pffastconv FIR, signal 2^20 real float, 4096 taps, overlap-save")
 
 
-def cpu_baseline(sample_log2: int, target_s: float):
-    """Time oracle/_ref (the reference's own SIMD path) on this host: loop of pffft_transform calls."""
+def _np_dtype(tag):
+    return np.float64 if tag == "f64" else np.float32
+
+
+def _host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def _cpubase():
     from oracle import ref as oref
     so = os.path.join(ROOT, "oracle", "_ref", "libcpubase.so")
     if not (oref.available() and os.path.exists(so)):
-        return None
+        return None, None
     lib = C.CDLL(so)
     lib.cpu_baseline_run.restype = C.c_double
     lib.cpu_baseline_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_long, C.c_int, C.c_int]
-    R = oref.get()
+    if hasattr(lib, "cpu_baseline_fir"):
+        lib.cpu_baseline_fir.restype = C.c_double
+        lib.cpu_baseline_fir.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                         C.POINTER(C.c_int)]
+    return lib, oref.get()
+
+
+def cpu_baseline(cfg, sample_log2: int, target_s: float):
+    """Time oracle/_ref (the reference's own SIMD path) on this host: loop of pffft_transform calls on the
+    host threads that measure fastest, sharing one setup (include/pffft/pffft.h:102-105)."""
+    lib, R = _cpubase()
+    if lib is None:
+        return None
+    dt = _np_dtype(cfg["dtype"])
+    a = R.api(dt)
+    N, tr = cfg["N"], cfg["tr"]
+    vs = N * (2 if tr == COMPLEX else 1)
     batch = 1 << sample_log2
-    a = R.f32
-    x = a.empty(batch * 2 * N_FFT)
-    x[:] = np.random.default_rng(2).uniform(-1, 1, x.size).astype(np.float32)
-    y = a.empty(batch * 2 * N_FFT)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    x = a.empty(batch * vs)
+    x[:] = np.random.default_rng(2).uniform(-1, 1, x.size).astype(dt)
+    y = a.empty(batch * vs)
+    cores = _host_cores()
+    isd = int(dt == np.float64)
 
     def run(threads, reps):
-        return lib.cpu_baseline_run(N_FFT, 1, 0, 0, 0, x.ctypes.data, y.ctypes.data, batch, reps, threads)
+        return lib.cpu_baseline_run(N, tr, isd, 0, 0, x.ctypes.data, y.ctypes.data, batch, reps, threads)
 
     run(min(cores, 8), 1)  # warm-up (page faults, caches)
-    t1 = run(1, 2)
-    one_thread = 2 * batch / t1
+    t1 = run(1, 1)
+    one_thread = batch / t1
     # the affinity mask can overstate what a container may use: pick the thread count that is
     # actually fastest on a short calibration, then spend the time budget there
     cands = sorted({c for c in (8, 16, 32, 64, 96, 128, 192, 256, cores) if c <= cores} | {min(cores, 4)})
     best_t, best_rate = 1, one_thread
     for th in cands:
-        r = 4
+        r = 2
         rate = r * batch / run(th, r)
         if rate > best_rate:
             best_t, best_rate = th, rate
-    cores = best_t
-    # spend ~target_s in chunks (the sustained rate under full load is lower than a short calibration suggests)
     chunk = max(1, int(0.5 * best_rate / batch))
     reps, tall = 0, 0.0
     while tall < target_s and reps < 1000000:
-        tall += run(cores, chunk)
+        tall += run(best_t, chunk)
         reps += chunk
-    all_cores = batch * reps / tall
+    rate = batch * reps / tall
     return {
-        "value": round(all_cores / 1e6, 4), "unit": "M transforms/s", "cores": cores, "kind": "reference",
-        "sample": f"{reps} x 2^{sample_log2} transforms (N=1024 cplx f32 fwd, pffft_transform loop, "
-                  f"{tall:.1f} s wall, {cores} threads sharing one setup)",
+        "value": round(rate / 1e6, 4), "unit": "M transforms/s", "cores": best_t, "kind": "reference",
+        "sample": f"{reps} x 2^{sample_log2} transforms (N={N} {'cplx' if tr else 'real'} {cfg['dtype']} fwd, "
+                  f"pffft{'d' if isd else ''}_transform loop, {tall:.1f} s wall, {best_t} threads sharing one setup)",
         "one_thread_value": round(one_thread / 1e6, 4), "simd_arch": a.simd_arch().decode(),
-        "gflops": round(all_cores * FLOPS_PER_TRANSFORM / 1e9, 2),
+        "gflops": round(rate * cfg["flops"] / 1e9, 2),
     }
+
+
+def cpu_baseline_fir(x: np.ndarray, h: np.ndarray, target_s: float):
+    lib, R = _cpubase()
+    if lib is None or not hasattr(lib, "cpu_baseline_fir"):
+        return None
+    a = R.f32
+    xx, hh = a.aligned(x), a.aligned(h)
+    cores = _host_cores()
+    prod = C.c_int(0)
+
+    def run(threads, reps):
+        y = a.empty(threads * xx.size)
+        return lib.cpu_baseline_fir(hh.ctypes.data, hh.size, xx.ctypes.data, xx.size, y.ctypes.data, reps, threads,
+                                    C.byref(prod))
+
+    t1 = run(1, 2) / 2
+    n_out = prod.value
+    best_t, best_rate = 1, n_out / t1
+    for th in sorted({c for c in (8, 16, 32, 64, 128, cores) if c <= cores}):
+        rate = th * 2 * n_out / run(th, 2)
+        if rate > best_rate:
+            best_t, best_rate = th, rate
+    reps = max(2, int(target_s * best_rate / (best_t * n_out)))
+    t = run(best_t, reps)
+    rate = best_t * reps * n_out / t
+    return {"value": round(rate / 1e9, 4), "unit": "G output samples/s", "cores": best_t, "kind": "reference",
+            "sample": f"{best_t} threads x {reps} calls of pffastconv_apply on the 2^{FIR['signal_log2']}-sample signal "
+                      f"({FIR['taps']} taps, own setup per thread, {t:.1f} s wall)",
+            "one_thread_value": round(n_out / t1 / 1e9, 4), "one_call_ms_one_thread": round(t1 * 1e3, 3)}
+
+
+# --------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    if args.backend == "nccl":
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} asked, {have} GPU(s) visible on this box — refusing to "
+                             "report a multi-GPU number from fewer devices")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Timer:
+    """HIP events on the launch stream (torch's current stream is the stream the C ABI launches on)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+
+    def __call__(self, fn, reps, warm=1):
+        t = self.torch
+        for _ in range(warm):
+            fn()
+        t.cuda.synchronize()
+        a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        t.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / reps
+
+
+def roofline(alg_bytes_per_launch, kernel_s, traffic=None):
+    ach = alg_bytes_per_launch / kernel_s
+    return {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK, 4), "traffic": traffic, "kernel_ms": round(kernel_s * 1e3, 4),
+            "algorithmic_bytes_per_launch": int(alg_bytes_per_launch)}
+
+
+def _traffic(key):
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc
+    try:
+        return json.load(open(p)).get(key)
+    except Exception:
+        return None
+
+
+def make_input(torch, dev, batch, vec_scalars, tdt, seed):
+    """Uniform [-1, 1) from torch's counter-based (Philox) generator, generated on the device, in place."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    x = torch.empty(batch, vec_scalars, device=dev, dtype=tdt)
+    x.uniform_(-1.0, 1.0, generator=gen)
+    return x
+
+
+def fft_config_run(torch, pa, dev, cfg, batch, steps, warmup, in_place, dist, rank):
+    """One FFT config on this rank's shard: W warm-up + K timed steps inside the barrier bracket.
+    Returns (elapsed_s of this rank, kernel_s from HIP events, kernel name, parity)."""
+    from pffft_amd.sharding import timed_steps
+    dt = _np_dtype(cfg["dtype"])
+    tdt = torch.float64 if cfg["dtype"] == "f64" else torch.float32
+    setup = pa.Setup(cfg["N"], cfg["tr"], dt)
+    x = make_input(torch, dev, batch, setup.vec_scalars, tdt, seed=2 + rank)
+    y = x if in_place else torch.empty_like(x)
+    # parity spot check against the real reference when it travelled (outside the timed region; tests/ are the gate)
+    parity = None
+    idx = sorted({0, 1, batch // 2, batch - 1})
+    x_keep = x[idx].cpu().numpy()
+
+    def step():
+        setup.transform_batch(x, y, pa.FORWARD, ordered=False)
+
+    if not in_place:
+        step()
+        torch.cuda.synchronize()
+        try:
+            from oracle import ref as oref
+            if oref.available():
+                rs = oref.get().setup(cfg["N"], cfg["tr"], dt)
+                want = rs.batch(x_keep, oref.FORWARD, False)
+                got = y[idx].cpu().numpy()
+                parity = float(max(np.abs(got[i] - want[i]).max() / np.abs(want[i]).max() for i in range(len(idx))))
+                rs.close()
+        except Exception as e:
+            parity = f"unchecked: {e}"
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    count = [0]
+
+    def timed_step():
+        if count[0] == warmup:
+            e0.record()
+        step()
+        count[0] += 1
+        if count[0] == warmup + steps:
+            e1.record()
+
+    elapsed = timed_steps(timed_step, steps, warmup, dist, torch.cuda.synchronize)
+    kernel_s = e0.elapsed_time(e1) * 1e-3 / steps
+    kname = pa.kernel_name(setup)
+    setup.close()
+    del x, y
+    torch.cuda.empty_cache()
+    return elapsed, kernel_s, kname, parity
+
+
+def fir_config(torch, pa, dev, timer, cpu_seconds):
+    """BASELINE configs[3].  The single 2^20-sample call is latency-bound (255 blocks); the throughput regime is
+    measured on (i) a batch of independent 2^20-sample signals through pffastconv_hip_apply_batch and (ii) one
+    2^26-sample signal — `roofline` is (ii): 8 B per output sample (read x once, write y once)."""
+    taps, L = FIR["taps"], 1 << FIR["signal_log2"]
+    h = np.random.default_rng(4).uniform(-1, 1, taps).astype(np.float32)
+    out = {"workload": FIR["name"]}
+    fc = pa.FastConv(h, 0, 0)
+    sig = make_input(torch, dev, 1, L, torch.float32, seed=4).reshape(-1)
+    y = torch.empty_like(sig)
+    t = timer(lambda: fc.apply(sig, True, out=y), 200, warm=3)
+    n_out = L - taps + 1
+    out["single_call_us"] = round(t * 1e6, 2)
+    out["single_call_Gsamples_per_s"] = round(n_out / t / 1e9, 2)
+    out["single_call_frac"] = round(8 * n_out / t / HBM_PEAK, 4)
+    # parity of the same call against the real reference (spot check; tests/ are the gate)
+    x_host = sig.cpu().numpy()
+    try:
+        from oracle import ref as oref
+        if oref.available():
+            yw, nw, _ = oref.get().fastconv(x_host, h, 0, 0, 1)
+            got = y[:nw].cpu().numpy()
+            out["parity_max_err_over_range"] = float(np.abs(got - yw).max() / (yw.max() - yw.min()))
+    except Exception as e:
+        out["parity_max_err_over_range"] = f"unchecked: {e}"
+    if hasattr(fc, "apply_batch"):
+        nsig = 256
+        xs = make_input(torch, dev, nsig, L, torch.float32, seed=5)
+        ys = torch.empty_like(xs)
+        t = timer(lambda: fc.apply_batch(xs, True, out=ys), 20, warm=2)
+        out["batch_signals"] = nsig
+        out["batch_Gsamples_per_s"] = round(nsig * n_out / t / 1e9, 2)
+        out["batch_frac"] = round(8 * nsig * n_out / t / HBM_PEAK, 4)
+        del xs, ys
+    Ll = 1 << FIR["long_log2"]
+    xl = make_input(torch, dev, 1, Ll, torch.float32, seed=6).reshape(-1)
+    yl = torch.empty_like(xl)
+    t = timer(lambda: fc.apply(xl, True, out=yl), 10, warm=2)
+    nl = Ll - taps + 1
+    out["value"] = round(nl / t / 1e9, 2)
+    out["unit"] = "G output samples/s"
+    out["long_signal"] = f"2^{FIR['long_log2']} samples, {taps} taps"
+    out["roofline"] = roofline(8 * nl, t)
+    fc.close()
+    del xl, yl, sig, y
+    torch.cuda.empty_cache()
+    cb = cpu_baseline_fir(x_host, h, cpu_seconds) if cpu_seconds > 0 else None
+    out["cpu_baseline"] = cb if cb else {"value": None, "unit": "G output samples/s", "cores": 0, "kind": "reference",
+                                         "sample": "oracle/_ref not present on this box"}
+    return out
+
+
+def fake_main(args, world, rank):
+    """Harness self-test on CPU (tests/test_dist.py): same spawn path, gloo, a host stand-in step — the transform
+    itself has no CPU implementation in the product."""
+    import torch
+    import torch.distributed as dist
+    from pffft_amd.sharding import combine, timed_steps
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    units = 1000.0
+    x = np.random.default_rng(rank).standard_normal((64, 64))
+    el = timed_steps(lambda: np.fft.fft(x, axis=1), args.steps, args.warmup, dist if world > 1 else None, None)
+    el, tot = combine(el, units, dist if world > 1 else None, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "harness self-test (no transform ran)", "value": tot * args.steps / el, "unit": "units/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "selftest": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-log2", type=int, default=20, help="transforms per GPU = 2^this (default 1M)")
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (default: >= 1 s of timed region on c2)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--batch-log2", type=int, default=None, help="override: transforms per GPU = 2^this (weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-extras", action="store_true", help="skip the inverse / ordered side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="headline line only: skip the other configs / side rates")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import torch
-    import pffft_amd as pa
-
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if args.selftest_cpu:
+        return fake_main(args, world, rank)
+
+    import torch
+    import pffft_amd as pa
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (local_rank {local_rank}, {torch.cuda.device_count()} visible)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    from pffft_amd.sharding import combine, shard_range
+    timer = Timer(torch)
+    cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
 
-    batch = 1 << args.batch_log2
-    setup = pa.Setup(N_FFT, pa.COMPLEX, np.float32)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(2 + rank)
-    x = torch.rand(batch, 2 * N_FFT, device=dev, generator=gen) * 2 - 1   # uniform [-1, 1), generated on device
-    y = torch.empty_like(x)
-
-    def step():
-        setup.transform_batch(x, y, pa.FORWARD, ordered=False)
-
-    # ---- parity spot check (outside the timed region) against the real reference when it travelled ----
-    parity = None
-    step()
-    torch.cuda.synchronize()
-    try:
-        from oracle import ref as oref
-        if oref.available():
-            rs = oref.get().setup(N_FFT, oref.COMPLEX, np.float32)
-            idx = [0, 1, batch // 2, batch - 1]
-            want = rs.batch(x[idx].cpu().numpy(), oref.FORWARD, False)
-            got = y[idx].cpu().numpy()
-            parity = float(np.abs(got - want).max() / np.abs(want).max())
-    except Exception as e:  # the checker is optional here; tests/ are the parity gate
-        parity = f"unchecked: {e}"
-
-    # W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize on both sides
-    # (pffft_amd/sharding.py); HIP events on the launch stream give the kernel's own average duration.
-    from pffft_amd.sharding import combine, timed_steps
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    count = [0]
-
-    def timed_step():
-        if count[0] == args.warmup:
-            e0.record()
-        step()
-        count[0] += 1
-        if count[0] == args.warmup + args.steps:
-            e1.record()
-
-    elapsed = timed_steps(timed_step, args.steps, args.warmup, dist, torch.cuda.synchronize)
-    kernel_s = e0.elapsed_time(e1) * 1e-3 / args.steps
-    elapsed, total = combine(elapsed, float(batch), dist, dev)
-
-    extras = {}
-    if not args.no_extras and rank == 0 and world == 1:   # side measurements only in the single-GPU run: no rank waits on another
-        def t_of(fn, reps=5):
-            fn(); torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(reps):
-                fn()
-            b.record(); torch.cuda.synchronize()
-            return a.elapsed_time(b) * 1e-3 / reps
-        for name, d, o in (("fwd_ordered", pa.FORWARD, True), ("inv_unordered", pa.BACKWARD, False),
-                           ("inv_ordered", pa.BACKWARD, True)):
-            ts = t_of(lambda: setup.transform_batch(x, y, d, ordered=o))
-            extras[name + "_Mtps"] = round(batch / ts / 1e6, 2)
-        ts = t_of(lambda: y.copy_(x))
-        extras["torch_copy_GBps"] = round(batch * BYTES_PER_TRANSFORM / ts / 1e9, 1)
-        # the other BASELINE.json configs (parity-test cases, reported here as side measurements only): fraction of the
-        # 8 TB/s HBM roofline on algorithmic bytes (2 x vector bytes per transform), and the C4 FIR call time
-        try:
-            del_later = []
-            def side(N, tr, dtype, b):
-                st = pa.Setup(N, tr, dtype)
-                tdt = torch.float32 if dtype == np.float32 else torch.float64
-                xi = torch.rand(b, st.vec_scalars, device=dev, dtype=tdt) * 2 - 1
-                yo = torch.empty_like(xi)
-                tt = t_of(lambda: st.transform_batch(xi, yo, pa.FORWARD, ordered=False))
-                fr = 2 * xi.numel() * xi.element_size() / tt / HBM_PEAK
-                st.close(); del xi, yo
-                return round(fr, 4), round(b / tt / 1e6, 3)
-            extras["c3_real16384_f32_fwd_frac"], extras["c3_Mtps"] = side(16384, pa.REAL, np.float32, 1 << 14)
-            extras["c5_cplx1024_f64_fwd_frac"], extras["c5_Mtps"] = side(1024, pa.COMPLEX, np.float64, 1 << 18)
-            sig = torch.rand(1 << 20, device=dev) * 2 - 1
-            taps = np.random.default_rng(4).uniform(-1, 1, 4096).astype(np.float32)
-            fc = pa.FastConv(taps, 0, 0)
-            yo = torch.empty_like(sig)
-            extras["c4_fir_us_per_call"] = round(t_of(lambda: fc.apply(sig, True, out=yo), reps=50) * 1e6, 2)
-            fc.close(); del sig, yo
-            torch.cuda.empty_cache()
-        except Exception as e:
-            extras["side_configs_error"] = str(e)[:200]
-        # SURVEY.md §8 row f-4: the PFDSP mixer fused into the load stage of the same transform, and the mixer alone
-        ts = t_of(lambda: setup.shift_transform_batch(x, 0.0137, 0.4, out=y, ordered=False))
-        extras["shift_fused_fwd_Mtps"] = round(batch / ts / 1e6, 2)
-        try:
-            from pffft_amd import pfdsp
-            xc, yc = x.view(torch.complex64).reshape(-1), y.view(torch.complex64).reshape(-1)
-            ts = t_of(lambda: pfdsp.shift_device(xc, 0.0137, 0.4, out=yc))
-            extras["mixer_GBps"] = round(xc.numel() * 16 / ts / 1e9, 1)
-        except Exception as e:  # the mixer library is its own .so; its absence must not hide the headline
-            extras["mixer_GBps"] = None
-            extras["mixer_error"] = str(e)[:200]
-
-    if rank == 0:
-        tps = total * args.steps / elapsed
-        achieved = batch * BYTES_PER_TRANSFORM / kernel_s
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("c1024_fwd_unordered_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "M transforms/s, batched N=1024 complex-float forward FFT (pffft_transform semantics)",
-            "value": round(tps / 1e6, 3), "unit": "M transforms/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "gflops": round(tps * FLOPS_PER_TRANSFORM / 1e9, 1),
-            "config": {"workload": "BASELINE configs[1]: N=1024 complex float forward, batch=2^%d per GPU, "
-                                   "device-resident, out-of-place, internal-layout spectrum" % args.batch_log2,
-                       "kernel": pa.kernel_name(setup), "batch_per_gpu": batch, "sharding": "batch-split, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-                         "kernel_ms": round(kernel_s * 1e3, 4), "algorithmic_bytes_per_launch": batch * BYTES_PER_TRANSFORM},
+    def run_fft(key, scaling, steps, warmup, batch_log2=None):
+        cfg = CONFIGS[key]
+        if scaling == "strong":
+            total = 1 << cfg["total_log2"]
+            _, batch = shard_range(total, rank, world)
+            in_place = True
+        else:
+            batch = 1 << (batch_log2 if batch_log2 is not None else cfg["batch_log2"])
+            in_place = False
+        el, ks, kname, parity = fft_config_run(torch, pa, dev, cfg, batch, steps, warmup, in_place, dist, rank)
+        el, tot = combine(el, float(batch), dist, dev)
+        tps = tot * steps / el
+        return {
+            "value": round(tps / 1e6, 3), "unit": "M transforms/s", "ms_per_step": round(el / steps * 1e3, 4),
+            "steps": steps, "scaling": scaling, "dtype": cfg["dtype"], "gflops": round(tps * cfg["flops"] / 1e9, 1),
+            "workload": f"{cfg['name']}, batch={'2^%d total / %d GPU(s), in place' % (cfg['total_log2'], world) if scaling == 'strong' else '2^%d per GPU, out of place' % int(np.log2(batch))}, "
+                        "device-resident, internal-layout spectrum",
+            "kernel": kname, "batch_per_gpu": batch,
+            "roofline": roofline(batch * cfg["bytes"], ks, _traffic(key + "_bytes_per_launch")),
             "parity_max_rel_err_vs_reference": parity,
         }
+
+    if args.config == "c4":
+        if world > 1:
+            raise SystemExit("bench.py: c4 (one 8 MiB signal) does not shard: replicas only (DESIGN.md §5)")
+        res = fir_config(torch, pa, dev, timer, cpu_s)
+        line = {"metric": "G output samples/s, pffastconv overlap-save FIR, 4096 taps", "value": res["value"],
+                "unit": res["unit"], "n_gpus": 1, "steps": 10, "warmup": 2,
+                "ms_per_step": res["roofline"]["kernel_ms"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": res.pop("workload")}}
+        line.update(res)
+        print(json.dumps(line), flush=True)
+        return
+
+    head = run_fft(args.config, args.scaling, args.steps, args.warmup, args.batch_log2)
+    cfg = CONFIGS[args.config]
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "M transforms/s, batched N=%d %s-%s forward FFT (pffft_transform semantics)" % (
+                cfg["N"], "complex" if cfg["tr"] else "real", "float" if cfg["dtype"] == "f32" else "double"),
+            "value": head["value"], "unit": "M transforms/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": cfg["dtype"],
+            "data": "synthetic", "gflops": head["gflops"],
+            "config": {"workload": head["workload"], "kernel": head["kernel"], "batch_per_gpu": head["batch_per_gpu"],
+                       "sharding": "batch-split, no data-path collective; RCCL for the final MAX/SUM only"},
+            "roofline": head["roofline"], "parity_max_rel_err_vs_reference": head["parity_max_rel_err_vs_reference"],
+        }
+    extras, configs = {}, {}
+    if not args.no_extras and args.config == "c2" and args.scaling == "weak":
+        if world == 1:
+            # side rates of the headline kernel family + every other BASELINE config at its stated size
+            setup = pa.Setup(1024, COMPLEX, np.float32)
+            b = 1 << 20
+            x = make_input(torch, dev, b, 2048, torch.float32, seed=2)
+            y = torch.empty_like(x)
+            for name, d, o in (("fwd_ordered", pa.FORWARD, True), ("inv_unordered", pa.BACKWARD, False),
+                               ("inv_ordered", pa.BACKWARD, True)):
+                ts = timer(lambda: setup.transform_batch(x, y, d, ordered=o), 20)
+                extras[name + "_Mtps"] = round(b / ts / 1e6, 2)
+            extras["torch_copy_GBps"] = round(b * 16384 / timer(lambda: y.copy_(x), 20) / 1e9, 1)
+            ts = timer(lambda: setup.shift_transform_batch(x, 0.0137, 0.4, out=y, ordered=False), 20)
+            extras["shift_fused_fwd_Mtps"] = round(b / ts / 1e6, 2)
+            try:
+                from pffft_amd import pfdsp
+                xc, yc = x.view(torch.complex64).reshape(-1), y.view(torch.complex64).reshape(-1)
+                extras["mixer_GBps"] = round(xc.numel() * 16 / timer(lambda: pfdsp.shift_device(xc, 0.0137, 0.4, out=yc), 20) / 1e9, 1)
+            except Exception as e:  # the mixer library is its own .so; its absence must not hide the headline
+                extras["mixer_error"] = str(e)[:200]
+            setup.close()
+            del x, y
+            torch.cuda.empty_cache()
+            for key, st in (("c3", 60), ("c5", 30)):
+                try:
+                    configs[key] = run_fft(key, "weak", st, 3)
+                    if cpu_s > 0:
+                        cb = cpu_baseline(CONFIGS[key], 10 if key == "c3" else 14, min(cpu_s, 5.0))
+                        configs[key]["cpu_baseline"] = cb if cb else {"value": None, "unit": "M transforms/s", "cores": 0,
+                                                                      "kind": "reference", "sample": "oracle/_ref not present"}
+                except Exception as e:
+                    configs[key] = {"error": str(e)[:300]}
+            try:
+                configs["c5_strong_1gpu"] = run_fft("c5", "strong", 4, 1)
+            except Exception as e:
+                configs["c5_strong_1gpu"] = {"error": str(e)[:300]}
+            try:
+                configs["c4"] = fir_config(torch, pa, dev, timer, min(cpu_s, 5.0))
+            except Exception as e:
+                configs["c4"] = {"error": str(e)[:300]}
+        else:
+            # BASELINE configs[4]: the double-precision config sharded over the same ranks, weak and strong
+            for name, sc, st in (("c5_weak", "weak", 30), ("c5_strong", "strong", 8)):
+                configs[name] = run_fft("c5", sc, st, 2)   # collective inside: every rank runs it
+    if rank == 0:
         out.update(extras)
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(15, args.cpu_seconds)
+        if configs:
+            out["configs"] = configs
+        if world == 1 and cpu_s > 0:
+            cb = cpu_baseline(cfg, 15 if cfg["N"] <= 1024 else 10, cpu_s)
             out["cpu_baseline"] = cb if cb else {"value": None, "unit": "M transforms/s", "cores": 0, "kind": "reference",
                                                  "sample": "oracle/_ref not present on this box"}
         print(json.dumps(out), flush=True)

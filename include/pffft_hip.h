@@ -13,9 +13,10 @@
  *
  * Pointer rule for PART 1: `float*` / `double*` arguments may be ordinary host pointers (staged
  * through the device: correct, PCIe-bound) or device / managed pointers (used in place).  There is
- * no CPU arithmetic path in this library: without a usable HIP device every transform entry
- * reports the failure on stderr and aborts (set PFFFT_HIP_NO_ABORT=1 to get NaN-filled output
- * instead).  `work` is accepted and ignored (reference: scratch of N / 2N scalars or NULL,
+ * no CPU arithmetic path in this library: without a usable HIP device (or on any HIP error) a
+ * transform entry FAILS SOFT — one line on stderr, the output vector filled with NaN, the failure
+ * counted in pffft_hip_error_count() and described by pffft_hip_last_error(); PFFFT_HIP_ABORT=1 in
+ * the environment turns that into abort().  `work` is accepted and ignored (reference: scratch of N / 2N scalars or NULL,
  * include/pffft/pffft.h:137-142).
  */
 #ifndef PFFFT_HIP_H
@@ -93,7 +94,14 @@ void pffastconv_free(void *);
 int pffastconv_simd_size(void);
 
 /* ------------------------------------------------- PART 2: batched / device extension -------- */
-/* All return 0 on success, otherwise a hipError_t value (pffft_hip_last_error() has the text).
+/* Concurrency bounds of the batched entries.  (i) A setup binds to the HIP device that is current at its first
+ * transform; calls from a thread whose current device differs return hipErrorInvalidDevice.  (ii) Kernels that
+ * pull their work in order draw a {next, done} counter pair from a ring of 4096 pairs per setup and re-arm it
+ * when they retire: at most 4096 launches of ONE setup may be in flight at the same time (summed over all
+ * streams).  Launches on one stream serialise, so only > 4096 concurrently RUNNING launches could collide.
+ * (iii) Scratch of the sizes beyond LDS is kept per stream: the same setup may run on several streams at once.
+ *
+ * All return 0 on success, otherwise a hipError_t value (pffft_hip_last_error() has the text).
  * `in`, `out`, `a`, `b`, `ab` are DEVICE pointers to `batch` contiguous vectors (N scalars for a
  * real setup, 2N for a complex one), 16-byte (float) / 32-byte (double) aligned.  `stream` is a
  * hipStream_t (NULL = default stream).  Calls are asynchronous with respect to the host.  in == out
@@ -130,10 +138,21 @@ int pffft_hip_shift_transform_batch(PFFFT_Setup *, const float *in, float *out, 
  * src/pffastconv.c:204-261): returns the number of output samples written, or -1 on error. */
 int pffastconv_hip_apply_device(PFFASTCONV_Setup *, const float *d_input, int inputLen, float *d_output,
                                 int applyFlush, void *stream);
+/* The same filter over `nsignals` independent signals of `inputLen` samples each (complex I/O: complex samples), signal
+ * i at d_input + i*inputStride and its output at d_output + i*outputStride (strides in floats, >= the signal's floats).
+ * Every signal is processed exactly as one pffastconv_hip_apply_device call would (src/pffastconv.c:133-263 per signal,
+ * same block schedule, same number of outputs — the return value, per signal); all blocks of all signals share one
+ * launch so that reference-sized calls (BASELINE configs[3]: 255 blocks) fill the chip.  -1 on error. */
+int pffastconv_hip_apply_batch(PFFASTCONV_Setup *, const float *d_input, int inputLen, size_t inputStride,
+                               float *d_output, size_t outputStride, int nsignals, int applyFlush, void *stream);
 
 /* Name of the kernel family a setup dispatches to ("c1024_f32", "generic", ...): for tests/bench. */
 const char *pffft_hip_kernel_name(const void *setup);
 const char *pffft_hip_last_error(void);
+/* Number of legacy (void) entries that failed in this process so far.  The legacy entries have no error channel
+ * (include/pffft/pffft.h:159); a failed call — no device, HIP error — prints one line on stderr, fills its output
+ * vector with NaN (all-ones bytes) and increments this counter.  PFFFT_HIP_ABORT=1 makes it abort() instead. */
+unsigned pffft_hip_error_count(void);
 int pffft_hip_device_count(void);
 /* 0 = default; other values select experimental variants of the headline kernel (bench A/B only) */
 void pffft_hip_set_variant(int variant);

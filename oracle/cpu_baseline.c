@@ -27,6 +27,11 @@ extern PFFFTD_Setup *pffftd_new_setup(int N, int transform);
 extern void pffftd_destroy_setup(PFFFTD_Setup *);
 extern void pffftd_transform(PFFFTD_Setup *, const double *in, double *out, double *work, int direction);
 
+typedef struct PFFASTCONV_Setup PFFASTCONV_Setup;
+extern PFFASTCONV_Setup *pffastconv_new_setup(const float *filterCoeffs, int filterLen, int *blockLen, int flags);
+extern void pffastconv_destroy_setup(PFFASTCONV_Setup *);
+extern int pffastconv_apply(PFFASTCONV_Setup *, const float *input, int inputLen, float *output, int applyFlush);
+
 typedef struct {
   void *setup; const char *in; char *out; size_t vec_bytes; long first, count; int reps, direction, ordered, is_double;
 } job_t;
@@ -71,5 +76,39 @@ double cpu_baseline_run(int N, int transform, int is_double, int direction, int 
   for (int t = 0; t < started; ++t) pthread_join(th[t], 0);
   clock_gettime(CLOCK_MONOTONIC, &t1);
   if (is_double) pffftd_destroy_setup((PFFFTD_Setup *)setup); else pffft_destroy_setup((PFFFT_Setup *)setup);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* FIR baseline (BASELINE configs[3]): `reps` calls of pffastconv_apply(setup, x, len, y, 1) over the whole signal on
+ * each of `threads` threads.  A PFFASTCONV_Setup is NOT shareable (include/pffft/pffastconv.h:77-80), so every thread
+ * owns its setup and its output buffer (y + t*len floats); the signal is shared read-only.  Returns elapsed wall
+ * seconds, < 0 on error; *produced = output samples of ONE call. */
+typedef struct { const float *h; int taps; const float *x; int len; float *y; int reps; int produced; } firjob_t;
+
+static void *fir_worker(void *arg) {
+  firjob_t *j = (firjob_t *)arg;
+  int bl = 0;
+  PFFASTCONV_Setup *s = pffastconv_new_setup(j->h, j->taps, &bl, 0);
+  if (!s) { j->produced = -1; return 0; }
+  for (int r = 0; r < j->reps; ++r) j->produced = pffastconv_apply(s, j->x, j->len, j->y, 1);
+  pffastconv_destroy_setup(s);
+  return 0;
+}
+
+double cpu_baseline_fir(const float *h, int taps, const float *x, int len, float *y, int reps, int threads, int *produced) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  pthread_t th[256];
+  firjob_t jobs[256];
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int t = 0; t < threads; ++t) {
+    jobs[t] = (firjob_t){h, taps, x, len, y + (size_t)t * (size_t)len, reps, 0};
+    pthread_create(&th[t], 0, fir_worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(th[t], 0);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (produced) *produced = jobs[0].produced;
+  for (int t = 0; t < threads; ++t) if (jobs[t].produced < 0) return -1.0;
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

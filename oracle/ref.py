@@ -21,6 +21,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REF_SO = os.path.join(_HERE, "_ref", "libpffft_ref.so")
 FFTPACK_SO = os.path.join(_HERE, "_ref", "libfftpack_ref.so")
+# BASELINE configs[0] builds of the same sources (oracle/Makefile): PFFFT_USE_SIMD=OFF = "4xScalar" vectors, and the
+# SIMD_SZ == 1 build (PFFFT_USE_SCALAR_VECT=OFF too) whose unordered output is FFTPACK's order
+REF_4XSCALAR_SO = os.path.join(_HERE, "_ref", "libpffft_ref_4xscalar.so")
+REF_SCALAR_SO = os.path.join(_HERE, "_ref", "libpffft_ref_scalar.so")
 REFERENCE_ROOT = os.environ.get("PFFFT_REFERENCE_ROOT", "/root/reference")
 
 FORWARD, BACKWARD = 0, 1
@@ -31,8 +35,11 @@ def build(force: bool = False) -> bool:
     """Compile oracle/_ref from /root/reference when the sources are present.
     Returns True when the .so exists afterwards.  On the GPU box /root/reference is
     absent and the prebuilt object shipped with the snapshot is used as is."""
-    if os.path.isdir(os.path.join(REFERENCE_ROOT, "src")) and (force or not os.path.exists(REF_SO)
-                                                              or not os.path.exists(os.path.join(_HERE, "_ref", "libpfdsp_ref.so"))):
+    want = [REF_SO, os.path.join(_HERE, "_ref", "libpfdsp_ref.so"), REF_4XSCALAR_SO, REF_SCALAR_SO,
+            os.path.join(_HERE, "_ref", "libcpubase.so")]
+    stale = any(not os.path.exists(f) for f in want) or (
+        os.path.getmtime(os.path.join(_HERE, "cpu_baseline.c")) > os.path.getmtime(want[-1]))
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "src")) and (force or stale):
         subprocess.run(["make", "-C", _HERE, f"REF={REFERENCE_ROOT}"], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return os.path.exists(REF_SO)

@@ -84,6 +84,10 @@ def lib():
     L.pffastconv_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.pffastconv_hip_apply_device.restype = C.c_int
     L.pffastconv_hip_apply_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.pffastconv_hip_apply_batch.restype = C.c_int
+    L.pffastconv_hip_apply_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
+                                             C.c_int, C.c_void_p]
+    L.pffft_hip_error_count.restype = C.c_uint
     L.pffastconv_simd_size.restype = C.c_int
     L.pffft_hip_shift_transform_batch.restype = C.c_int
     L.pffft_hip_shift_transform_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double,
@@ -122,6 +126,15 @@ def is_valid_size(N, transform, dtype=np.float32) -> bool:
 
 def nearest_transform_size(N, transform, higher, dtype=np.float32) -> int:
     return getattr(lib(), f"{_pfx(dtype)}_nearest_transform_size")(N, transform, int(bool(higher)))
+
+
+def error_count() -> int:
+    """Legacy (void) entries that failed soft in this process (include/pffft_hip.h)."""
+    return int(lib().pffft_hip_error_count())
+
+
+def last_error() -> str:
+    return lib().pffft_hip_last_error().decode()
 
 
 def set_variant(v: int) -> None:
@@ -322,3 +335,19 @@ class FastConv:
         y = _aligned_empty(max(xin.size, 1), np.float32)
         n = self._L.pffastconv_apply(self.handle, xin.ctypes.data, n_in, y.ctypes.data, int(bool(flush)))
         return y[:n * cpl].copy(), n
+
+    def apply_batch(self, x, flush: bool = True, out=None):
+        """pffastconv_hip_apply_batch: x is a [nsignals, floats-per-signal] CUDA tensor of independent signals; every row
+        is filtered exactly as apply() would.  Returns (y[:, :n_out*cpl], n_out); n_out is per signal."""
+        import torch
+        cpl = 2 if (self.flags & 1) else 1
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        nsig, fl = x.shape
+        y = out if out is not None else torch.empty_like(x)
+        assert y.dim() == 2 and y.shape[0] == nsig and y.stride(1) == 1
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        n = self._L.pffastconv_hip_apply_batch(self.handle, x.data_ptr(), fl // cpl, x.stride(0) if nsig > 1 else fl,
+                                               y.data_ptr(), y.stride(0) if nsig > 1 else fl, nsig, int(bool(flush)), st)
+        if n < 0:
+            raise RuntimeError("pffastconv_hip_apply_batch failed: " + self._L.pffft_hip_last_error().decode())
+        return y[:, :n * cpl], n

@@ -42,27 +42,41 @@ def _build_dsp(force: bool, verbose: bool) -> None:
     subprocess.run(cmd, check=True, cwd=CSRC)
 
 
+def _obj_stale(obj: str) -> bool:
+    """True when `obj` is missing or older than any file its depfile (hipcc -MD) lists."""
+    dep = obj[:-2] + ".d"
+    if not (os.path.exists(obj) and os.path.exists(dep)):
+        return True
+    t = os.path.getmtime(obj)
+    txt = open(dep).read().replace("\\\n", " ")
+    files = txt.split(":", 1)[1].split() if ":" in txt else []
+    return any((not os.path.exists(f)) or os.path.getmtime(f) > t for f in files)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     _build_dsp(force, verbose)
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
+             "-Wno-pass-failed",   # "loop not unrolled" remarks of fully unrollable radix loops hid real diagnostics
              "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
     os.makedirs(OBJDIR, exist_ok=True)
-    # one hipcc per translation unit, in parallel (the generated Stockham units hold ~600 kernel instantiations)
-    procs = []
+    # one hipcc per translation unit, in parallel (the generated Stockham units hold ~600 kernel instantiations);
+    # a unit is recompiled only when one of the files in its depfile changed
+    procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + flags + ["-c", "-o", obj, os.path.join(CSRC, src)]
+        objs.append(obj)
+        if not force and not _obj_stale(obj):
+            continue
+        cmd = [hipcc] + flags + ["-MD", "-MF", obj[:-2] + ".d", "-c", "-o", obj, os.path.join(CSRC, src)]
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC)))
-    objs = []
-    for cmd, obj, pr in procs:
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-        objs.append(obj)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(link))

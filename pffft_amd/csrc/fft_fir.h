@@ -30,7 +30,9 @@ template <class C>
 __global__ void __launch_bounds__(C::WG_THREADS, 2)
 fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const cx<float>* __restrict__ Hc,
                       int nblk, int step, int inputLen, int lastOut,
-                      const cx<float>* __restrict__ twg, const cx<float>* __restrict__ twrg, unsigned* ctr) {
+                      const cx<float>* __restrict__ twg, const cx<float>* __restrict__ twrg, unsigned* ctr,
+                      int nsig, size_t xstride, size_t ystride) {
+    // nsig independent signals (pffastconv_hip_apply_batch): block index = sig * nblk + block-in-signal
     typedef float T;
     typedef cx<T> CX;
     typedef Tiled<C, FWD, 1> KF;
@@ -68,20 +70,25 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         __syncthreads();
         g = s_next[0];
     }
-    for (unsigned it = 0; (int)(g * C::T_PER_WG) < nblk; ++it) {
+    const long long nblk_all = (long long)nblk * nsig;
+    for (unsigned it = 0; (long long)g * C::T_PER_WG < nblk_all; ++it) {
         if (dyn && threadIdx.x == 0) {
             s_next[(it + 1) & 1] = pend;
             pend = atomicAdd(&ctr[0], 1u);
         }
-        const int blk = (int)(g * C::T_PER_WG) + slot;
-        const bool active = blk < nblk;
-        const long off = (long)(active ? blk : nblk - 1) * step;  // first input / output sample of the block
+        const long long blk_all = (long long)g * C::T_PER_WG + slot;
+        const bool active = blk_all < nblk_all;
+        const int sig = active ? (int)(blk_all / nblk) : nsig - 1;
+        const int blk = active ? (int)(blk_all - (long long)sig * nblk) : nblk - 1;
+        const long off = (long)blk * step;  // first input / output sample of the block
         const int numOut = (active && blk == nblk - 1) ? lastOut : step;
+        const float* xs = x + (size_t)sig * xstride;
+        float* ys = y + (size_t)sig * ystride;
         CX v[E];
         PF_STAMP(1);
         // ---- gather: stage-0 operand order, zero beyond the end of the signal (src/pffastconv.c:231-233) ----
         {
-            const float* src = x + off;
+            const float* src = xs + off;
             const long avail = (long)inputLen - off;  // samples of this block that exist
 #pragma unroll
             for (int ii = 0; ii < 1; ++ii)
@@ -136,7 +143,7 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         PF_STAMP(7);
         // ---- scatter the first numOut samples (src/pffastconv.c:255) ----
         if (active) {
-            float* dst = y + off;
+            float* dst = ys + off;
 #pragma unroll
             for (int ii = 0; ii < 1; ++ii)
 #pragma unroll

@@ -326,20 +326,30 @@ PD_EXPORT float shift_addfast_inp_c(complexf* in_out, int N_cplx, shift_addfast_
 }
 
 // ---- D ----
+// Tables of algorithms D and E: entry i = (cos, sin) of the phase accumulator after i + 1 additions of the increment.
+// The accumulator is a FLOAT that is brought back into [-pi, pi] after every addition (src/pf_mixer.cpp:341-347,
+// :419-425), so entry i is not cos((i + 1) * inc): the rounding of every partial sum is part of the table, and the
+// structs have to come out bit-identical to the reference's (tests/test_pfdsp.py).  One builder for both.
+static void wrapped_accumulator_table(float inc, int count, float* tcos, float* tsin) {
+    const float two_pi = 2 * PI_F;
+    float acc = 0.0f;
+    for (int i = 0; i < count; ++i) {
+        acc += inc;
+        for (; acc > PI_F; acc -= two_pi) {}
+        for (; acc < -PI_F; acc += two_pi) {}
+        tcos[i] = cosf(acc);
+        tsin[i] = sinf(acc);
+    }
+}
+
 PD_EXPORT shift_unroll_data_t shift_unroll_init(float rate, int size) {   // :333-350
     shift_unroll_data_t o;
-    o.phase_increment = 2 * rate * PI_F;
+    const size_t cap = sizeof(float) * (size_t)(size > 0 ? size : 1);
     o.size = size;
-    o.dsin = (float*)malloc(sizeof(float) * (size > 0 ? size : 1));
-    o.dcos = (float*)malloc(sizeof(float) * (size > 0 ? size : 1));
-    float myphase = 0;
-    for (int i = 0; i < size; ++i) {
-        myphase += o.phase_increment;
-        while (myphase > PI_F) myphase -= 2 * PI_F;
-        while (myphase < -PI_F) myphase += 2 * PI_F;
-        o.dsin[i] = sinf(myphase);
-        o.dcos[i] = cosf(myphase);
-    }
+    o.phase_increment = 2 * rate * PI_F;
+    o.dcos = (float*)malloc(cap);
+    o.dsin = (float*)malloc(cap);
+    wrapped_accumulator_table(o.phase_increment, size, o.dcos, o.dsin);
     return o;
 }
 PD_EXPORT void shift_unroll_deinit(shift_unroll_data_t* d) {
@@ -364,15 +374,8 @@ PD_EXPORT float shift_unroll_inp_c(complexf* in_out, int size, shift_unroll_data
 PD_EXPORT shift_limited_unroll_data_t shift_limited_unroll_init(float rate) {   // :413-429
     shift_limited_unroll_data_t o;
     o.phase_increment = 2 * rate * PI_F;
-    float myphase = 0;
-    for (int i = 0; i < PF_SHIFT_LIMITED_UNROLL_SIZE; ++i) {
-        myphase += o.phase_increment;
-        while (myphase > PI_F) myphase -= 2 * PI_F;
-        while (myphase < -PI_F) myphase += 2 * PI_F;
-        o.dcos[i] = cosf(myphase);
-        o.dsin[i] = sinf(myphase);
-    }
-    o.complex_phase.i = 1.0F;
+    wrapped_accumulator_table(o.phase_increment, PF_SHIFT_LIMITED_UNROLL_SIZE, o.dcos, o.dsin);
+    o.complex_phase.i = 1.0F;   // unit phasor: the state limited_run advances block by block
     o.complex_phase.q = 0.0F;
     return o;
 }

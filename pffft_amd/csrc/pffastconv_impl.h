@@ -20,15 +20,21 @@ struct FastConv {
     float scale;
     std::vector<float> h_filter_image;  // time-domain image the reference builds in Xt (:99-106)
     std::mutex mu;
+    bool ready = false;     // set only after EVERY step of fc_ensure_device succeeded
+    int device = -1;
     float* d_Hf = nullptr;
     float* d_Hc = nullptr;  // canonical-order filter spectrum * 1/Nfft for the fused kernel
     // throughput regime (many blocks): the same outputs through LARGER internal blocks (better overlap-save efficiency)
     PFFFT_Setup* st_big = nullptr; float* d_Hc_big = nullptr; int Nfft_big = 0;
     std::vector<float> h_td;  // y[m] = sum_i h_td[i] x[m + i]: the filter as the time-domain kernel applies it (zero padded to 8)
     float* d_td = nullptr;
-    float* d_work = nullptr; size_t work_floats = 0;
-    float* d_x = nullptr; size_t x_floats = 0;
+    // work image of the composed path: one per stream (two streams running one setup must not share scratch)
+    struct Work { float* p = nullptr; size_t floats = 0; };
+    std::map<hipStream_t, Work> work;
+    float* d_x = nullptr; size_t x_floats = 0;   // staging of pffastconv_apply's host pointers (large signals)
     float* d_y = nullptr; size_t y_floats = 0;
+    float* h_x = nullptr; size_t hx_floats = 0;  // pinned host images the kernels read / write directly (zero copy)
+    float* h_y = nullptr; size_t hy_floats = 0;
 };
 constexpr uint32_t FC_MAGIC = 0x46434e56u;
 
@@ -83,8 +89,10 @@ constexpr int TD_THREADS = 256, TD_PER = 8, TD_TILE = TD_THREADS * TD_PER, TD_MA
 template <int STRIDE>
 __global__ void __launch_bounds__(TD_THREADS)
 fastconv_td_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ c, int flen8, long produced,
-                   long inputLen) {
+                   long inputLen, size_t xstride, size_t ystride) {
     extern __shared__ __attribute__((aligned(16))) float sx[];
+    x += (size_t)blockIdx.y * xstride;   // blockIdx.y = signal of a batch (pffastconv_hip_apply_batch)
+    y += (size_t)blockIdx.y * ystride;
     const int tid = threadIdx.x;
     const long o0 = (long)blockIdx.x * TD_TILE;
     const int outs = (produced - o0) < TD_TILE ? (int)(produced - o0) : TD_TILE;
@@ -133,8 +141,11 @@ static int fc_grow(float** p, size_t* have, size_t want) {
     return 0;
 }
 
-static int fc_ensure_device(FastConv* s) {
-    if (s->d_Hf) return 0;
+static void fc_free_device(FastConv* s) {
+    for (float** p : {&s->d_Hf, &s->d_Hc}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+static int fc_init_device(FastConv* s) {
     PF_CHECK(hipMalloc((void**)&s->d_Hf, sizeof(float) * s->Nfft));
     PF_CHECK(hipMemcpy(s->d_Hf, s->h_filter_image.data(), sizeof(float) * s->Nfft, hipMemcpyHostToDevice));
     int rc = transform_batch<float>(s->st, s->d_Hf, s->d_Hf, 1, PFFFT_FORWARD, 0, nullptr);  // :108
@@ -149,23 +160,41 @@ static int fc_ensure_device(FastConv* s) {
     return 0;
 }
 
+static int fc_ensure_device(FastConv* s) {
+    int dev = -1;
+    PF_CHECK(hipGetDevice(&dev));
+    if (s->ready) {
+        if (dev == s->device) return 0;
+        g_last_error = "pffastconv: setup is bound to another device than the calling thread's current one";
+        return (int)hipErrorInvalidDevice;
+    }
+    const int rc = fc_init_device(s);
+    if (rc) { fc_free_device(s); return rc; }   // a later call starts over instead of launching on half-built tables
+    s->device = dev;
+    s->ready = true;
+    return 0;
+}
+
+struct FcBatch { int nsig; size_t xstride, ystride; };   // signals of one call (1 for the reference entries)
+
 template <class C>
 static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
-                           hipStream_t st, PFFFT_Setup* pst = nullptr, const float* d_Hc = nullptr) {
+                           hipStream_t st, const FcBatch& fb, PFFFT_Setup* pst = nullptr, const float* d_Hc = nullptr) {
     auto k = fastconv_fused_kernel<C>;
     int rc = allow_big_lds(k, C::LDS_BYTES);
     if (rc) return rc;
     int per_cu = 0;
     PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, C::LDS_BYTES));
     if (per_cu < 1) per_cu = 1;
-    size_t groups = ((size_t)nblk + C::T_PER_WG - 1) / C::T_PER_WG;
+    size_t groups = ((size_t)nblk * fb.nsig + C::T_PER_WG - 1) / C::T_PER_WG;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
     Setup* ps = pst ? pst : s->st;
     if (!d_Hc) d_Hc = s->d_Hc;
     unsigned* ctr = groups <= grid ? nullptr : ps->d_ctr + 2 * (ps->ctr_slot.fetch_add(1) % CTR_RING);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), C::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
-                       nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, ctr);
+                       nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, ctr,
+                       fb.nsig, fb.xstride, fb.ystride);
     PF_CHECK(hipGetLastError());
     return 0;
 }
@@ -175,7 +204,7 @@ static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, 
 // when a call has many blocks the same `produced` outputs are computed with longer internal blocks: overlap-save
 // efficiency (Nfft - len + 1) / Nfft goes from ~0.5 (the reference's Nfft = 2 next_pow2(len-1), src/pffastconv.c:62-63)
 // to 0.75-0.94.  PFFASTCONV_HIP_NFFT=<n> forces a length (A/B), =0 switches this off.
-static int fc_big_nfft(const FastConv* s, long produced) {
+static int fc_big_nfft(const FastConv* s, long produced, int nsig) {
     static const int forced = [] { const char* e = getenv("PFFASTCONV_HIP_NFFT"); return e ? atoi(e) : -1; }();
     if (forced == 0) return 0;
     const int taps = s->filterLen;
@@ -186,7 +215,7 @@ static int fc_big_nfft(const FastConv* s, long produced) {
     if (forced > 0) return want;
     if (taps <= 128) return 0;
     const long bblk = (produced + (want - taps)) / (want - taps + 1);
-    return bblk >= num_cus() ? want : 0;                 // fewer blocks: latency regime, one reference-sized block per CU is faster
+    return bblk * nsig >= num_cus() ? want : 0;          // fewer blocks: latency regime, one reference-sized block per CU is faster
 }
 
 static int fc_ensure_big(FastConv* s, int Nfft_big) {
@@ -248,7 +277,7 @@ static int fc_schedule(const FastConv* s, int inputLen, int flush, int* lastOut,
 }
 
 static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, float* d_y, int flush, hipStream_t st,
-                           int* produced_out) {
+                           int* produced_out, const FcBatch& fb = FcBatch{1, 0, 0}) {
     std::lock_guard<std::mutex> lk(s->mu);
     int rc = fc_ensure_device(s);
     if (rc) return rc;
@@ -262,17 +291,17 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     const int Nfft = s->Nfft;
     const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
     if (mode == 0 && s->cplxFactor == 1 && g_variant != 30) {
-        const int nbig = fc_big_nfft(s, produced);
+        const int nbig = fc_big_nfft(s, produced, fb.nsig);
         if (nbig) {
             if ((rc = fc_ensure_big(s, nbig))) return rc;
             const int bstep = nbig - s->filterLen + 1;
             const int bblk = (int)(((long)produced + bstep - 1) / bstep);
             const int blast = (int)(produced - (long)(bblk - 1) * bstep);
             switch (nbig / 2) {
-                case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, s->st_big, s->d_Hc_big);
-                case 2048: return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, s->st_big, s->d_Hc_big);
-                case 4096: return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, s->st_big, s->d_Hc_big);
-                case 8192: return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, s->st_big, s->d_Hc_big);
+                case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, fb, s->st_big, s->d_Hc_big);
+                case 2048: return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, fb, s->st_big, s->d_Hc_big);
+                case 4096: return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, fb, s->st_big, s->d_Hc_big);
+                case 8192: return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, fb, s->st_big, s->d_Hc_big);
                 default: break;
             }
         }
@@ -287,38 +316,45 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         const int flen8 = (int)s->h_td.size();
         const bool cplx = mode == 1 || s->cplxFactor == 2;
         const long out_f = mode == 1 ? 2L * produced : produced, in_f = mode == 1 ? 2L * inputLen : inputLen;
-        const unsigned grid = (unsigned)((out_f + TD_TILE - 1) / TD_TILE);
+        const dim3 grid((unsigned)((out_f + TD_TILE - 1) / TD_TILE), (unsigned)fb.nsig);
         const size_t lds = sizeof(float) * (TD_TILE + (cplx ? 2 : 1) * flen8 + 8);
-        if (cplx) hipLaunchKernelGGL(fastconv_td_kernel<2>, dim3(grid), dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, out_f, in_f);
-        else hipLaunchKernelGGL(fastconv_td_kernel<1>, dim3(grid), dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, out_f, in_f);
+        if (cplx) hipLaunchKernelGGL(fastconv_td_kernel<2>, grid, dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, out_f, in_f, fb.xstride, fb.ystride);
+        else hipLaunchKernelGGL(fastconv_td_kernel<1>, grid, dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, out_f, in_f, fb.xstride, fb.ystride);
         PF_CHECK(hipGetLastError());
         return 0;
     }
     if (mode == 0 && g_variant != 30) {  // one real stream: the fused one-kernel path when Nfft/2 has a tiled kernel
         switch (Nfft / 2) {
-            case 512: return fc_launch_fused<FirCfg::C512>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
-            case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
-            case 2048: return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
-            case 4096: return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
-            case 8192: return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, nblk, step, inputLen, lastOut, st);
+            case 512: return fc_launch_fused<FirCfg::C512>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            case 2048: return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            case 4096: return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            case 8192: return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             default: break;
         }
     }
-    rc = fc_grow(&s->d_work, &s->work_floats, (size_t)nblk * Nfft);
+    // composed path (complex-I/O modes with long filters): signal by signal on the same stream through one work image
+    FastConv::Work& wk = s->work[st];
+    rc = fc_grow(&wk.p, &wk.floats, (size_t)nblk * Nfft);
     if (rc) return rc;
+    float* const d_work = wk.p;
     const unsigned grid = (unsigned)std::min<size_t>(((size_t)nblk * Nfft + 255) / 256, (size_t)num_cus() * 16);
-    hipLaunchKernelGGL(fastconv_gather_kernel, dim3(grid), dim3(256), 0, st, d_x, s->d_work, nblk, Nfft, step, inputLen,
-                       mode);
-    PF_CHECK(hipGetLastError());
-    rc = transform_batch<float>(s->st, s->d_work, s->d_work, nblk, PFFFT_FORWARD, 0, st);            // :235
-    if (rc) return rc;
-    rc = zconvolve_batch<float>(s->st, s->d_work, s->d_Hf, s->d_work, s->scale, nblk, 0, 1, st);     // :238
-    if (rc) return rc;
-    rc = transform_batch<float>(s->st, s->d_work, s->d_work, nblk, PFFFT_BACKWARD, 0, st);           // :254
-    if (rc) return rc;
-    hipLaunchKernelGGL(fastconv_scatter_kernel, dim3(grid), dim3(256), 0, st, s->d_work, d_y, nblk, Nfft, step, lastOut,
-                       mode);
-    PF_CHECK(hipGetLastError());
+    for (int sig = 0; sig < fb.nsig; ++sig) {
+        const float* xs = d_x + (size_t)sig * fb.xstride;
+        float* ys = d_y + (size_t)sig * fb.ystride;
+        hipLaunchKernelGGL(fastconv_gather_kernel, dim3(grid), dim3(256), 0, st, xs, d_work, nblk, Nfft, step, inputLen,
+                           mode);
+        PF_CHECK(hipGetLastError());
+        rc = transform_batch<float>(s->st, d_work, d_work, nblk, PFFFT_FORWARD, 0, st);            // :235
+        if (rc) return rc;
+        rc = zconvolve_batch<float>(s->st, d_work, s->d_Hf, d_work, s->scale, nblk, 0, 1, st);     // :238
+        if (rc) return rc;
+        rc = transform_batch<float>(s->st, d_work, d_work, nblk, PFFFT_BACKWARD, 0, st);           // :254
+        if (rc) return rc;
+        hipLaunchKernelGGL(fastconv_scatter_kernel, dim3(grid), dim3(256), 0, st, d_work, ys, nblk, Nfft, step, lastOut,
+                           mode);
+        PF_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -360,7 +396,9 @@ PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
     if (!s) return;
     pffft_destroy_setup(s->st);
     if (s->st_big) pffft_destroy_setup(s->st_big);
-    for (float* p : {s->d_Hf, s->d_Hc, s->d_Hc_big, s->d_td, s->d_work, s->d_x, s->d_y}) if (p) (void)hipFree(p);
+    for (float* p : {s->d_Hf, s->d_Hc, s->d_Hc_big, s->d_td, s->d_x, s->d_y}) if (p) (void)hipFree(p);
+    for (auto& kv : s->work) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (float* p : {s->h_x, s->h_y}) if (p) (void)hipHostFree(p);
     s->magic = 0;
     delete s;
 }
@@ -373,32 +411,82 @@ PF_EXPORT int pffastconv_hip_apply_device(PFFASTCONV_Setup* s, const float* d_in
     return rc ? -1 : produced;
 }
 
+PF_EXPORT int pffastconv_hip_apply_batch(PFFASTCONV_Setup* s, const float* d_input, int inputLen, size_t inputStride,
+                                         float* d_output, size_t outputStride, int nsignals, int applyFlush, void* stream) {
+    if (!s || s->magic != pf::FC_MAGIC || nsignals < 0) return -1;
+    const size_t fl = (size_t)inputLen * ((s->flags & PFFASTCONV_HIP_CPLX_INP_OUT) ? 2 : 1);
+    if (nsignals > 1 && (inputStride < fl || outputStride == 0)) { pf::g_last_error = "pffastconv_hip_apply_batch: stride smaller than a signal"; return -1; }
+    int produced = 0;
+    if (nsignals == 0) {   // nothing to do, but the count a call would produce is still defined
+        int lastOut = 0;
+        (void)pf::fc_schedule(s, s->cplxFactor * inputLen, applyFlush, &lastOut, &produced);
+        return produced / s->cplxFactor;
+    }
+    int rc = pf::fc_apply_device(s, d_input, inputLen, d_output, applyFlush, (hipStream_t)stream, &produced,
+                                 pf::FcBatch{nsignals, inputStride, outputStride});
+    return rc ? -1 : produced;
+}
+
+namespace pf {
+static int fc_pinned(float** p, size_t* have, size_t want) {
+    if (*have >= want) return 0;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *have = 0;
+    PF_CHECK(hipHostMalloc((void**)p, want * sizeof(float), hipHostMallocDefault));
+    *have = want;
+    return 0;
+}
+}  // namespace pf
+
+// Host pointers (the reference's calling convention): up to FC_ZC_LIMIT bytes per signal there is no DMA copy — the signal
+// is copied by the CPU into a pinned host image that the kernel reads over PCIe directly, the kernel writes its outputs
+// into another pinned image, one stream synchronisation, CPU copy out (the same scheme as the transform entries,
+// pffft_hip.hip legacy_run).  Larger signals are staged through device buffers.  Failure: fail-soft like the transform
+// entries (stderr, pffft_hip_last_error(), returns 0 samples produced), abort() only under PFFFT_HIP_ABORT=1.
 PF_EXPORT int pffastconv_apply(PFFASTCONV_Setup* s, const float* input, int cplxInputLen, float* output, int applyFlush) {
     using namespace pf;
-    if (!s || s->magic != FC_MAGIC) { fprintf(stderr, "pffastconv_apply: bad setup\n"); abort(); }
+    if (!s || s->magic != FC_MAGIC) {
+        g_last_error = "pffastconv_apply: bad setup";
+        legacy_fatal((int)hipErrorInvalidHandle, "pffastconv_apply", nullptr, 0, true);
+        return 0;
+    }
+    constexpr size_t FC_ZC_LIMIT = (size_t)64 << 20;
     const bool in_dev = is_device_ptr(input), out_dev = is_device_ptr(output);
     const int cpl = (s->flags & PFFASTCONV_HIP_CPLX_INP_OUT) ? 2 : 1;
     const size_t in_floats = (size_t)cplxInputLen * cpl;
     const float* d_in = input; float* d_out = output;
     int rc = 0, produced = 0;
+    const bool zc = zero_copy_enabled() && in_floats * sizeof(float) <= FC_ZC_LIMIT;
+    bool out_pinned = false;
     do {
         if (!in_dev) {
-            if ((rc = fc_grow(&s->d_x, &s->x_floats, in_floats ? in_floats : 1))) break;
-            if (in_floats && hipMemcpy(s->d_x, input, in_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = -1; break; }
-            d_in = s->d_x;
+            if (zc && fc_pinned(&s->h_x, &s->hx_floats, in_floats ? in_floats : 1) == 0) {
+                if (in_floats) memcpy(s->h_x, input, in_floats * sizeof(float));
+                d_in = s->h_x;
+            } else {
+                if ((rc = fc_grow(&s->d_x, &s->x_floats, in_floats ? in_floats : 1))) break;
+                if (in_floats && hipMemcpy(s->d_x, input, in_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = -1; break; }
+                d_in = s->d_x;
+            }
         }
         if (!out_dev) {
-            if ((rc = fc_grow(&s->d_y, &s->y_floats, in_floats ? in_floats : 1))) break;
-            d_out = s->d_y;
+            if (zc && fc_pinned(&s->h_y, &s->hy_floats, in_floats ? in_floats : 1) == 0) { d_out = s->h_y; out_pinned = true; }
+            else {
+                if ((rc = fc_grow(&s->d_y, &s->y_floats, in_floats ? in_floats : 1))) break;
+                d_out = s->d_y;
+            }
         }
         if ((rc = fc_apply_device(s, d_in, cplxInputLen, d_out, applyFlush, nullptr, &produced))) break;
-        if (!out_dev) {
+        if (!out_dev && !out_pinned) {
             if (produced > 0 && hipMemcpy(output, d_out, (size_t)produced * cpl * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = -1; break; }
-        } else if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = -1; break; }
+        } else {
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = -1; break; }
+            if (out_pinned && produced > 0) memcpy(output, d_out, (size_t)produced * cpl * sizeof(float));
+        }
     } while (0);
-    if (rc) {
-        fprintf(stderr, "pffastconv_apply: HIP path failed (%d): %s\n", rc, g_last_error.c_str());
-        abort();
+    if (rc) {   // the reference cannot fail here: NaN over the caller's output vector, 0 samples produced
+        legacy_fatal(rc, "pffastconv_apply", output, in_floats * sizeof(float), !out_dev);
+        return 0;
     }
     return produced;
 }

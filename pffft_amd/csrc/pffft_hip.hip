@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -45,15 +46,26 @@ static int fail(hipError_t e, const char* what) {
         if (_e != hipSuccess) return fail(_e, #expr);    \
     } while (0)
 
-// Legacy void entries have no error channel (include/pffft/pffft.h:159): fail loudly.
+// Legacy void entries have no error channel (include/pffft/pffft.h:159).  A drop-in must not kill its caller where the
+// reference could not fail: the default is FAIL-SOFT — one line on stderr (the first 8 failures per process), the text in
+// pffft_hip_last_error(), the failure counted in pffft_hip_error_count(), and the output vector filled with NaN (all-ones
+// bytes; host or device memory alike) so that a failed call can never be mistaken for a spectrum.
+// PFFFT_HIP_ABORT=1 restores fail-fast (abort()).
+static std::atomic<unsigned> g_error_count{0};
+static bool abort_on_error() {
+    static const bool v = [] { const char* e = getenv("PFFFT_HIP_ABORT"); return e && e[0] == '1'; }();
+    return v;
+}
 static void legacy_fatal(int code, const char* entry, void* out, size_t out_bytes, bool out_is_host) {
-    fprintf(stderr, "%s: HIP path failed (%d): %s\n", entry, code, g_last_error.c_str());
-    const char* na = getenv("PFFFT_HIP_NO_ABORT");
-    if (na && na[0] == '1') {
-        if (out && out_is_host) memset(out, 0xFF, out_bytes);  // all-ones = NaN pattern
-        return;
+    const unsigned nth = g_error_count.fetch_add(1);
+    if (nth < 8 || abort_on_error())
+        fprintf(stderr, "%s: HIP path failed (%d): %s%s\n", entry, code, g_last_error.c_str(),
+                abort_on_error() ? "" : " -- output filled with NaN (PFFFT_HIP_ABORT=1 aborts instead)");
+    if (abort_on_error()) abort();
+    if (out && out_bytes) {
+        if (out_is_host) memset(out, 0xFF, out_bytes);  // all-ones = NaN pattern
+        else if (hipMemset(out, 0xFF, out_bytes) != hipSuccess) (void)hipGetLastError();
     }
-    abort();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -125,6 +137,7 @@ struct Setup {
     std::mutex mu;        // guards the lazy device initialisation
     std::mutex stage_mu;  // guards the staging buffers of the legacy host-pointer entries
     bool dev_ready = false;
+    int device = -1;        // the device the tables / counters / scratch of this setup live on (bound at first use)
     void* d_tw = nullptr;   // W_n^j, j < n
     void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
     void* d_twc[2] = {nullptr, nullptr};  // compact per-stage base twiddles of the Stockham plans (forward / backward order)
@@ -136,9 +149,11 @@ struct Setup {
     // sizes beyond LDS (K_BIG): n = bigN[0] x bigN[1], one strided plan + twiddle table per factor
     StridedPlan bigp[2];
     void* d_bigtw[2] = {nullptr, nullptr};
-    std::mutex big_mu;                    // the two HBM work buffers are owned by the setup
-    void* d_big[2] = {nullptr, nullptr};
-    size_t big_bytes[2] = {0, 0};
+    // HBM work buffers of the beyond-LDS path: one pair PER STREAM (kernels of one stream serialise; two streams running
+    // the same setup concurrently must not share scratch).  big_mu guards the map, not the kernels.
+    struct Scratch { void* buf[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; };
+    std::mutex big_mu;
+    std::map<hipStream_t, Scratch> big_scratch;
     void* d_stage[3] = {nullptr, nullptr, nullptr};  // staging for host-pointer legacy calls
     size_t stage_bytes[3] = {0, 0, 0};
     void* h_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned host images the kernels read / write directly (small vectors)
@@ -254,21 +269,52 @@ static void destroy_setup(Setup* s) {
         if (s->d_tw) (void)hipFree(s->d_tw);
         if (s->d_twr) (void)hipFree(s->d_twr);
         for (void* q : s->d_twc) if (q) (void)hipFree(q);
-        if (s->d_ctr) (void)hipFree(s->d_ctr);
     }
+    if (s->d_ctr) (void)hipFree(s->d_ctr);
     if (s->sub) destroy_setup(s->sub);
     for (void* p : s->d_bigtw) if (p) (void)hipFree(p);
-    for (void* p : s->d_big) if (p) (void)hipFree(p);
+    for (auto& kv : s->big_scratch) for (void* p : kv.second.buf) if (p) (void)hipFree(p);
     for (void* p : s->d_stage) if (p) (void)hipFree(p);
     for (void* p : s->h_stage) if (p) (void)hipHostFree(p);
     s->magic = 0;
     delete s;
 }
 
+// A setup binds to the device that is current at its first transform: tables, counters and scratch live there.  Later
+// calls from a thread whose current device differs are an error (the pointers they pass could not be used by kernels
+// launched there anyway) rather than a fault inside a kernel.
+static int check_device(Setup* s) {
+    int dev = -1;
+    PF_CHECK(hipGetDevice(&dev));
+    if (s->device < 0) s->device = dev;
+    if (s->device != dev) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "pffft_hip: setup is bound to device %d but the calling thread's current device is %d",
+                 s->device, dev);
+        g_last_error = buf;
+        return (int)hipErrorInvalidDevice;
+    }
+    return 0;
+}
+
+static int alloc_counter_ring(Setup* s) {
+    // Each launch of a dynamic kernel takes its own {next, done} counter pair from this ring; the
+    // kernel re-arms the pair when its last workgroup retires.  A pair is reused only CTR_RING
+    // launches later, i.e. at most CTR_RING launches of one setup may be in flight at once
+    // (stated in include/pffft_hip.h; launches on one stream serialise, so this bounds concurrent streams x depth).
+    if (s->d_ctr) return 0;
+    PF_CHECK(hipMalloc((void**)&s->d_ctr, sizeof(unsigned) * 2 * CTR_RING));
+    PF_CHECK(hipMemset(s->d_ctr, 0, sizeof(unsigned) * 2 * CTR_RING));
+    return 0;
+}
+
 template <typename T>
 static int ensure_device(Setup* s) {
     std::lock_guard<std::mutex> lk(s->mu);
-    if (s->dev_ready) return 0;
+    if (s->dev_ready) return check_device(s);
+    int rc = check_device(s);
+    if (rc) return rc;
+    if ((rc = alloc_counter_ring(s))) return rc;   // every kernel family may take the in-order path (zconvolve on K_BIG too)
     if (s->kernel == K_BIG) {
         for (int i = 0; i < 2; ++i) {
             const int m = s->bigp[i].n;
@@ -318,13 +364,6 @@ static int ensure_device(Setup* s) {
         }
         PF_CHECK(hipMalloc(&s->d_twc[d], sizeof(cx<T>) * tc.size()));
         PF_CHECK(hipMemcpy(s->d_twc[d], tc.data(), sizeof(cx<T>) * tc.size(), hipMemcpyHostToDevice));
-    }
-    {
-        // Each launch of a dynamic kernel takes its own {next, done} counter pair from this ring; the
-        // kernel re-arms the pair when its last workgroup retires.  A pair is reused only CTR_RING
-        // launches later, i.e. at most CTR_RING launches of one setup may be in flight at once.
-        PF_CHECK(hipMalloc((void**)&s->d_ctr, sizeof(unsigned) * 2 * CTR_RING));
-        PF_CHECK(hipMemset(s->d_ctr, 0, sizeof(unsigned) * 2 * CTR_RING));
     }
     s->dev_ready = true;
     return 0;
@@ -705,17 +744,22 @@ static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, 
 // internal layout composed around it (fft_big.h)
 template <typename T>
 static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
-    std::lock_guard<std::mutex> lk(s->big_mu);
     const size_t bytes = batch * (size_t)s->n * sizeof(cx<T>);
-    for (int i = 0; i < 2; ++i)
-        if (s->big_bytes[i] < bytes) {
-            if (s->d_big[i]) (void)hipFree(s->d_big[i]);
-            s->d_big[i] = nullptr; s->big_bytes[i] = 0;
-            PF_CHECK(hipMalloc(&s->d_big[i], bytes));
-            s->big_bytes[i] = bytes;
-        }
-    cx<T>* bufA = (cx<T>*)s->d_big[0];
-    cx<T>* bufB = (cx<T>*)s->d_big[1];
+    cx<T>*bufA, *bufB;
+    {
+        std::lock_guard<std::mutex> lk(s->big_mu);
+        Setup::Scratch& sc = s->big_scratch[st];
+        for (int i = 0; i < 2; ++i)
+            if (sc.bytes[i] < bytes) {
+                // hipFree waits for the device: kernels of this stream still using the old buffer finish first
+                if (sc.buf[i]) (void)hipFree(sc.buf[i]);
+                sc.buf[i] = nullptr; sc.bytes[i] = 0;
+                PF_CHECK(hipMalloc(&sc.buf[i], bytes));
+                sc.bytes[i] = bytes;
+            }
+        bufA = (cx<T>*)sc.buf[0];
+        bufB = (cx<T>*)sc.buf[1];
+    }
     const bool real = s->transform == PFFFT_REAL;
     const bool fwd = dir == PFFFT_FORWARD;
     const unsigned egrid = (unsigned)std::min<size_t>((batch * (size_t)s->n / 2 + 255) / 256, (size_t)num_cus() * 16);
@@ -1227,6 +1271,7 @@ PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
     }
 }
 PF_EXPORT const char* pffft_hip_last_error(void) { return pf::g_last_error.c_str(); }
+PF_EXPORT unsigned pffft_hip_error_count(void) { return pf::g_error_count.load(); }
 PF_EXPORT int pffft_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

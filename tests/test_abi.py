@@ -136,3 +136,36 @@ def test_no_oracle_in_product():
                 assert not re.search(r"(from|import)\s+oracle|#include\s+\"[^\"]*oracle|libpffft_ref|dlopen", txt), f
     out = subprocess.run(["ldd", pa.lib_path()], capture_output=True, text=True).stdout
     assert "pffft_ref" not in out and "fftpack" not in out
+
+
+_FAILSOFT = r"""
+import numpy as np, pffft_amd as pa
+s = pa.Setup(64, pa.REAL)
+x = np.random.default_rng(0).uniform(-1, 1, 64).astype(np.float32)
+assert pa.error_count() == 0
+y = s.transform(x)                       # legacy void entry, host pointers, no device
+assert np.isnan(y).all() and pa.error_count() == 1 and "no ROCm-capable device" in pa.last_error()
+y = s.transform_ordered(x)
+assert np.isnan(y).all() and pa.error_count() == 2
+fc = pa.FastConv(np.ones(8, np.float32), 0, 0)
+yy, n = fc.apply(np.ones(100, np.float32))
+assert n == 0 and pa.error_count() == 3
+print("FAILSOFT-OK")
+"""
+
+
+def test_legacy_entries_fail_soft_without_a_device():
+    """The legacy entries are `void` (include/pffft/pffft.h:159): where the reference could not fail, the drop-in must not
+    kill its caller.  Without a HIP device: stderr line + NaN-filled output + pffft_hip_error_count(); abort() only under
+    PFFFT_HIP_ABORT=1.  (Runs where no GPU is visible — i.e. in the CPU suite.)"""
+    import sys
+    if pa.device_count() > 0:
+        pytest.skip("a HIP device is present: the failure path cannot be provoked this way")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("PFFFT_HIP_ABORT", None)
+    p = subprocess.run([sys.executable, "-c", _FAILSOFT], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "FAILSOFT-OK" in p.stdout, p.stdout + p.stderr
+    assert "output filled with NaN" in p.stderr
+    env["PFFFT_HIP_ABORT"] = "1"
+    p = subprocess.run([sys.executable, "-c", _FAILSOFT], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode < 0 and "FAILSOFT-OK" not in p.stdout     # killed by SIGABRT: fail-fast on request only

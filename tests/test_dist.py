@@ -61,3 +61,46 @@ def test_two_rank_gloo_bracket():
     assert t0 == t1 == total                      # SUM over ranks of the units
     assert m0 == m1 == pytest.approx(max(e0, e1))  # MAX over ranks of the elapsed time
     assert d0 == d1 == 4                          # 1 warm-up + exactly 3 timed steps
+
+
+# ------------------------------------------------------------------ bench.py's own launcher
+def _bench(*args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                          env=env, timeout=timeout)
+
+
+def test_bench_gpus_2_spawns_two_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no launcher must itself start 2 ranks (torch.distributed.run, 127.0.0.1) and print
+    ONE line with n_gpus: 2.  Driven here on CPU over gloo with the harness self-test step (the transform has no CPU
+    implementation in the product); on a multi-GPU box the same path runs over RCCL."""
+    import json
+    p = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--selftest-cpu")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["selftest"] is True
+    assert rec["value"] > 0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`--gpus 2` on a box that shows fewer than 2 GPUs must fail loudly, not report n_gpus: 1."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this box really has 2 GPUs")
+    p = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert p.returncode != 0
+    assert "GPU(s) visible" in (p.stderr + p.stdout)
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_refuses_world_size_mismatch():
+    p = _bench("--gpus", "4", "--selftest-cpu", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)

@@ -150,3 +150,76 @@ def test_single_tone_spectrum(N, cplx):
         assert abs(np.sqrt(P[carrier]) / np.sqrt(expected) - 1) <= 1e-5
         back = po.transform(X, N, po.COMPLEX if cplx else po.REAL, po.BACKWARD, True)
         assert np.sum((back / N - x) ** 2) <= N * 1e-7
+
+
+# ------------------------------------------------------------------ BASELINE configs[0] (C1): the PFFFT_USE_SIMD=OFF builds
+def _c1_inputs():
+    """N=64 real float forward, x[i] = hash32(seed=1, i)/2^31 - 1 in [-1, 1) and the single-tone
+    case of tests/test_pffft.c:126-140 (cosine at bin k, amplitude 1, phase 0.3 rad)."""
+    i = np.arange(64, dtype=np.uint64)
+    h = (i * np.uint64(2654435761) + np.uint64(1) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF); h ^= h >> np.uint64(13)
+    x_hash = (h.astype(np.float64) / 2.0 ** 31 - 1.0).astype(np.float32)
+    k = 5
+    x_tone = np.cos(2 * np.pi * k * np.arange(64) / 64 + 0.3).astype(np.float32)
+    return {"hash": x_hash, "tone": x_tone}
+
+
+def test_c1_4xscalar_build_is_bit_identical_to_sse():
+    """The survey's finding 3 ("every SIMD_SZ == 4 build gives bit-identical results") as a committed test for C1:
+    -DPFFFT_SIMD_DISABLE=1 -DPFFFT_SCALVEC_ENABLED=1 (CMakeLists.txt:19-20,172-181) vs the SSE object, N=64 real forward,
+    ordered and unordered, plus the inverse; and both against the numpy restatement."""
+    import os
+    from conftest import missing_checker
+    from oracle import ref as oref
+    if not oref.available():
+        oref.build()
+    for so in (oref.REF_SO, oref.REF_4XSCALAR_SO):
+        if not os.path.exists(so):
+            missing_checker(so)
+    sse, s4 = oref.get(), oref.Reference(oref.REF_4XSCALAR_SO)
+    assert s4.f32.simd_arch().decode() == "4xScalar" and s4.f32.simd_size() == 4
+    assert sse.f32.simd_size() == 4 and sse.f32.simd_arch().decode() != "4xScalar"
+    a, b = sse.setup(64, 0), s4.setup(64, 0)
+    for name, x in _c1_inputs().items():
+        fu_a, fu_b = a.transform_unordered(x, 0), b.transform_unordered(x, 0)
+        fo_a, fo_b = a.transform_ordered(x, 0), b.transform_ordered(x, 0)
+        assert np.array_equal(fu_a, fu_b) and np.array_equal(fo_a, fo_b), name
+        assert np.array_equal(a.transform_unordered(fu_a, 1), b.transform_unordered(fu_b, 1)), name
+        assert np.array_equal(a.zreorder(fu_a, 0), fo_b), name
+        assert relerr(po.transform(x, 64, po.REAL, po.FORWARD, True, np.float32), fo_b) <= 1e-6, name
+        assert relerr(po.transform(x, 64, po.REAL, po.FORWARD, False, np.float32), fu_b) <= 1e-6, name
+    # the analytic answer of the tone: bin 5 = (N/2) e^{i 0.3}
+    fo = b.transform_ordered(_c1_inputs()["tone"], 0)
+    assert abs(fo[10] - 32 * np.cos(0.3)) <= 1e-4 and abs(fo[11] - 32 * np.sin(0.3)) <= 1e-4
+    a.close(); b.close()
+
+
+def test_c1_scalar_build_pins_the_fftpack_order_layout():
+    """SCALAR_VECT=OFF as well (SIMD_SZ == 1): simd_size 1, min sizes 2 / 1, ordered output equal (to rounding) to the
+    SIMD_SZ == 4 builds', and the UNORDERED output in FFTPACK's half-complex order r0, r1, i1, ..., r_{N/2}
+    (src/pffft_priv_impl.h:1712-1766: the scalar path's transform IS the ordered transform up to the canonical pack) —
+    the layout SURVEY.md §8(c) warns not to use for unordered / convolution parity."""
+    import os
+    from conftest import missing_checker
+    from oracle import ref as oref
+    if not os.path.exists(oref.REF_SCALAR_SO):
+        oref.build()
+    if not os.path.exists(oref.REF_SCALAR_SO):
+        missing_checker(oref.REF_SCALAR_SO)
+    sc, sse = oref.Reference(oref.REF_SCALAR_SO), oref.get()
+    assert sc.f32.simd_size() == 1 and sc.f32.min_fft_size(0) == 2 and sc.f32.min_fft_size(1) == 1
+    a, b = sc.setup(64, 0), sse.setup(64, 0)
+    for name, x in _c1_inputs().items():
+        fo = a.transform_ordered(x, 0)
+        assert relerr(fo, b.transform_ordered(x, 0)) <= 1e-6, name
+        z = np.fft.rfft(x.astype(np.float64))
+        want_ordered = np.empty(64); want_ordered[0] = z[0].real; want_ordered[1] = z[32].real
+        want_ordered[2::2] = z[1:32].real; want_ordered[3::2] = z[1:32].imag
+        assert relerr(fo, want_ordered) <= 1e-6, name
+        fu = a.transform_unordered(x, 0)
+        want_fftpack = np.empty(64); want_fftpack[0] = z[0].real; want_fftpack[63] = z[32].real
+        want_fftpack[1:63:2] = z[1:32].real; want_fftpack[2:63:2] = z[1:32].imag
+        assert relerr(fu, want_fftpack) <= 1e-6, name
+        assert not np.allclose(fu, b.transform_unordered(x, 0))   # NOT the SIMD_SZ == 4 internal layout
+    a.close(); b.close()

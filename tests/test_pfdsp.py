@@ -35,7 +35,7 @@ def _need_gpu():
 @pytest.fixture(scope="module")
 def R():
     if not pfdsp_ref.available():
-        pytest.skip("oracle/_ref/libpfdsp_ref.so not shipped")
+        __import__("conftest").missing_checker("oracle/_ref/libpfdsp_ref.so")
     return pfdsp_ref.get()
 
 

@@ -26,7 +26,7 @@ def R():
         from oracle import ref as oref
         oref.build()
     if not pfdsp_ref.available():
-        pytest.skip("oracle/_ref/libpfdsp_ref.so not built (needs /root/reference)")
+        __import__("conftest").missing_checker("oracle/_ref/libpfdsp_ref.so")
     return pfdsp_ref.get()
 
 

@@ -2,7 +2,7 @@
 test_fft_factors.c, test_pffastconv.c, benchmarks/bench_pffft.c --validate, examples/*), compiled from their
 sources against libpffft_hip.so by tests/refprogs/Makefile ("the cheapest, strongest
 proof of drop-in").  The executables are built in the dev container (where /root/reference exists) into
-tests/_refbin/ and travel to the GPU box with the snapshot; the tests skip when they are absent."""
+tests/_refbin/ and travel to the GPU box with the snapshot; the tests skip when they are absent on a CPU-only box and FAIL when they are absent on a GPU box."""
 import os
 import subprocess
 
@@ -16,7 +16,8 @@ BIN = os.path.join(ROOT, "tests", "_refbin")
 def _run(name, *args, timeout=900):
     exe = os.path.join(BIN, name)
     if not os.path.exists(exe):
-        pytest.skip(f"{exe} not built (make -C tests/refprogs needs /root/reference)")
+        from conftest import missing_checker
+        missing_checker(exe)
     p = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout)
     return p.returncode, p.stdout + p.stderr
 
