@@ -149,12 +149,13 @@ def cpu_baseline_fir(x: np.ndarray, h: np.ndarray, target_s: float):
 
     t1 = run(1, 2) / 2
     n_out = prod.value
-    best_t, best_rate = 1, n_out / t1
+    best_t, best_rate, best_call = 1, n_out / t1, t1
     for th in sorted({c for c in (8, 16, 32, 64, 128, cores) if c <= cores}):
-        rate = th * 2 * n_out / run(th, 2)
+        tt = run(th, 2)
+        rate = th * 2 * n_out / tt
         if rate > best_rate:
-            best_t, best_rate = th, rate
-    reps = max(2, int(target_s * best_rate / (best_t * n_out)))
+            best_t, best_rate, best_call = th, rate, tt / 2
+    reps = max(2, min(100000, int(target_s / (1.5 * best_call))))   # the sustained rate is lower than the calibration's
     t = run(best_t, reps)
     rate = best_t * reps * n_out / t
     return {"value": round(rate / 1e9, 4), "unit": "G output samples/s", "cores": best_t, "kind": "reference",
