@@ -1,0 +1,455 @@
+// LDS-DMA staged variants of the register-tiled power-of-two kernels (fft_tiled.h) for the transforms that need a
+// whole workgroup per vector (n >= 2048 complex points in float: 16 ... 64 KiB per vector).
+//
+// Same reference functions as fft_tiled.h (cfftf1_ps / rfftf1_ps / rfftb1_ps pass drivers, src/pffft_priv_impl.h:809-901,
+// :1004-1048, with the finalize / preprocess / zreorder steps :1158-1462 folded in): one pass over HBM per vector.
+//
+// What was wrong with the register-staged kernels at these sizes (VERDICT r01 "C3 0.63"): a vector does
+// not fit the registers twice, so the loads of the NEXT vector could not be kept in flight while the current one was
+// transformed (the prefetch registers spilled), and with 64 KiB of LDS image per vector only two workgroups fit a CU —
+// HBM idled whenever both were in a compute phase.
+//
+// Here ONE persistent 512-thread workgroup per CU owns TWO LDS images.  While image A is transformed in place (stage-0
+// operands are read straight from it, the exchanges of the later stages reuse it), the next group of vectors lands in
+// image B by `global_load_lds_dwordx4` — asynchronous global -> LDS copies that occupy no VGPR and need no ds_write
+// pass.  The probe tools/dma_probe.hip measured this skeleton (64 KiB groups pulled in order from an atomic counter,
+// counted `s_waitcnt vmcnt`) at 0.78-0.80 of the 8 TB/s roofline with up to four conflict-free LDS exchanges and ~600
+// VALU instructions per thread per group fully hidden behind the DMA.
+//
+// Ordering rules of the DMA (MI355X_MICROARCH.md "Two waves per SIMD" item 7, cdna_hip_programming.md §LDS-DMA):
+//   * a landed piece may be read only after the ISSUING wave's `s_waitcnt vmcnt` has retired it AND a barrier the reader
+//     passed afterwards: top of every iteration = counted vmcnt -> lgkmcnt(0) -> s_barrier, the reads come after it;
+//   * the pieces of group i+1 are issued after that same barrier, i.e. after every wave finished reading image B in
+//     iteration i-1 (write-after-read), and are older than the global stores of iteration i, so the wait at the top of
+//     iteration i+1 is `vmcnt(<stores per thread>)`: the stores stay in flight;
+//   * barriers inside the iteration are raw `s_barrier` + `lgkmcnt(0)` (never a fence that drains vmcnt).
+#pragma once
+#include "fft_tiled.h"
+#include "fft_fir.h"
+
+namespace pf {
+
+// one 1 KiB piece: lane L copies 16 bytes from gsrc to LDS byte address lds_dst + 16 L (lds_dst wave-uniform)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wg_sync_raw() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+template <class C> struct DmaGeom {
+    typedef typename C::real_t T;
+    static constexpr int VEC_BYTES = C::n * 2 * (int)sizeof(T);
+    static constexpr int GROUP_BYTES = C::T_PER_WG * VEC_BYTES;       // contiguous in HBM
+    static constexpr int PIECES = GROUP_BYTES / 1024, WAVES = C::WG_THREADS / 64, PPW = PIECES / WAVES;
+    static constexpr int PPV = VEC_BYTES / 1024;                      // pieces per vector
+    static constexpr int IMG_BYTES = C::IMG * 2 * (int)sizeof(T);
+    static constexpr int BUF_BYTES = C::T_PER_WG * IMG_BYTES;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES + 16;
+    static constexpr int NSTORE = C::NCH;                             // 16-byte global stores per thread and iteration
+    static_assert(PIECES % WAVES == 0 && PPW >= 1, "a group must split into whole 1 KiB pieces per wavefront");
+    static_assert(VEC_BYTES % 1024 == 0, "a vector must be a whole number of 1 KiB pieces");
+    static_assert(LDS_BYTES <= 160 * 1024, "two images must fit LDS");
+    static_assert(C::TWMODE == 3 || C::TWMODE == 0, "register twiddles only (no LDS table next to two images)");
+};
+
+// flags: bit0 = input in internal layout, bit1 = output in internal layout
+// COUNTED = 1: the counted vmcnt of the header; 0: vmcnt(0) (A/B)
+template <class C, int DIR, int REAL, int COUNTED = 1>
+__global__ void __launch_bounds__(C::WG_THREADS, 1)
+fft_dma_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned batch, int flags,
+               const cx<typename C::real_t>* __restrict__ twg, const cx<typename C::real_t>* __restrict__ twrg,
+               unsigned* ctr) {
+    typedef typename C::real_t T;
+    typedef cx<T> CX;
+    typedef Tiled<C, DIR, REAL> K;
+    typedef typename K::S0 S0;
+    typedef typename K::SL SL;
+    typedef ChunkOps<T> CO;
+    typedef DmaGeom<C> G;
+    constexpr int n = C::n, E = C::E, TPT = C::TPT, VEC = C::VEC, CH = C::CH, NCH = C::NCH;
+    constexpr int R0 = K::R0, RL = K::RL;
+    static_assert(VEC == 1 || (S0::PAIR && SL::PAIR), "float configs need an even butterfly count in the first/last stage");
+    static_assert(TPT >= 64, "one or more wavefronts per transform");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int slot = threadIdx.x / TPT, t = threadIdx.x % TPT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + 2 * (size_t)G::BUF_BYTES);
+    const bool in_int = flags & 1, out_int = flags & 2;
+    const bool plain_in = REAL ? (DIR == FWD) : !in_int;   // stage-0 operand order straight from the landed vector
+    const bool plain_out = REAL ? (DIR == BWD) : !out_int;
+
+    typename K::Tw w;
+    K::load_tw(w, t, twg, twrg);
+    const CX* twt = twg;
+
+    const bool dyn = ctr != nullptr;
+    unsigned pend = 0;
+    unsigned g = blockIdx.x;
+    if (dyn && threadIdx.x == 0) {
+        s_next[0] = atomicAdd(&ctr[0], 1u);
+        pend = atomicAdd(&ctr[0], 1u);
+    }
+    __syncthreads();
+    if (dyn) g = s_next[0];
+    const size_t last = (size_t)batch - 1;
+
+    // pieces of group `grp` into image `b`: piece p = wave + WAVES i holds bytes [1024 p, 1024 p + 1024) of the group
+    auto issue = [&](unsigned grp, int b) {
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i) {
+            const int p = wave + G::WAVES * i;
+            const int sl = p / G::PPV, pv = p % G::PPV;
+            size_t tr = (size_t)grp * C::T_PER_WG + sl;
+            if (tr > last) tr = last;                           // slots beyond the batch re-read the last vector
+            const char* src = reinterpret_cast<const char*>(in) + tr * (size_t)G::VEC_BYTES + pv * 1024 + lane * 16;
+            glds16(src, lds0 + (unsigned)(b * G::BUF_BYTES + sl * G::IMG_BYTES + pv * 1024));
+        }
+    };
+    issue(g, 0);
+    int b = 0;
+    bool prev_full = false;
+    for (unsigned it = 0; (size_t)g * C::T_PER_WG < batch; ++it) {
+        if (dyn && threadIdx.x == 0) {
+            s_next[(it + 1) & 1] = pend;
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        // ---- the group of this iteration has landed (its pieces are older than the previous iteration's stores)
+        if (COUNTED && prev_full) wait_vmcnt<G::NSTORE>(); else wait_vmcnt<0>();
+        wg_sync_raw();
+        const unsigned gn = dyn ? s_next[(it + 1) & 1] : g + gridDim.x;
+        issue(gn, b ^ 1);                                        // lands while this group is transformed
+        const size_t tr = (size_t)g * C::T_PER_WG + slot;
+        const bool active = tr < batch;
+        prev_full = ((size_t)g + 1) * C::T_PER_WG <= batch;      // every wave issues exactly NSTORE stores
+        T* dst = out + (active ? tr : last) * 2 * (size_t)n;
+        CX* img = reinterpret_cast<CX*>(smem_raw + (size_t)b * G::BUF_BYTES) + (size_t)slot * C::IMG;
+        T* imgs = reinterpret_cast<T*>(img);
+        const chunk16* land16 = reinterpret_cast<const chunk16*>(img);  // the landed vector: linear, unpadded
+        CX v[E];
+        int tl = t;
+        asm volatile("" : "+v"(tl));
+
+        // ------------------------------------------------------------------ input
+        if (plain_in) {
+            if constexpr (VEC == 2) {
+#pragma unroll
+                for (int ii = 0; ii < S0::B / 2; ++ii)
+#pragma unroll
+                    for (int q = 0; q < R0; ++q) {
+                        const chunk16 c = land16[K::plain_chunk(t, ii * R0 + q)];
+                        v[(2 * ii) * R0 + q] = mk<T>(c.x, c.y);
+                        v[(2 * ii + 1) * R0 + q] = mk<T>(c.z, c.w);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const chunk16 c = land16[K::plain_chunk(t, i)];
+                    v[i] = mk<T>(CO::get(c, 0), CO::get(c, 1));
+                }
+            }
+        } else if (in_int) {
+            // internal layout: the landed linear chunks move into the padded block image (16-byte accesses), then every
+            // thread picks the scalars of its own stage-0 operands
+            chunk16 raw[NCH];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) raw[i] = land16[t + TPT * i];
+            wg_sync_raw();
+            chunk16* im16 = reinterpret_cast<chunk16*>(imgs);
+            constexpr int CPB = 32 / CH;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = t + TPT * i;
+                im16[(c / CPB) * (C::IBS / CH) + (c % CPB)] = raw[i];
+            }
+            wg_sync_raw();
+#pragma unroll
+            for (int u = 0; u < S0::B; ++u)
+#pragma unroll
+                for (int q = 0; q < R0; ++q) {
+                    const int ip = K::template ipos<R0>(K::template jm<0>(t, u), q);
+                    v[u * R0 + q] = mk<T>(imgs[ip], imgs[ip + 4]);
+                }
+            if constexpr (REAL) K::pair_regs(v, t, w);
+        } else {
+            // canonical half-complex spectrum (real backward): the landed vector IS the natural-order image, unpadded
+#pragma unroll
+            for (int u = 0; u < S0::B; ++u)
+#pragma unroll
+                for (int q = 0; q < R0; ++q) {
+                    const int j = K::template jm<0>(tl, u);
+                    v[u * R0 + q] = lds_ld(img + j + q * (n / R0));
+                }
+            if constexpr (REAL) K::pair_regs(v, t, w);
+        }
+
+        // ------------------------------------------------------------------ transform (exchanges reuse the image in place)
+        K::template butterflies<0>(v, t, w, twt);
+        wg_sync_raw();                                           // every thread holds its stage-0 operands: the image is free
+        if constexpr (C::NS > 1) { K::template xwrite<0>(v, t, img); wg_sync_raw(); K::template xread<0>(v, t, img); wg_sync_raw(); K::template butterflies<1>(v, t, w, twt); }
+        if constexpr (C::NS > 2) { K::template xwrite<1>(v, t, img); wg_sync_raw(); K::template xread<1>(v, t, img); wg_sync_raw(); K::template butterflies<2>(v, t, w, twt); }
+        if constexpr (C::NS > 3) { K::template xwrite<2>(v, t, img); wg_sync_raw(); K::template xread<2>(v, t, img); wg_sync_raw(); K::template butterflies<3>(v, t, w, twt); }
+
+        // ------------------------------------------------------------------ output
+        if (plain_out) {
+            if (active) {
+                chunk16* d16 = reinterpret_cast<chunk16*>(dst);
+                if constexpr (VEC == 2) {
+#pragma unroll
+                    for (int ii = 0; ii < SL::B / 2; ++ii)
+#pragma unroll
+                        for (int d = 0; d < RL; ++d) {
+                            const CX a = v[(2 * ii) * RL + d], bb = v[(2 * ii + 1) * RL + d];
+                            chunk16 x; x.x = a.x; x.y = a.y; x.z = bb.x; x.w = bb.y;
+                            __builtin_nontemporal_store(x, d16 + t + TPT * ii + d * (n / (2 * RL)));
+                        }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SL::B; ++u)
+#pragma unroll
+                        for (int d = 0; d < RL; ++d) {
+                            chunk16 x;
+                            CO::set(x, 0, v[u * RL + d].x); CO::set(x, 1, v[u * RL + d].y);
+                            __builtin_nontemporal_store(x, d16 + t + TPT * u + d * (n / RL));
+                        }
+                }
+            }
+        } else {
+            if constexpr (REAL) K::pair_regs(v, t, w);
+            if (out_int) {
+                // scatter re / im scalars into the padded internal-layout image, read it back linearly
+#pragma unroll
+                for (int u = 0; u < SL::B; ++u)
+#pragma unroll
+                    for (int d = 0; d < RL; ++d) {
+                        const int ip = K::template ipos<RL>(K::template jm<C::NS - 1>(t, u), d);
+                        imgs[ip] = v[u * RL + d].x;
+                        imgs[ip + 4] = v[u * RL + d].y;
+                    }
+                wg_sync_raw();
+                const chunk16* im16 = reinterpret_cast<const chunk16*>(imgs);
+                chunk16* d16o = reinterpret_cast<chunk16*>(dst);
+                constexpr int CPB = 32 / CH;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = t + TPT * i;
+                    const chunk16 o = im16[(c / CPB) * (C::IBS / CH) + (c % CPB)];
+                    if (active) __builtin_nontemporal_store(o, d16o + c);
+                }
+            } else {
+                // canonical half-complex spectrum (real forward, ordered): natural-order image, linear chunks out
+#pragma unroll
+                for (int u = 0; u < SL::B; ++u)
+#pragma unroll
+                    for (int d = 0; d < RL; ++d) {
+                        const int j = K::template jm<C::NS - 1>(t, u);
+                        lds_st(img + j + C::PADN * (j >> 6) + K::nat_off(d * (n / RL)), v[u * RL + d]);
+                    }
+                wg_sync_raw();
+                chunk16* d16 = reinterpret_cast<chunk16*>(dst);
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = tl + TPT * i;
+                    chunk16 o;
+                    if constexpr (VEC == 2) {
+                        const CX a = lds_ld(img + phys_nat<C>(2 * c)), bb = lds_ld(img + phys_nat<C>(2 * c + 1));
+                        o.x = a.x; o.y = a.y; o.z = bb.x; o.w = bb.y;
+                    } else {
+                        const CX a = lds_ld(img + phys_nat<C>(c));
+                        CO::set(o, 0, a.x); CO::set(o, 1, a.y);
+                    }
+                    if (active) __builtin_nontemporal_store(o, d16 + c);
+                }
+            }
+        }
+        g = gn;
+        b ^= 1;
+    }
+    wait_vmcnt<0>();                                             // the speculative pieces of the group after the last one
+    if (dyn && threadIdx.x == 0) {
+        __threadfence();
+        unsigned d = atomicAdd(&ctr[1], 1u);
+        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Overlap-save FIR block kernel on the same skeleton (the register-staged one: fft_fir.h; reference: the block loop of
+// pffastconv_apply, src/pffastconv.c:207-261).  A block's Nfft input floats land by DMA (block offsets are multiples
+// of 4 bytes only: the copies are dword-aligned 16-byte transfers), forward real FFT, x Hf, inverse real FFT in
+// registers / one LDS image, stores of the valid samples; the next group of blocks lands meanwhile.
+// The store count per wave varies (ragged last chunk), so the landing wait is vmcnt(0) (measured equal to the counted
+// wait on the copy skeleton, tools/dma_probe.hip).
+template <class C>
+__global__ void __launch_bounds__(C::WG_THREADS, 1)
+fastconv_dma_kernel(const float* __restrict__ x, float* __restrict__ y, const cx<float>* __restrict__ Hc,
+                    int nblk, int step, int inputLen, int lastOut,
+                    const cx<float>* __restrict__ twg, const cx<float>* __restrict__ twrg, unsigned* ctr,
+                    int nsig, size_t xstride, size_t ystride) {
+    typedef float T;
+    typedef cx<T> CX;
+    typedef Tiled<C, FWD, 1> KF;
+    typedef Tiled<C, BWD, 1> KB;
+    typedef DmaGeom<C> G;
+    constexpr int n = C::n, E = C::E, TPT = C::TPT, NS = C::NS;
+    constexpr int R0 = C::rad(0), RL = C::rad(NS - 1);
+    static_assert(R0 == RL && E / R0 == 2 && C::VEC == 2, "fused FIR needs R0 == RL, two butterflies per thread, float");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int slot = threadIdx.x / TPT, t = threadIdx.x % TPT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + 2 * (size_t)G::BUF_BYTES);
+
+    typename KF::Tw wf;
+    typename KB::Tw wb;
+    KF::load_tw(wf, t, twg, twrg);
+    KB::load_tw(wb, t, twg, twrg);
+    CX h[E];   // filter spectrum of the bins this thread owns after the forward transform: k = jm(t,u) + d n/R
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int d = 0; d < RL; ++d) h[u * RL + d] = Hc[KF::template jm<NS - 1>(t, u) + d * (n / RL)];
+
+    const bool dyn = ctr != nullptr;
+    unsigned pend = 0;
+    unsigned g = blockIdx.x;
+    if (dyn && threadIdx.x == 0) {
+        s_next[0] = atomicAdd(&ctr[0], 1u);
+        pend = atomicAdd(&ctr[0], 1u);
+    }
+    __syncthreads();
+    if (dyn) g = s_next[0];
+    const long long nblk_all = (long long)nblk * nsig;
+    // the last 16 bytes a lane may read: copies that would run past the signal are clamped there (their samples are
+    // replaced by the zero padding of src/pffastconv.c:231-233 when the operands are picked up)
+    auto issue = [&](unsigned grp, int b) {
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i) {
+            const int p = wave + G::WAVES * i;
+            const int sl = p / G::PPV, pv = p % G::PPV;
+            long long ba = (long long)grp * C::T_PER_WG + sl;
+            if (ba >= nblk_all) ba = nblk_all - 1;
+            const int sig = (int)(ba / nblk);
+            const int blk = (int)(ba - (long long)sig * nblk);
+            long e = (long)blk * step + pv * 256 + lane * 4;     // first of this lane's 4 floats
+            if (e > (long)inputLen - 4) e = inputLen >= 4 ? (long)inputLen - 4 : 0;
+            glds16(x + (size_t)sig * xstride + e, lds0 + (unsigned)(b * G::BUF_BYTES + sl * G::IMG_BYTES + pv * 1024));
+        }
+    };
+    issue(g, 0);
+    int b = 0;
+    for (unsigned it = 0; (long long)g * C::T_PER_WG < nblk_all; ++it) {
+        if (dyn && threadIdx.x == 0) {
+            s_next[(it + 1) & 1] = pend;
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        wait_vmcnt<0>();
+        wg_sync_raw();
+        const unsigned gn = dyn ? s_next[(it + 1) & 1] : g + gridDim.x;
+        issue(gn, b ^ 1);
+        const long long blk_all = (long long)g * C::T_PER_WG + slot;
+        const bool active = blk_all < nblk_all;
+        const int sig = active ? (int)(blk_all / nblk) : nsig - 1;
+        const int blk = active ? (int)(blk_all - (long long)sig * nblk) : nblk - 1;
+        const long off = (long)blk * step;
+        const int numOut = (active && blk == nblk - 1) ? lastOut : step;
+        float* ys = y + (size_t)sig * ystride;
+        CX* img = reinterpret_cast<CX*>(smem_raw + (size_t)b * G::BUF_BYTES) + (size_t)slot * C::IMG;
+        const chunk16* land16 = reinterpret_cast<const chunk16*>(img);
+        CX v[E];
+        // ---- stage-0 operands from the landed block, zero beyond the end of the signal (src/pffastconv.c:231-233).
+        //      A clamped copy (issue) holds x[inputLen-4 .. inputLen-1] in place of the lane's own 4 floats: lanes whose
+        //      first float is past inputLen-4 rebuild their samples from it.
+        {
+            const long avail = (long)inputLen - off;  // samples of this block that exist
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                const int c = t + q * (n / (2 * R0));
+                const int e0 = 4 * c;
+                const chunk16 cc = land16[c];
+                float f0 = cc.x, f1 = cc.y, f2 = cc.z, f3 = cc.w;
+                if (e0 + 3 >= avail) {
+                    // the copy of this chunk was clamped to the last 4 floats of the signal (issue): its element k is
+                    // sample avail - 4 + k of the block, so sample e0 + k = element k + sh, zero padding beyond
+                    const long sh = (long)e0 - (avail - 4);      // >= 1
+                    f0 = sh == 1 ? cc.y : sh == 2 ? cc.z : sh == 3 ? cc.w : 0.f;
+                    f1 = sh == 1 ? cc.z : sh == 2 ? cc.w : 0.f;
+                    f2 = sh == 1 ? cc.w : 0.f;
+                    f3 = 0.f;
+                }
+                v[q] = mk<T>(f0, f1);
+                v[R0 + q] = mk<T>(f2, f3);
+            }
+        }
+        // ---- forward transform ----
+        KF::template butterflies<0>(v, t, wf, twg);
+        wg_sync_raw();
+        KF::template xwrite<0>(v, t, img); wg_sync_raw();
+        KF::template xread<0>(v, t, img); wg_sync_raw(); KF::template butterflies<1>(v, t, wf, twg);
+        if constexpr (NS > 2) { KF::template xwrite<1>(v, t, img); wg_sync_raw(); KF::template xread<1>(v, t, img); wg_sync_raw(); KF::template butterflies<2>(v, t, wf, twg); }
+        if constexpr (NS > 3) { KF::template xwrite<2>(v, t, img); wg_sync_raw(); KF::template xread<2>(v, t, img); wg_sync_raw(); KF::template butterflies<3>(v, t, wf, twg); }
+        KF::pair_regs(v, t, wf);                       // packed spectrum -> half-complex spectrum X[k]
+        // ---- X[k] * H[k] (scaled by 1/Nfft, src/pffastconv.c:97,238); bin 0 carries (DC, Nyquist): two real products
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const CX p = cmul(v[i], h[i]);
+            if (i == 0) {
+                const CX r = mk<T>(v[0].x * h[0].x, v[0].y * h[0].y);
+                v[0] = KF::sel(t == 0, r, p);
+            } else {
+                v[i] = p;
+            }
+        }
+        KB::pair_regs(v, t, wb);                       // half-complex spectrum -> packed spectrum of the inverse
+        // ---- backward transform (first-stage operands are already in place) ----
+        KB::template butterflies<0>(v, t, wb, twg);
+        KB::template xwrite<0>(v, t, img); wg_sync_raw();
+        KB::template xread<0>(v, t, img); wg_sync_raw(); KB::template butterflies<1>(v, t, wb, twg);
+        if constexpr (NS > 2) { KB::template xwrite<1>(v, t, img); wg_sync_raw(); KB::template xread<1>(v, t, img); wg_sync_raw(); KB::template butterflies<2>(v, t, wb, twg); }
+        if constexpr (NS > 3) { KB::template xwrite<2>(v, t, img); wg_sync_raw(); KB::template xread<2>(v, t, img); wg_sync_raw(); KB::template butterflies<3>(v, t, wb, twg); }
+        // ---- the first numOut samples (src/pffastconv.c:255) ----
+        if (active) {
+            float* dst = ys + off;
+#pragma unroll
+            for (int d = 0; d < RL; ++d) {
+                const int e0 = 4 * (t + d * (n / (2 * RL)));
+                const CX a = v[d], bb = v[RL + d];
+                if (e0 + 3 < numOut) {
+                    F4u q4; q4.a = a.x; q4.b = a.y; q4.c = bb.x; q4.d = bb.y;
+                    *reinterpret_cast<F4u*>(dst + e0) = q4;
+                } else {
+                    if (e0 < numOut) dst[e0] = a.x;
+                    if (e0 + 1 < numOut) dst[e0 + 1] = a.y;
+                    if (e0 + 2 < numOut) dst[e0 + 2] = bb.x;
+                }
+            }
+        }
+        g = gn;
+        b ^= 1;
+    }
+    wait_vmcnt<0>();
+    if (dyn && threadIdx.x == 0) {
+        __threadfence();
+        unsigned d = atomicAdd(&ctr[1], 1u);
+        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+}
+
+// ---- configurations: <T, log2 n, threads/transform, stages, R0..R3, PAD0, PADN, TWMODE, PREFETCH(unused), WG threads, OCC> ----
+// 16 points per thread, 512-thread workgroups: n = 8192 one vector per workgroup iteration, 4096 two, 2048 four.
+struct DmaCfgF32 {
+    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 0, 512, 1> D8192;
+    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 0, 0, 512, 1> D8192t0;   // every twiddle in registers
+    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 0, 512, 1> D4096;
+    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 8, 3, 0, 512, 1> D2048;
+};
+
+}  // namespace pf

@@ -173,7 +173,7 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
 }
 
 // scale a canonical half-complex spectrum (n bins) into the table the fused kernel multiplies with
-__global__ void fastconv_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int count, float s) {
+static __global__ void fastconv_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int count, float s) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) out[i] = in[i] * s;
 }
 

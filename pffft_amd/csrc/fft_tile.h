@@ -1,0 +1,272 @@
+// Power-of-two transforms beyond LDS in TWO (n <= 2^20) or THREE (n <= 2^27) passes over HBM.
+//
+// Reference: what the reference does for every size — one sweep over main memory per radix pass (cfftf1_ps,
+// src/pffft_priv_impl.h:1004-1048; N up to 2^26 accepted, :1069) — reduced to the minimum a workgroup's LDS allows.
+// Replaces, for power-of-two n, the three-to-five-sweep composition of fft_big.h (0.10-0.24 of the
+// roofline, >= 6 x vector bytes moved against 2 x algorithmic).
+//
+// n = N1 N2:   x[n1 N2 + n2] --pass A--> Y[k1 N2 + n2] = W_n^(k1 n2) sum_n1 x[..] W_N1^(n1 k1)
+//              Y[k1 N2 + n2] --pass B--> X[k1 + N1 k2] = sum_n2 Y[..] W_N2^(n2 k2)
+// Both passes are the same kernel on a TILE of C sequences x L points held in one LDS image [point][sequence]
+// (sequence fastest, 16-byte units = 2 float / 1 double sequences, rows padded by one unit):
+//   pass A: the C sequences are ADJACENT COLUMNS — every global access is a run of C complex numbers (128 bytes), the
+//           loads go straight into the stage-0 operand registers;
+//   pass B: the C sequences are C rows (contiguous over their points): coalesced loads, transposed into the image,
+//           and the spectrum leaves from the image in runs of C adjacent k1 — the transpose is the store.
+// Radix-8 Stockham stages (a leading radix 2 / 4 for odd log2 L), 8 points per thread and sequence, stage twiddles
+// W_L^k and the four-step twiddles W_M^m (three-level 512-entry tables, two products per twiddle) built in LDS at kernel
+// start by exact-argument sincospi in double: no host tables.
+// n > 2^20: n = L1 (L2 L3): pass A over L1, then passes A / B on the rows of length L2 L3 with the scatter of the last pass
+// carrying both outer indices (TileDesc strides).
+#pragma once
+#include <type_traits>
+
+#include "cxmath.h"
+
+namespace pf {
+
+struct TileDesc {
+    unsigned TA, TB;                                  // tiles per vector: TA x TB; tile id = (vec TA + a) TB + b
+    unsigned long long vstride;                       // complex elements per vector
+    unsigned long long in_a, in_b, out_a, out_b;      // tile base = vec vstride + a x_a + b x_b
+    unsigned long long ips, iss;                      // input strides between points / between sequences
+    unsigned long long ops;                           // output stride between points (sequences are adjacent)
+    unsigned col_a, col_b;                            // four-step twiddle column of sequence c: a col_a + b col_b + c
+    unsigned long long M;                             // modulus of the four-step twiddle, output (k, c) *= W_M^(k col); 0 = none
+    int seq_contig;                                   // 1: pass A tile (iss == 1), 0: pass B tile (ips == 1)
+};
+
+template <typename T> struct TileUnit;                // one 16-byte LDS / global unit
+template <> struct TileUnit<float> {
+    typedef __attribute__((ext_vector_type(4))) float U;
+    static constexpr int S = 2;
+    static __device__ __forceinline__ cx<float> get(const U& u, int s) { return s ? mk<float>(u.z, u.w) : mk<float>(u.x, u.y); }
+    static __device__ __forceinline__ void set(U& u, int s, cx<float> v) { if (s) { u.z = v.x; u.w = v.y; } else { u.x = v.x; u.y = v.y; } }
+};
+template <> struct TileUnit<double> {
+    typedef __attribute__((ext_vector_type(2))) double U;
+    static constexpr int S = 1;
+    static __device__ __forceinline__ cx<double> get(const U& u, int) { return mk<double>(u.x, u.y); }
+    static __device__ __forceinline__ void set(U& u, int, cx<double> v) { u.x = v.x; u.y = v.y; }
+};
+
+template <typename T, int LOGL, int PP> struct TileGeom {
+    static constexpr int L = 1 << LOGL, TPT = L / 8, WG = TPT * PP, S = TileUnit<T>::S, C = PP * S;
+    static constexpr int PITCH = PP + 1;                                  // 16-byte units per point row
+    static constexpr int NS = (LOGL + 2) / 3;
+    static constexpr size_t IMG_BYTES = (size_t)L * PITCH * 16;
+    // + W_L^k (L entries) + `levels` x 512 entries of the four-step twiddle table
+    __host__ __device__ static constexpr size_t lds_bytes(int levels) { return IMG_BYTES + ((size_t)L + (size_t)levels * 512) * 2 * sizeof(T) + 16; }
+    __host__ __device__ static constexpr int rad(int s) { return (LOGL % 3 == 0 || s > 0) ? 8 : (1 << (LOGL % 3)); }
+    __host__ __device__ static constexpr int nsprod(int s) { int p = 1; for (int i = 0; i < s; ++i) p *= rad(i); return p; }
+};
+
+template <typename T> __device__ __forceinline__ cx<T> tile_unit_root(double turns) {   // exp(-2 pi i turns)
+    double sn, cs;
+    sincospi(2.0 * turns, &sn, &cs);
+    return mk<T>((T)cs, (T)-sn);
+}
+
+// `levels`-level 512-entry table of W_M^m: w3[l][d] = W_M^(d 512^l); W_M^idx = product of its digits' entries
+template <typename CX> __device__ __forceinline__ CX tile_w3(const CX* w3, unsigned idx, bool lv3) {
+    CX f = cmul(w3[idx & 511], w3[512 + ((idx >> 9) & 511)]);
+    if (lv3) f = cmul(f, w3[1024 + (idx >> 18)]);
+    return f;
+}
+
+// SEQC = 1: pass A (adjacent columns, four-step twiddle)   SEQC = 0: pass B (rows in, transposing store)
+// PF = 1: the loads of the workgroup's next tile fly while the current one is transformed (for the tiles so large that
+//         one workgroup fills a CU: nothing else would overlap its load latency)
+template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF>
+__global__ void __launch_bounds__((1 << LOGL) / 8 * PP, PF ? 2 : 3)
+tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned long long ntiles, TileDesc D, unsigned* ctr) {
+    typedef cx<T> CX;
+    typedef TileGeom<T, LOGL, PP> G;
+    typedef TileUnit<T> TU;
+    typedef typename TU::U U;
+    constexpr int L = G::L, TPT = G::TPT, WG = G::WG, S = G::S, C = G::C, PITCH = G::PITCH, NS = G::NS;
+    constexpr int NLD = SEQC ? 8 : C * L / WG / (S == 2 ? 1 : 1);   // loads per thread and tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    U* img = reinterpret_cast<U*>(smem);
+    CX* wl = reinterpret_cast<CX*>(smem + G::IMG_BYTES);
+    CX* w3 = wl + L;
+    const int tid = threadIdx.x, t = tid / PP, p = tid % PP;
+
+    for (int i = tid; i < L; i += WG) wl[i] = tile_unit_root<T>((double)i / (double)L);
+    const bool lv3 = D.M > (1ull << 18);
+    if (SEQC) {
+        const double invM = 1.0 / (double)D.M;
+        for (int i = tid; i < (lv3 ? 3 : 2) * 512; i += WG) {
+            const int lvl = i >> 9, m = i & 511;
+            w3[i] = tile_unit_root<T>((double)m * (double)(1u << (9 * lvl)) * invM);
+        }
+    }
+    __syncthreads();
+    // four-step twiddle of output k = t + d L/8 of column col0 + c:  W^(t col0) W^(t c) [W^((L/8) col0) W^((L/8) c)]^d :
+    // the c-dependent factors are per-thread constants, the col0-dependent ones one table product per tile
+    CX c0[S], c1[S];
+    if constexpr (SEQC) {
+#pragma unroll
+        for (int sq = 0; sq < S; ++sq) {
+            c0[sq] = tile_w3(w3, (unsigned)t * (unsigned)(S * p + sq), lv3);
+            c1[sq] = tile_w3(w3, (unsigned)(L / 8) * (unsigned)(S * p + sq), lv3);
+        }
+    }
+
+    auto tile_bases = [&](unsigned long long tile, const CX*& src, CX*& dst, unsigned& col0) {
+        const unsigned b = (unsigned)(tile % D.TB);
+        const unsigned long long rest = tile / D.TB;
+        const unsigned a = (unsigned)(rest % D.TA);
+        const unsigned long long vec = rest / D.TA;
+        src = in + vec * D.vstride + a * D.in_a + b * D.in_b;
+        dst = out + vec * D.vstride + a * D.out_a + b * D.out_b;
+        col0 = a * D.col_a + b * D.col_b;
+    };
+    // pass A: unit p of points t + TPT m straight into the stage-0 operand registers;
+    // pass B: elements g = tid + i WG of the [sequence][point] tile (coalesced over the points of a row)
+    typedef typename std::conditional<SEQC != 0, U, CX>::type LD;
+    auto issue_loads = [&](const CX* src, LD (&r)[NLD]) {
+        if constexpr (SEQC) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                r[m] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)(t + TPT * m) * D.ips + S * p));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int g = tid + i * WG, seq = g / L, pt = g % L;
+                r[i] = __builtin_nontemporal_load(src + (unsigned long long)seq * D.iss + pt);
+            }
+        }
+    };
+
+    // Tiles are taken IN ORDER from an atomic counter (ctr != nullptr): the workgroups in flight then sweep neighbouring
+    // column bands / row blocks together, which HBM rewards; the grab runs two tiles ahead so that the
+    // prefetch knows its tile.  ctr == nullptr: static stride.
+    unsigned* s_next = reinterpret_cast<unsigned*>(w3 + (lv3 ? 3 : 2) * 512);
+    const bool dyn = ctr != nullptr;
+    unsigned long long tile = blockIdx.x, tile1 = (unsigned long long)blockIdx.x + gridDim.x;
+    unsigned pend = 0;
+    if (dyn) {
+        if (tid == 0) {
+            s_next[0] = atomicAdd(&ctr[0], 1u);
+            s_next[1] = atomicAdd(&ctr[0], 1u);
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        __syncthreads();
+        tile = s_next[0]; tile1 = s_next[1];
+        __syncthreads();
+    }
+    LD nxt[NLD];
+    if constexpr (PF) {
+        if (tile < ntiles) { const CX* s0; CX* d0; unsigned cc; tile_bases(tile, s0, d0, cc); issue_loads(s0, nxt); }
+    }
+    for (unsigned it = 0; tile < ntiles; ++it) {
+        if (dyn && tid == 0) {
+            s_next[it & 1] = pend;                   // tile of iteration it + 2, read by everyone after the first barrier below
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        const CX* src; CX* dst; unsigned col0;
+        tile_bases(tile, src, dst, col0);
+        LD cur[NLD];
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) cur[i] = nxt[i];
+            if (tile1 < ntiles) { const CX* s1; CX* d1; unsigned cc; tile_bases(tile1, s1, d1, cc); issue_loads(s1, nxt); }
+        } else {
+            issue_loads(src, cur);
+        }
+        U v[8];   // v[m] = unit p of point t + TPT m
+        if constexpr (SEQC) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = cur[m];
+        } else {
+            // C rows, contiguous over their points: transposed into the [point][sequence] image
+            CX* imgc = reinterpret_cast<CX*>(img);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int g = tid + i * WG, seq = g / L, pt = g % L;
+                imgc[pt * (PITCH * S) + seq] = cur[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p];
+            __syncthreads();
+        }
+        // ---- Stockham stages; stage s, butterfly u (point j = t + TPT u): operands v[u + q B], outputs to
+        //      (j div Ns) Ns R + (j mod Ns) + d Ns
+        auto stage = [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int R = G::rad(s), B = 8 / R, Ns = G::nsprod(s);
+            if constexpr (s > 0) {
+                __syncthreads();                     // every thread wrote its outputs of the stage before
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p];
+                __syncthreads();                     // ... and read its operands: the image is free again
+            }
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const int j = t + TPT * u;
+                CX w[R];
+                if constexpr (s > 0) {
+                    const int k = j & (Ns - 1);
+#pragma unroll
+                    for (int q = 1; q < R; ++q) w[q] = wl[(q * k) * (L / (Ns * R))];
+                }
+                CX o[S][R];
+#pragma unroll
+                for (int sq = 0; sq < S; ++sq) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {
+                        o[sq][q] = TU::get(v[u + q * B], sq);
+                        if constexpr (s > 0) if (q) o[sq][q] = twmul<DIR>(o[sq][q], w[q]);
+                    }
+                    dftR<R, DIR>(o[sq]);
+                }
+                if constexpr (SEQC && s == NS - 1 && NS > 1) {
+                    // the last stage is a radix 8 with one butterfly per thread: outputs k = t + d L/8
+                    static_assert(R == 8 && B == 1 && Ns == L / 8, "last stage shape");
+                    const CX A = tile_w3(w3, (unsigned)t * col0, lv3), Bc = tile_w3(w3, (unsigned)(L / 8) * col0, lv3);
+#pragma unroll
+                    for (int sq = 0; sq < S; ++sq) {
+                        CX f[8];
+                        f[0] = cmul(A, c0[sq]);
+                        const CX st = cmul(Bc, c1[sq]), st2 = cmul(st, st), st4 = cmul(st2, st2);
+                        f[1] = cmul(f[0], st); f[2] = cmul(f[0], st2); f[3] = cmul(f[1], st2);
+                        f[4] = cmul(f[0], st4); f[5] = cmul(f[1], st4); f[6] = cmul(f[2], st4); f[7] = cmul(f[3], st4);
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) o[sq][d] = twmul<DIR>(o[sq][d], f[d]);
+                    }
+                }
+                const int pbase = (j / Ns) * (Ns * R) + (j & (Ns - 1));
+#pragma unroll
+                for (int d = 0; d < R; ++d) {
+                    U x;
+#pragma unroll
+                    for (int sq = 0; sq < S; ++sq) TU::set(x, sq, o[sq][d]);
+                    img[(pbase + d * Ns) * PITCH + p] = x;
+                }
+            }
+        };
+        stage(std::integral_constant<int, 0>{});
+        if constexpr (NS > 1) stage(std::integral_constant<int, 1>{});
+        if constexpr (NS > 2) stage(std::integral_constant<int, 2>{});
+        if constexpr (NS > 3) stage(std::integral_constant<int, 3>{});
+        __syncthreads();
+        // ---- the image holds the spectrum [k][sequence]: runs of C adjacent sequences per point
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = tid + i * WG, pt = g / PP, pu = g % PP;
+            __builtin_nontemporal_store(img[pt * PITCH + pu], reinterpret_cast<U*>(dst + (unsigned long long)pt * D.ops + S * pu));
+        }
+        const unsigned long long tile2 = dyn ? (unsigned long long)s_next[it & 1] : tile1 + gridDim.x;
+        __syncthreads();
+        tile = tile1; tile1 = tile2;
+    }
+    if (dyn && tid == 0) {
+        __threadfence();
+        const unsigned dn = atomicAdd(&ctr[1], 1u);
+        if (dn == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+}
+
+}  // namespace pf

@@ -705,6 +705,9 @@ struct TiledAltF32b {
     // of the exchanges 2304 -> 1536, conflict-free with PAD0 = 2, PADN = 0: tools/tiled_lds_search.py); variants 75 / 76
     typedef TiledCfg<float, 13, 256, 3, 16, 32, 16, 1, 2, 0, 3, 1, 256, 2> T8192;
     typedef TiledCfg<float, 13, 256, 3, 16, 32, 16, 1, 2, 0, 3, 0, 256, 2> T8192np;
+    // every twiddle resident in registers (two workgroups of 256 threads per CU leave 256 VGPRs per lane): no power
+    // recomputation in the loop (variant 79)
+    typedef TiledCfg<float, 13, 256, 3, 16, 32, 16, 1, 2, 0, 0, 0, 256, 2> T8192np0;
     // the same idea one and two sizes down: 32 points per thread, three stages (variants 77 prefetch / 78 none)
     typedef TiledCfg<float, 11, 64, 3, 16, 8, 16, 1, 2, 0, 3, 1> T2048;            // ONE wavefront per transform
     typedef TiledCfg<float, 11, 64, 3, 16, 8, 16, 1, 2, 0, 3, 0> T2048np;

@@ -1,0 +1,98 @@
+// Host-side declarations shared by the translation units of libpffft_hip.so: the plan ("PFFFT_Setup":
+// src/pffft_priv_impl.h:1051-1060), error plumbing and launch helpers.  pffft_hip.hip owns the definitions; dma_tu.hip
+// (the LDS-DMA staged kernels, compiled on their own so that they can be iterated on in seconds) uses them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "fft_generic.h"
+#include "fft_big.h"
+#include "stock_plan.h"
+
+namespace pf {
+
+extern thread_local std::string g_last_error;
+extern int g_variant;
+int fail(hipError_t e, const char* what);
+#define PF_CHECK(expr)                                   \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return fail(_e, #expr);    \
+    } while (0)
+
+int num_cus();
+
+template <typename K>
+static int allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        PF_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1, K_TILED = 2, K_BIG = 3 };
+constexpr size_t LDS_MAX = 160 * 1024;
+constexpr unsigned CTR_RING = 4096;
+
+struct Setup {
+    uint32_t magic;
+    int N, transform, is_double;
+    int n;           // complex length of the device transform
+    size_t vec_scalars;  // scalars per vector: N (real) / 2N (complex)
+    Kernel kernel;
+    GenericPlan gp;
+    int gthreads;
+    size_t glds;
+    // mixed-radix Stockham plans (fft_stock.h): [0] forward order, [1] backward order of the same radices
+    StockPlan sk[2], skw[2];          // workgroup-phase plans; wave-local plans (small n)
+    int sk_threads = 0, skw_threads = 0;
+    bool sk_ok = false, skw_ok = false;
+    // device state (lazy: creating a setup never touches the GPU)
+    std::mutex mu;        // guards the lazy device initialisation
+    std::mutex stage_mu;  // guards the staging buffers of the legacy host-pointer entries
+    bool dev_ready = false;
+    int device = -1;        // the device the tables / counters / scratch of this setup live on (bound at first use)
+    void* d_tw = nullptr;   // W_n^j, j < n
+    void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
+    void* d_twc[2] = {nullptr, nullptr};  // compact per-stage base twiddles of the Stockham plans (forward / backward order)
+    unsigned* d_ctr = nullptr;             // ring of {next, done} work counters for the dynamic kernels
+    std::atomic<unsigned> ctr_slot{0};
+    // sizes beyond LDS with a small factor (fft_big.h, three streaming passes): n = bigR x sub->n
+    int bigR = 0;
+    Setup* sub = nullptr;
+    // sizes beyond LDS (K_BIG): n = bigN[0] x bigN[1], one strided plan + twiddle table per factor
+    StridedPlan bigp[2];
+    void* d_bigtw[2] = {nullptr, nullptr};
+    // HBM work buffers of the beyond-LDS path: one pair PER STREAM (kernels of one stream serialise; two streams running
+    // the same setup concurrently must not share scratch).  big_mu guards the map, not the kernels.
+    struct Scratch { void* buf[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; };
+    std::mutex big_mu;
+    std::map<hipStream_t, Scratch> big_scratch;
+    void* d_stage[3] = {nullptr, nullptr, nullptr};  // staging for host-pointer legacy calls
+    size_t stage_bytes[3] = {0, 0, 0};
+    void* h_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned host images the kernels read / write directly (small vectors)
+    size_t hstage_bytes[4] = {0, 0, 0, 0};
+};
+constexpr uint32_t MAGIC = 0x50464654u;  // "PFFT"
+
+struct FcBatch { int nsig; size_t xstride, ystride; };   // signals of one pffastconv call (1 for the reference entries)
+
+// dma_tu.hip: the LDS-DMA staged kernels (fft_dma.h).  launch_dma returns -1 when the size has no such kernel.
+int launch_dma(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st, int mode);
+int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
+                   hipStream_t st, const FcBatch& fb);
+
+// tile_tu.hip: power-of-two sizes beyond LDS in two / three passes (fft_tile.h); canonical complex, in -> out through `work`
+// (same size, distinct from both; in may equal out).  -1 when the size has no tile plan.
+int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, int logn, int dir, hipStream_t st);
+
+}  // namespace pf

@@ -175,8 +175,6 @@ static int fc_ensure_device(FastConv* s) {
     return 0;
 }
 
-struct FcBatch { int nsig; size_t xstride, ystride; };   // signals of one call (1 for the reference entries)
-
 template <class C>
 static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
                            hipStream_t st, const FcBatch& fb, PFFFT_Setup* pst = nullptr, const float* d_Hc = nullptr) {
@@ -198,6 +196,8 @@ static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, 
     PF_CHECK(hipGetLastError());
     return 0;
 }
+
+static int g_fir_dma = [] { const char* e = getenv("PFFASTCONV_HIP_DMA"); return e ? atoi(e) : -1; }();   // -1 = default
 
 // Internal block length for the throughput regime.  What a caller can observe of the reference's blocks is only HOW MANY
 // samples a call produces (fc_schedule); the values are those of the exact convolution whatever the block length, so
@@ -297,6 +297,11 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
             const int bstep = nbig - s->filterLen + 1;
             const int bblk = (int)(((long)produced + bstep - 1) / bstep);
             const int blast = (int)(produced - (long)(bblk - 1) * bstep);
+            const bool use_dma = g_variant == 97 || (g_variant == 0 && g_fir_dma > 0);
+            if (use_dma) {
+                rc = launch_fir_dma(s->st_big, s->d_Hc_big, d_x, d_y, bblk, bstep, inputLen, blast, st, fb);
+                if (rc != -1) return rc;
+            }
             switch (nbig / 2) {
                 case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, fb, s->st_big, s->d_Hc_big);
                 case 2048: return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, bblk, bstep, inputLen, blast, st, fb, s->st_big, s->d_Hc_big);
@@ -322,6 +327,10 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         else hipLaunchKernelGGL(fastconv_td_kernel<1>, grid, dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, out_f, in_f, fb.xstride, fb.ystride);
         PF_CHECK(hipGetLastError());
         return 0;
+    }
+    if (mode == 0 && (g_variant == 97 || (g_variant == 0 && g_fir_dma > 0)) && (long)nblk * fb.nsig >= 2L * num_cus()) {
+        rc = launch_fir_dma(s->st, s->d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);   // many reference-sized blocks
+        if (rc != -1) return rc;
     }
     if (mode == 0 && g_variant != 30) {  // one real stream: the fused one-kernel path when Nfft/2 has a tiled kernel
         switch (Nfft / 2) {

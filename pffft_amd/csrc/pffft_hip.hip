@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/pffft_hip.h"
+#include "pf_host.h"
 #include "fft_c1024.h"
 #include "fft_generic.h"
 #include "fft_tiled.h"
@@ -31,20 +32,15 @@ namespace pf {
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
-static thread_local std::string g_last_error;
-static int g_variant = 0;
+thread_local std::string g_last_error;
+int g_variant = 0;
 
-static int fail(hipError_t e, const char* what) {
+int fail(hipError_t e, const char* what) {
     char buf[512];
     snprintf(buf, sizeof buf, "pffft_hip: %s failed: %s (%d)", what, hipGetErrorString(e), (int)e);
     g_last_error = buf;
     return (int)e;
 }
-#define PF_CHECK(expr)                                   \
-    do {                                                 \
-        hipError_t _e = (expr);                          \
-        if (_e != hipSuccess) return fail(_e, #expr);    \
-    } while (0)
 
 // Legacy void entries have no error channel (include/pffft/pffft.h:159).  A drop-in must not kill its caller where the
 // reference could not fail: the default is FAIL-SOFT — one line on stderr (the first 8 failures per process), the text in
@@ -116,50 +112,6 @@ static void aligned_free64(void* p) {
 // ------------------------------------------------------------------------------------------------
 // the plan ("PFFFT_Setup": src/pffft_priv_impl.h:1051-1060)
 // ------------------------------------------------------------------------------------------------
-enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1, K_TILED = 2, K_BIG = 3 };
-constexpr size_t LDS_MAX = 160 * 1024;
-constexpr unsigned CTR_RING = 4096;
-
-struct Setup {
-    uint32_t magic;
-    int N, transform, is_double;
-    int n;           // complex length of the device transform
-    size_t vec_scalars;  // scalars per vector: N (real) / 2N (complex)
-    Kernel kernel;
-    GenericPlan gp;
-    int gthreads;
-    size_t glds;
-    // mixed-radix Stockham plans (fft_stock.h): [0] forward order, [1] backward order of the same radices
-    StockPlan sk[2], skw[2];          // workgroup-phase plans; wave-local plans (small n)
-    int sk_threads = 0, skw_threads = 0;
-    bool sk_ok = false, skw_ok = false;
-    // device state (lazy: creating a setup never touches the GPU)
-    std::mutex mu;        // guards the lazy device initialisation
-    std::mutex stage_mu;  // guards the staging buffers of the legacy host-pointer entries
-    bool dev_ready = false;
-    int device = -1;        // the device the tables / counters / scratch of this setup live on (bound at first use)
-    void* d_tw = nullptr;   // W_n^j, j < n
-    void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
-    void* d_twc[2] = {nullptr, nullptr};  // compact per-stage base twiddles of the Stockham plans (forward / backward order)
-    unsigned* d_ctr = nullptr;             // ring of {next, done} work counters for the dynamic kernels
-    std::atomic<unsigned> ctr_slot{0};
-    // sizes beyond LDS with a small factor (fft_big.h, three streaming passes): n = bigR x sub->n
-    int bigR = 0;
-    Setup* sub = nullptr;
-    // sizes beyond LDS (K_BIG): n = bigN[0] x bigN[1], one strided plan + twiddle table per factor
-    StridedPlan bigp[2];
-    void* d_bigtw[2] = {nullptr, nullptr};
-    // HBM work buffers of the beyond-LDS path: one pair PER STREAM (kernels of one stream serialise; two streams running
-    // the same setup concurrently must not share scratch).  big_mu guards the map, not the kernels.
-    struct Scratch { void* buf[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; };
-    std::mutex big_mu;
-    std::map<hipStream_t, Scratch> big_scratch;
-    void* d_stage[3] = {nullptr, nullptr, nullptr};  // staging for host-pointer legacy calls
-    size_t stage_bytes[3] = {0, 0, 0};
-    void* h_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned host images the kernels read / write directly (small vectors)
-    size_t hstage_bytes[4] = {0, 0, 0, 0};
-};
-constexpr uint32_t MAGIC = 0x50464654u;  // "PFFT"
 
 static void destroy_setup(Setup* s);
 
@@ -372,7 +324,7 @@ static int ensure_device(Setup* s) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static int num_cus() {
+int num_cus() {
     static int cus = 0;
     if (!cus) {
         hipDeviceProp_t prop;
@@ -382,14 +334,6 @@ static int num_cus() {
         if (cus <= 0) cus = 256;
     }
     return cus;
-}
-
-template <typename K>
-static int allow_big_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024)
-        PF_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return 0;
 }
 
 template <typename T>
@@ -547,6 +491,7 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
             if (n == 2048) { *e = pf ? tiled_entry<T, TiledAltF32b::T2048>(dir, real) : tiled_entry<T, TiledAltF32b::T2048np>(dir, real); return true; }
             if (n == 4096) { *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real); return true; }
         }
+        if (n == 8192 && g_variant == 79) { *e = tiled_entry<T, TiledAltF32b::T8192np0>(dir, real); return true; }
         if (n == 8192 && g_variant == 75) { *e = tiled_entry<T, TiledAltF32b::T8192>(dir, real); return true; }
         if (n == 8192 && g_variant == 76) { *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real); return true; }
     }
@@ -612,6 +557,9 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
     PF_CHECK(hipGetLastError());
     return 0;
 }
+
+// PFFFT_HIP_DMA=<0|1|2>: LDS-DMA staged kernels off / counted vmcnt / vmcnt(0) for every size that has one (A/B)
+static int g_dma_mode = [] { const char* e = getenv("PFFFT_HIP_DMA"); return e ? atoi(e) : -1; }();   // -1 = per-size default
 
 template <typename T>
 static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
@@ -775,7 +723,18 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
         PF_CHECK(hipGetLastError());
     }
     cx<T>* dest = (fwd && !ordered) ? bufA : (cx<T>*)out;
-    if (s->bigR && g_variant != 80) {   // three streaming passes (fft_big.h); variant 80 = the strided kernels (A/B)
+    bool done = false;
+    if ((s->n & (s->n - 1)) == 0 && g_variant != 80 && g_variant != 82) {
+        // power-of-two sizes: two passes over HBM up to n = 2^20, three beyond (fft_tile.h); variant 82 = the
+        // three-to-five-pass composition below (A/B)
+        int logn = 0;
+        while ((1 << logn) < s->n) ++logn;
+        const int trc = launch_tile_fft(s, cur, bufB, dest, batch, logn, dir, st);
+        if (trc > 0) return trc;
+        done = trc == 0;
+    }
+    if (done) {
+    } else if (s->bigR && g_variant != 80) {   // three streaming passes (fft_big.h); variant 80 = the strided kernels (A/B)
         if ((rc = big_small_factor<T>(s, cur, bufB, dest, batch, dir, st))) return rc;
     } else {
         if ((rc = launch_strided<T>(s, 0, cur, bufB, batch, dir, st))) return rc;
@@ -840,6 +799,12 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         if (s->kernel == K_C1024_F32 && g_variant != 1 && g_variant != 50 && batch < (1ull << 32))
             return launch_c1024(s, in, out, batch, dir, ordered, st);
     }
+    if constexpr (sizeof(T) == 4) {
+        // variants 95 / 96 (or PFFFT_HIP_DMA=1 / 2): the LDS-DMA staged kernels, counted vmcnt / vmcnt(0) (fft_dma.h)
+        const int dma = g_variant == 95 ? 1 : g_variant == 96 ? 2 : g_variant == 98 ? 3 : (g_variant == 0 ? g_dma_mode : 0);
+        if (s->kernel == K_TILED && dma > 0 && batch < (1ull << 32) && s->n >= 2048 && s->n <= 8192)
+            return launch_dma(s, in, out, batch, dir, ordered, st, dma);
+    }
     if (s->kernel == K_TILED && g_variant != 1 && g_variant != 50 && batch < (1ull << 32)) {
         // power-of-two sizes where the Stockham kernel instantiated on its compile-time plan measured faster than
         // the register-tiled one (float, 1 GiB of vectors, tools/stock_ab.py; variant 54 = always tiled):
@@ -850,7 +815,7 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         //   (double n = 2048 / 4096 went back to the tiled family with its TiledAltF64 variants: 0.75-0.80 vs 0.65-0.73;
         //    only the real backward N = 8192 stays here: 0.70 / 0.73 vs 0.68 / 0.76)
         bool stock = false;
-        if (s->sk_ok && g_variant != 54 && !(g_variant >= 70 && g_variant <= 78)) {
+        if (s->sk_ok && g_variant != 54 && !(g_variant >= 70 && g_variant <= 79)) {
             const int n = s->n;
             const bool cplx = s->transform == PFFFT_COMPLEX;
             if (sizeof(T) == 4) stock = cplx ? (n <= 64) : (n <= 32 || (n == 8192 && dir == PFFFT_BACKWARD));

@@ -1,0 +1,119 @@
+// libpffft_hip.so, translation unit of the two / three-pass tile kernels for power-of-two sizes beyond LDS (fft_tile.h).
+#include <hip/hip_runtime.h>
+
+#include "../../include/pffft_hip.h"
+#include "pf_host.h"
+#include "fft_tile.h"
+
+namespace pf {
+
+static int g_tile_pp = [] { const char* e = getenv("PFFFT_HIP_TILE_PP"); return e ? atoi(e) : 0; }();   // A/B: force 4 or 8
+static int g_tile_pf = [] { const char* e = getenv("PFFFT_HIP_TILE_PF"); return e ? atoi(e) : -1; }();  // A/B: prefetch off / on
+
+template <typename T, int LOGL, int PP>
+static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s) {
+    typedef TileGeom<T, LOGL, PP> G;
+    const size_t lds = G::lds_bytes(D.M > (1ull << 18) ? 3 : 2);
+    void (*k)(const cx<T>*, cx<T>*, unsigned long long, TileDesc, unsigned*);
+    // register prefetch of the next tile where one or two workgroups fill a CU (images of 40 KiB and more)
+    const bool pf = g_tile_pf >= 0 ? g_tile_pf != 0 : lds > 40 * 1024;
+    const bool fw = dir == PFFFT_FORWARD;
+    if (D.seq_contig) k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 1> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 1>)
+                             : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0>);
+    else k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 1>)
+                : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 0> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 0>);
+    int rc = allow_big_lds(k, lds);
+    if (rc) return rc;
+    int per_cu = 0;
+    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), G::WG, lds));
+    if (per_cu < 1) per_cu = 1;
+    unsigned long long grid = (unsigned long long)num_cus() * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    // in-order tiles only where a tile is 64 KiB or more: one counter address serves ~80 M atomics/s, so 16-32 KiB tiles
+    // are throttled by the grab (2^15: 0.30 static, 0.20 in order; 2^18 .. 2^20: 0.27-0.31 / 0.19 static, 0.29-0.32 / 0.24 in
+    // order).  PFFFT_HIP_TILE_DYN=0/1 forces it (A/B).
+    static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_TILE_DYN"); return e ? atoi(e) : -1; }();
+    const bool want_dyn = dyn_env >= 0 ? dyn_env != 0 : (size_t)G::L * G::C * sizeof(cx<T>) >= 64 * 1024;
+    unsigned* ctr = (ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D, ctr);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T, int PP>
+static int tile_dispatch(int logl, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s) {
+    switch (logl) {
+        case 6: return tile_pass<T, 6, PP>(in, out, ntiles, D, dir, st, s);
+        case 7: return tile_pass<T, 7, PP>(in, out, ntiles, D, dir, st, s);
+        case 8: return tile_pass<T, 8, PP>(in, out, ntiles, D, dir, st, s);
+        case 9: return tile_pass<T, 9, PP>(in, out, ntiles, D, dir, st, s);
+        case 10: if constexpr (PP == 4) return tile_pass<T, 10, 4>(in, out, ntiles, D, dir, st, s);
+        default: break;
+    }
+    g_last_error = "pffft_hip: tile pass length out of range";
+    return (int)hipErrorInvalidValue;
+}
+
+static int pick_pp(int logl) {
+    if (logl == 10) return 4;                 // two images of 1024 x 128 bytes do not fit LDS
+    if (g_tile_pp == 4 || g_tile_pp == 8) return g_tile_pp;
+    return 8;                                 // 128-byte runs: 64-byte runs measured 0.18 against 0.30 of the roofline
+}
+
+// pass A: `nvec` vectors of len = L x cols complex points; length-L transforms over the columns (stride cols), times
+// W_len^(k col); same layout out (in place allowed)
+template <typename T>
+static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, int logl, unsigned long long cols, int dir, hipStream_t st) {
+    const int pp = pick_pp(logl), C = pp * TileUnit<T>::S;
+    TileDesc D{};
+    D.TA = (unsigned)(cols / C); D.TB = 1;
+    D.vstride = ((unsigned long long)1 << logl) * cols;
+    D.in_a = C; D.out_a = C; D.ips = cols; D.iss = 1; D.ops = cols;
+    D.col_a = (unsigned)C; D.M = D.vstride; D.seq_contig = 1;
+    const unsigned long long ntiles = nvec * D.TA;
+    return pp == 8 ? tile_dispatch<T, 8>(logl, in, out, ntiles, D, dir, st, s) : tile_dispatch<T, 4>(logl, in, out, ntiles, D, dir, st, s);
+}
+
+// pass B: rows of length L = 2^logl; row (vec, o, i) [o < outer, i < inner] sits at vec vlen + (o inner + i) L and its
+// spectrum goes to X[vec vlen + (k inner + i) outer + o]   (outer index fastest: runs of C adjacent o)
+template <typename T>
+static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, int logl, unsigned long long outer,
+                     unsigned long long inner, int dir, hipStream_t st) {
+    const int pp = pick_pp(logl), C = pp * TileUnit<T>::S;
+    const unsigned long long L = (unsigned long long)1 << logl;
+    TileDesc D{};
+    D.TA = (unsigned)(outer / C); D.TB = (unsigned)inner;
+    D.vstride = outer * inner * L;
+    D.in_a = (unsigned long long)C * inner * L; D.in_b = L; D.ips = 1; D.iss = inner * L;
+    D.out_a = C; D.out_b = outer; D.ops = outer * inner;
+    D.M = 0; D.seq_contig = 0;
+    const unsigned long long ntiles = nvec * D.TA * D.TB;
+    return pp == 8 ? tile_dispatch<T, 8>(logl, in, out, ntiles, D, dir, st, s) : tile_dispatch<T, 4>(logl, in, out, ntiles, D, dir, st, s);
+}
+
+// canonical complex transform of `batch` vectors of n = 2^logn points: in -> out through ONE work buffer of the same size
+// (in may equal out; work must differ from both).  Returns -1 when the size is outside the tile plans.
+template <typename T>
+static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, int logn, int dir, hipStream_t st) {
+    const int minlog = 12;
+    if (logn < minlog || logn > 27) return -1;
+    int rc;
+    if (logn <= 20) {
+        const int l1 = logn / 2, l2 = logn - l1;
+        if ((rc = pass_columns<T>(s, in, work, batch, l1, 1ull << l2, dir, st))) return rc;
+        return pass_rows<T>(s, work, out, batch, l2, 1ull << l1, 1, dir, st);
+    }
+    const int l1 = logn / 3, rem = logn - l1, l2 = rem / 2, l3 = rem - l2;
+    // n = L1 n', n' = L2 L3:  A over L1 (columns n'), then per row of length n': A over L2 (in place), B over L3 with the
+    // scatter X[(k3 L2 + k2) L1 + k1]
+    if ((rc = pass_columns<T>(s, in, work, batch, l1, 1ull << rem, dir, st))) return rc;
+    if ((rc = pass_columns<T>(s, work, work, batch << l1, l2, 1ull << l3, dir, st))) return rc;
+    return pass_rows<T>(s, work, out, batch, l3, 1ull << l1, 1ull << l2, dir, st);
+}
+
+int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, int logn, int dir, hipStream_t st) {
+    if (s->is_double) return tile_fft<double>(s, (const cx<double>*)in, (cx<double>*)work, (cx<double>*)out, batch, logn, dir, st);
+    return tile_fft<float>(s, (const cx<float>*)in, (cx<float>*)work, (cx<float>*)out, batch, logn, dir, st);
+}
+
+}  // namespace pf

@@ -25,7 +25,7 @@ constexpr int BUF = 73808;   // the FFT kernel's padded image size: second buffe
 
 // MODE 0: counted vmcnt (stores younger than the DMA stay in flight)   MODE 1: vmcnt(0)
 // XCH: number of extra LDS exchange rounds (ds_write_b64 x16 + ds_read_b64 x16 per thread, like an FFT stage exchange)
-template <int MODE, int XCH, int DYN>
+template <int MODE, int XCH, int DYN, int VALU>
 __global__ void __launch_bounds__(WG, 1)
 dma_copy(const char* __restrict__ in, char* __restrict__ out, unsigned ngroups, unsigned* ctr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -63,19 +63,33 @@ dma_copy(const char* __restrict__ in, char* __restrict__ out, unsigned ngroups, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = L[tid + WG * i];
         if (XCH > 0) {
+            // realistic stage exchange: conflict-free ds_write_b64 x16 in "column" order, ds_read_b64 x16 in "row" order
+            // through a padded image (stride 17 float2 per 16), VALU work of a radix-8/16 stage in between
             float2* X = reinterpret_cast<float2*>(smem + b * BUF);
-#pragma unroll 1
-            for (int r = 0; r < XCH; ++r) {
-                wait_lgkm0(); raw_barrier();
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    X[(tid * 16 + 2 * i) ^ (r + 1)] = float2{v[i].x, v[i].y};
-                    X[(tid * 16 + 2 * i + 1) ^ (r + 1)] = float2{v[i].z, v[i].w};
+            for (int r = 0; r < XCH; ++r) {
+                if (VALU) {
+#pragma unroll
+                    for (int k = 0; k < VALU; ++k)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const V4 t = v[i];
+                            v[i].x = __builtin_fmaf(t.y, 0.70710678f, t.x); v[i].y = __builtin_fmaf(t.x, -0.70710678f, t.y);
+                            v[i].z = __builtin_fmaf(t.w, 0.38268343f, t.z); v[i].w = __builtin_fmaf(t.z, -0.38268343f, t.w);
+                        }
                 }
                 wait_lgkm0(); raw_barrier();
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float2 a = X[(tid * 16 + 2 * i) ^ (r + 1)], c = X[(tid * 16 + 2 * i + 1) ^ (r + 1)];
+                    const int p0 = tid + WG * (2 * i), p1 = tid + WG * (2 * i + 1);
+                    X[p0 + (p0 >> 4)] = float2{v[i].x, v[i].y};
+                    X[p1 + (p1 >> 4)] = float2{v[i].z, v[i].w};
+                }
+                wait_lgkm0(); raw_barrier();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q0 = 16 * tid + 2 * i, q1 = q0 + 1;
+                    const float2 a = X[q0 + (q0 >> 4)], c = X[q1 + (q1 >> 4)];
                     v[i] = V4{a.x, a.y, c.x, c.y};
                 }
             }
@@ -94,10 +108,10 @@ dma_copy(const char* __restrict__ in, char* __restrict__ out, unsigned ngroups, 
     }
 }
 
-template <int MODE, int XCH, int DYN>
+template <int MODE, int XCH, int DYN, int VALU = 0>
 static void run(const char* name, const char* din, char* dout, size_t bytes, unsigned* ctr, const std::vector<float>& h_in) {
     const unsigned ngroups = (unsigned)(bytes / GROUP);
-    auto k = dma_copy<MODE, XCH, DYN>;
+    auto k = dma_copy<MODE, XCH, DYN, VALU>;
     const size_t lds = 2 * BUF + 16;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipMemset(dout, 0, bytes));
@@ -108,7 +122,7 @@ static void run(const char* name, const char* din, char* dout, size_t bytes, uns
     // verify (sampled + first / last group)
     std::vector<float> h((size_t)GROUP / 4);
     size_t bad = 0;
-    for (unsigned gi : {0u, 1u, 255u, 256u, ngroups / 2, ngroups - 2, ngroups - 1}) {
+    if (XCH == 0) for (unsigned gi : {0u, 1u, 255u, 256u, ngroups / 2, ngroups - 2, ngroups - 1}) {
         CK(hipMemcpy(h.data(), dout + (size_t)gi * GROUP, GROUP, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < h.size(); ++i) if (h[i] != h_in[(size_t)gi * (GROUP / 4) + i]) ++bad;
     }
@@ -135,9 +149,15 @@ int main() {
     run<1, 0, 0>("static, vmcnt(0)", din, dout, bytes, ctr, h);
     run<0, 0, 1>("in-order, counted vmcnt", din, dout, bytes, ctr, h);
     run<1, 0, 1>("in-order, vmcnt(0)", din, dout, bytes, ctr, h);
-    run<0, 1, 1>("in-order, counted, +1 LDS exchange", din, dout, bytes, ctr, h);
-    run<0, 3, 1>("in-order, counted, +3 LDS exchanges", din, dout, bytes, ctr, h);
-    run<0, 4, 1>("in-order, counted, +4 LDS exchanges", din, dout, bytes, ctr, h);
-    run<1, 3, 1>("in-order, vmcnt(0), +3 LDS exchanges", din, dout, bytes, ctr, h);
+    run<0, 1, 1>("in-order, +1 exchange", din, dout, bytes, ctr, h);
+    run<0, 2, 1>("in-order, +2 exchanges", din, dout, bytes, ctr, h);
+    run<0, 3, 1>("in-order, +3 exchanges", din, dout, bytes, ctr, h);
+    run<0, 4, 1>("in-order, +4 exchanges", din, dout, bytes, ctr, h);
+    run<0, 3, 1, 6>("in-order, +3 exchanges, 3x192 VALU/thread", din, dout, bytes, ctr, h);
+    run<0, 3, 1, 12>("in-order, +3 exchanges, 3x384 VALU/thread", din, dout, bytes, ctr, h);
+    run<0, 4, 1, 8>("in-order, +4 exchanges, 4x256 VALU/thread", din, dout, bytes, ctr, h);
+    run<0, 4, 1, 16>("in-order, +4 exchanges, 4x512 VALU/thread", din, dout, bytes, ctr, h);
+    run<0, 7, 1, 8>("in-order, +7 exchanges, 7x256 VALU (FIR-like)", din, dout, bytes, ctr, h);
+    run<1, 3, 1, 6>("vmcnt(0), +3 exchanges, 3x192 VALU/thread", din, dout, bytes, ctr, h);
     return 0;
 }
