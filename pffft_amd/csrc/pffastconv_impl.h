@@ -297,7 +297,10 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
             const int bstep = nbig - s->filterLen + 1;
             const int bblk = (int)(((long)produced + bstep - 1) / bstep);
             const int blast = (int)(produced - (long)(bblk - 1) * bstep);
-            const bool use_dma = g_variant == 97 || (g_variant == 0 && g_fir_dma > 0);
+            // The LDS-DMA staged block kernel (fft_dma.h) where it measured faster (tools/dma_ab.py, fraction of the 8 B / sample
+            // roofline, register-staged -> DMA): Nfft 16384: 2^26 samples 0.190 -> 0.209, 256 signals x 2^20 0.204 -> 0.246;
+            // Nfft 8192: a tie (0.22-0.29 both).  Variant 97 / PFFASTCONV_HIP_DMA=1 force it, =0 switches it off (A/B).
+            const bool use_dma = g_variant == 97 || (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && nbig == 16384)));
             if (use_dma) {
                 rc = launch_fir_dma(s->st_big, s->d_Hc_big, d_x, d_y, bblk, bstep, inputLen, blast, st, fb);
                 if (rc != -1) return rc;
@@ -328,7 +331,8 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         PF_CHECK(hipGetLastError());
         return 0;
     }
-    if (mode == 0 && (g_variant == 97 || (g_variant == 0 && g_fir_dma > 0)) && (long)nblk * fb.nsig >= 2L * num_cus()) {
+    if (mode == 0 && (g_variant == 97 || (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && Nfft == 16384)))) &&
+        (long)nblk * fb.nsig >= 2L * num_cus()) {
         rc = launch_fir_dma(s->st, s->d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);   // many reference-sized blocks
         if (rc != -1) return rc;
     }

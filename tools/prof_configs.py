@@ -1,0 +1,29 @@
+"""Launches the dominant kernel of every BASELINE config at its stated size a few times (for rocprofv3 passes):
+c2 N=1024 cplx f32 2^20, c3 N=16384 real f32 2^16, c5 N=1024 cplx f64 2^20, c4 FIR 2^26 samples / 4096 taps,
+beyond-LDS N=2^16 and 2^20 cplx f32 (1 GiB of vectors)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pffft_amd as pa
+reps = 3
+def fft(N, tr, dtype, B, ordered=False):
+    s = pa.Setup(N, tr, dtype)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    x = torch.empty(B, s.vec_scalars, device="cuda", dtype=tdt).uniform_(-1, 1)
+    y = torch.empty_like(x)
+    for _ in range(reps + 1):
+        s.transform_batch(x, y, pa.FORWARD, ordered)
+    torch.cuda.synchronize()
+    s.close(); del x, y; torch.cuda.empty_cache()
+fft(1024, pa.COMPLEX, np.float32, 1 << 20)
+fft(16384, pa.REAL, np.float32, 1 << 16)
+fft(1024, pa.COMPLEX, np.float64, 1 << 20)
+h = np.random.default_rng(4).uniform(-1, 1, 4096).astype(np.float32)
+fc = pa.FastConv(h, 0, 0)
+x = torch.empty(1 << 26, device="cuda").uniform_(-1, 1); y = torch.empty_like(x)
+for _ in range(reps + 1):
+    fc.apply(x, True, out=y)
+torch.cuda.synchronize()
+fc.close(); del x, y; torch.cuda.empty_cache()
+fft(1 << 16, pa.COMPLEX, np.float32, 2048, ordered=True)
+fft(1 << 20, pa.COMPLEX, np.float32, 128, ordered=True)
