@@ -208,9 +208,16 @@ static int fc_big_nfft(const FastConv* s, long produced, int nsig) {
     static const int forced = [] { const char* e = getenv("PFFASTCONV_HIP_NFFT"); return e ? atoi(e) : -1; }();
     if (forced == 0) return 0;
     const int taps = s->filterLen;
-    // measured on MI355X (tools/fir_long.py, Gsamples/s on 2^26 samples): 600 taps 102 (reference Nfft 2048) -> 253 (8192),
-    // 1024 taps 77 -> 249, 2048 taps 142 -> 223, 4096 taps 160 -> 193 (16384); the time-domain kernel wins up to ~128 taps
-    const int want = forced > 0 ? forced : (taps <= 2048 ? 8192 : 16384);
+    // measured table (MI355X, tools/fir_quick.py with PFFASTCONV_HIP_NFFT forced; fraction of the 8 B / sample roofline on
+    // 2^26 samples / on 256 signals of 2^20; r02):      Nfft   2048          4096          8192          16384
+    //    200 taps (FFT route forced)                         0.12 / 0.15   0.23 / 0.30   0.26 / 0.31   0.26 / 0.30
+    //    600 taps                                            0.10 / 0.12   0.22 / 0.27   0.25 / 0.30   0.27 / 0.29
+    //   1024 taps                                            0.08 / 0.09   0.20 / 0.24   0.24 / 0.28   0.26 / 0.29
+    //   2048 taps                                                 -        0.14 / 0.17   0.22 / 0.25   0.25 / 0.27
+    //   4096 taps                                                 -             -        0.16 / 0.19   0.21 / 0.24
+    // -> 16384 from 1024 taps on, 8192 below (the time-domain kernel wins up to ~128 taps).  All block kernels saturate
+    // near 0.26-0.30: two 8192-point transforms per block cost ~33 k cycles per CU whatever the filter.
+    const int want = forced > 0 ? forced : (taps < 1024 ? 8192 : 16384);
     if (want <= s->Nfft || want > 16384 || (want & (want - 1)) || want < 2 * taps) return 0;
     if (forced > 0) return want;
     if (taps <= 128) return 0;
