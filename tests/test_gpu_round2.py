@@ -274,3 +274,56 @@ def test_one_2p26_vector_per_precision(ref, dt):
     assert float((gu / N - xd).abs().max()) <= (4e-5 if dt == "f32" else 1e-11)
     s.close(); rs.close()
     assert pa.Setup  # (2^26 + 16 is rejected like the reference does: tests/test_abi.py)
+
+
+# ------------------------------------------------------------------ LDS-DMA staged kernels (opt-in variants of fft_dma.h)
+@pytest.mark.parametrize("variant", [95, 96])
+@pytest.mark.parametrize("n", [2048, 4096, 8192])
+def test_dma_staged_kernels_against_reference(ref, variant, n):
+    """fft_dma.h: global -> LDS DMA landing, counted vmcnt (95) / vmcnt(0) (96).  Opt-in for the plain transforms
+    (measured slower than the register-staged kernels) but shipped: same parity bar, every direction /
+    layout, complex and real, ragged batches (inactive slots of the last group), in place."""
+    try:
+        for tr in (pa.COMPLEX, pa.REAL):
+            N = n if tr == pa.COMPLEX else 2 * n
+            s = pa.Setup(N, tr)
+            rs = ref.setup(N, tr)
+            for B in (1, 5, 259):
+                x = _uniform((B, s.vec_scalars), 100 + B)
+                idx = sorted({0, B // 2, B - 1})
+                xh = x[idx].cpu().numpy()
+                for d in (pa.FORWARD, pa.BACKWARD):
+                    for o in (True, False):
+                        pa.set_variant(variant)
+                        y = s.transform_batch(x, None, d, o)
+                        z = x.clone(); s.transform_batch(z, z, d, o)
+                        pa.set_variant(0)
+                        assert relerr(y[idx].cpu().numpy(), rs.batch(xh, d, o)) <= 1e-5, (tr, B, d, o)
+                        assert torch.equal(z, y), (tr, B, d, o)
+            s.close(); rs.close()
+    finally:
+        pa.set_variant(0)
+
+
+@pytest.mark.parametrize("flush", [1, 0])
+def test_fastconv_dma_block_kernel_on_a_long_signal(ref, flush):
+    """fastconv_dma_kernel (default for Nfft 16384 when a call spans many blocks): 4096 taps over 2^23 samples — dword-aligned
+    DMA of overlapping blocks, clamped tail — against the reference over the WHOLE signal."""
+    taps, L = 4096, (1 << 23) + 12345
+    rng = np.random.default_rng(97)
+    x = rng.uniform(-1, 1, L).astype(np.float32)
+    h = rng.uniform(-1, 1, taps).astype(np.float32)
+    yw, nw, _ = ref.fastconv(x, h, 0, 0, flush)
+    fc = pa.FastConv(h, 0, 0)
+    try:
+        pa.set_variant(97)
+        y, n = fc.apply(torch.from_numpy(x).cuda(), bool(flush))
+        pa.set_variant(0)
+        y0, n0 = fc.apply(torch.from_numpy(x).cuda(), bool(flush))      # whatever the default picks
+    finally:
+        pa.set_variant(0)
+    assert n == nw == n0
+    lim = (yw.max() - yw.min()) / 1e5
+    assert np.abs(y.cpu().numpy() - yw).max() <= lim
+    assert np.abs(y0.cpu().numpy() - yw).max() <= lim
+    fc.close()
