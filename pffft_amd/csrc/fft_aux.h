@@ -94,35 +94,48 @@ zconvolve_stream_kernel(const T* a, const T* b, T* ab, size_t total, unsigned np
 // q = 16-byte unit index over the whole batch, nq = units per vector (n/2); DC/Nyquist of a real spectrum are the .x
 // of units 0 and 1 of a vector and multiply as reals (src/pffft_priv_impl.h:1626-1629, :1680-1683): out.x = P.x.
 constexpr int ZD_WAVES = 8;
-template <typename T> struct Zd {
-    static constexpr int ROWS = sizeof(T) == 4 ? 8 : 4;      // 8 KiB of every stream per wave chunk in both precisions
-    static constexpr unsigned CHUNK = 64 * ROWS;             // units per wave chunk
-};
-
-template <typename T> __device__ __forceinline__ T dpp_swap1(T v);
+// One 16-byte unit per lane in BOTH precisions (a 32-byte unit per lane made every wave instruction touch half of each
+// 128-byte line: double ran at 0.66 of the roofline against 0.79 for float).  float: a unit is a whole 4-scalar re- or
+// im-group, the partner group sits in lane ^ 1; double: a unit is HALF a group (2 scalars), the matching half of the
+// partner group sits in lane ^ 2.  DC / Nyquist of a real spectrum are the .x of the first re-unit and the first im-unit
+// of a vector: units 0, 1 (float) / 0, 2 (double).
+template <typename T> __device__ __forceinline__ T dpp_swap1(T v);   // lane ^ 1 inside every quad
 template <> __device__ __forceinline__ float dpp_swap1<float>(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
-template <> __device__ __forceinline__ double dpp_swap1<double>(double v) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, 0xB1, 0xF, 0xF, true);
-    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), 0xB1, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-template <typename T> __device__ __forceinline__ vec4<T> dpp_swap(vec4<T> v) {
-    vec4<T> o; o.x = dpp_swap1<T>(v.x); o.y = dpp_swap1<T>(v.y); o.z = dpp_swap1<T>(v.z); o.w = dpp_swap1<T>(v.w);
-    return o;
-}
+template <typename T> struct Zd;
+template <> struct Zd<float> {
+    typedef vec4<float> V;
+    static constexpr int ROWS = 8, UPG = 1;                  // 8 KiB of every stream per wave chunk; units per 4-scalar group
+    static constexpr unsigned CHUNK = 64 * ROWS;             // units per wave chunk
+    static __device__ __forceinline__ float swap1(float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+    }
+    static __device__ __forceinline__ V swap(V v) { V o; o.x = swap1(v.x); o.y = swap1(v.y); o.z = swap1(v.z); o.w = swap1(v.w); return o; }
+};
+template <> struct Zd<double> {
+    typedef vec2<double> V;
+    static constexpr int ROWS = 8, UPG = 2;
+    static constexpr unsigned CHUNK = 64 * ROWS;
+    static __device__ __forceinline__ double swap1(double v) {                                                          // lane ^ 2
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, 0x4E, 0xF, 0xF, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), 0x4E, 0xF, 0xF, true);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    static __device__ __forceinline__ V swap(V v) { V o; o.x = swap1(v.x); o.y = swap1(v.y); return o; }
+};
 
 template <typename T, int ACC, int BCAST>
 __global__ void __launch_bounds__(ZD_WAVES * 64)
 zconvolve_dyn_kernel(const T* a, const T* b, T* ab, unsigned long long Q, unsigned nq, int is_real, T scaling, unsigned* ctr) {
-    typedef vec4<T> V;
+    typedef typename Zd<T>::V V;
+    constexpr int UPG = Zd<T>::UPG;
     constexpr int ZD_ROWS = Zd<T>::ROWS;
     constexpr unsigned ZD_CHUNK = Zd<T>::CHUNK;
     __shared__ unsigned s_next[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool odd = lane & 1;
+    const bool odd = (lane / UPG) & 1;               // this lane holds (part of) an im-group
     const V* a4 = reinterpret_cast<const V*>(a);
     const V* b4 = reinterpret_cast<const V*>(b);
     V* c4 = reinterpret_cast<V*>(ab);
@@ -172,12 +185,12 @@ zconvolve_dyn_kernel(const T* a, const T* b, T* ab, unsigned long long Q, unsign
 #pragma unroll
             for (int r = 0; r < ZD_ROWS; ++r) {
                 const V A = xa[r], B = xb[r];
-                const V Bp = dpp_swap<T>(B);
+                const V Bp = Zd<T>::swap(B);
                 const V P = A * B, X = A * Bp;
                 const V S = odd ? P : X;            // what the partner needs
-                const V R = dpp_swap<T>(S);
+                const V R = Zd<T>::swap(S);
                 V o = odd ? X + R : P - R;
-                if (is_real && rem[r] < 2) o.x = P.x;
+                if (is_real && (rem[r] == 0 || rem[r] == UPG)) o.x = P.x;
                 if (ACC) o = xc[r] + o * scaling; else o = o * scaling;
                 const unsigned long long q = q0 + 64 * r;
                 if (q < Q) __builtin_nontemporal_store(o, c4 + q);

@@ -938,7 +938,7 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
     // measured 0.57-0.60
     // long batches (>= 64 MiB per stream): in-order streaming kernel with DPP pair exchange (fft_aux.h); variant 61 = off
     {
-        const unsigned long long Q = 2ull * total;
+        const unsigned long long Q = 2ull * total * Zd<T>::UPG;   // 16-byte units in the batch
         if (g_variant != 60 && g_variant != 61 && g_variant != 42 && Q / Zd<T>::CHUNK >= 8192u &&
             Q / Zd<T>::CHUNK < 0xffffffffull) {
             int rc = ensure_device<T>(s);
@@ -946,7 +946,7 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
             unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
             const int real = s->transform == PFFFT_REAL;
             const dim3 grid((unsigned)num_cus()), blk(ZD_WAVES * 64);
-            const unsigned nq = (unsigned)(s->n / 2);
+            const unsigned nq = (unsigned)(s->n / 2) * Zd<T>::UPG;   // units per vector
 #define PF_ZD(ACC, BC) hipLaunchKernelGGL((zconvolve_dyn_kernel<T, ACC, BC>), grid, blk, 0, st, a, b, ab, Q, nq, real, scaling, ctr)
             if (accumulate) { if (b_broadcast) PF_ZD(1, 1); else PF_ZD(1, 0); }
             else { if (b_broadcast) PF_ZD(0, 1); else PF_ZD(0, 0); }

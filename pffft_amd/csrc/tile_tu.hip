@@ -55,7 +55,7 @@ static int tile_dispatch(int logl, const cx<T>* in, cx<T>* out, unsigned long lo
 }
 
 static int pick_pp(int logl) {
-    if (logl == 10) return 4;                 // two images of 1024 x 128 bytes do not fit LDS
+    if (logl == 10) return 4;                 // a padded image of 1024 x 144 bytes plus the tables does not fit LDS: 64-byte runs
     if (g_tile_pp == 4 || g_tile_pp == 8) return g_tile_pp;
     return 8;                                 // 128-byte runs: 64-byte runs measured 0.18 against 0.30 of the roofline
 }
