@@ -713,6 +713,11 @@ struct TiledAltF32b {
     typedef TiledCfg<float, 11, 64, 3, 16, 8, 16, 1, 2, 0, 3, 0> T2048np;
     typedef TiledCfg<float, 12, 128, 3, 16, 16, 16, 1, 2, 0, 3, 1, 256, 2> T4096;
     typedef TiledCfg<float, 12, 128, 3, 16, 16, 16, 1, 2, 0, 3, 0, 256, 2> T4096np;
+    // n = 16384 (one 128 KiB image, one workgroup per CU): 32 points per thread, 512 threads -> 256 VGPRs per lane, room for
+    // the register prefetch of the next vector that the 1024-thread configuration (128 VGPRs) cannot hold (variants 83 / 84)
+    typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 2, 0, 3, 1, 512, 2> T16384;
+    typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 2, 0, 3, 0, 512, 2> T16384np;
+    typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 4, 8, 3, 1, 512, 2> T16384b;   // the paddings of the 1024-thread one
 };
 template <> struct TiledPick<double> {
     typedef TiledCfg<double, 4, 2, 2, 4, 4, 1, 1, 1, 0, 0, 0, 256> C16;

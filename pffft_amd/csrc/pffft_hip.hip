@@ -491,6 +491,14 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
             if (n == 2048) { *e = pf ? tiled_entry<T, TiledAltF32b::T2048>(dir, real) : tiled_entry<T, TiledAltF32b::T2048np>(dir, real); return true; }
             if (n == 4096) { *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real); return true; }
         }
+        // n = 16384: 512 threads x 32 points with the register prefetch (tools/c16k_quick.py, fraction of 8 TB/s on 4 GiB,
+        // 1024-thread configuration -> this one): complex fwd canonical 0.66 -> 0.69, bwd 0.63 / 0.67 -> 0.68 / 0.70, real
+        // N = 32768 bwd 0.52 / 0.59 -> 0.54 / 0.64; real forward spills into the internal layout (0.55 -> 0.45) and stays.
+        // Both layouts of a direction share one configuration (ordered == zreorder(unordered) bit for bit).
+        if (n == 16384 && g_variant == 0 && (!real || dir == PFFFT_BACKWARD)) { *e = tiled_entry<T, TiledAltF32b::T16384>(dir, real); return true; }
+        if (n == 16384 && g_variant == 83) { *e = tiled_entry<T, TiledAltF32b::T16384>(dir, real); return true; }
+        if (n == 16384 && g_variant == 84) { *e = tiled_entry<T, TiledAltF32b::T16384np>(dir, real); return true; }
+        if (n == 16384 && g_variant == 85) { *e = tiled_entry<T, TiledAltF32b::T16384b>(dir, real); return true; }
         if (n == 8192 && g_variant == 79) { *e = tiled_entry<T, TiledAltF32b::T8192np0>(dir, real); return true; }
         if (n == 8192 && g_variant == 75) { *e = tiled_entry<T, TiledAltF32b::T8192>(dir, real); return true; }
         if (n == 8192 && g_variant == 76) { *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real); return true; }
