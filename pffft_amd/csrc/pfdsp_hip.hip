@@ -14,6 +14,8 @@
 // state in double precision.  There is NO CPU arithmetic path: the wrappers only do O(LANES) state math.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -122,14 +124,21 @@ static int legacy_mix(const complexf* in, complexf* out, size_t n, int lanes, co
     return 0;
 }
 
+// The reference's mixer entries cannot fail; like the transform entries of libpffft_hip.so they FAIL SOFT here: one line
+// on stderr (the first 8 per process), the output samples filled with NaN, the failure counted in
+// pfdsp_hip_error_count().  PFFFT_HIP_ABORT=1 turns a failure into abort().
+static std::atomic<unsigned> g_error_count{0};
 static void legacy_fatal(int code, const char* entry, complexf* out, size_t n) {
-    fprintf(stderr, "%s: HIP path failed (%d): %s\n", entry, code, g_last_error.c_str());
-    const char* na = getenv("PFFFT_HIP_NO_ABORT");
-    if (na && na[0] == '1') {
-        if (out && !is_device_ptr(out)) memset(out, 0xFF, n * sizeof(complexf));
-        return;
+    static const bool fail_fast = [] { const char* e = getenv("PFFFT_HIP_ABORT"); return e && e[0] == '1'; }();
+    const unsigned nth = g_error_count.fetch_add(1);
+    if (nth < 8 || fail_fast)
+        fprintf(stderr, "%s: HIP path failed (%d): %s%s\n", entry, code, g_last_error.c_str(),
+                fail_fast ? "" : " -- output filled with NaN (PFFFT_HIP_ABORT=1 aborts instead)");
+    if (fail_fast) abort();
+    if (out && n) {
+        if (!is_device_ptr(out)) memset(out, 0xFF, n * sizeof(complexf));
+        else if (hipMemset(out, 0xFF, n * sizeof(complexf)) != hipSuccess) (void)hipGetLastError();
     }
-    abort();
 }
 
 static void mix_or_die(const char* entry, const complexf* in, complexf* out, long n, int lanes, const double (*S)[2],
@@ -472,3 +481,4 @@ PD_EXPORT int pfdsp_hip_shift_device(const complexf* d_in, complexf* d_out, size
     return rc;
 }
 PD_EXPORT const char* pfdsp_hip_last_error(void) { return pd::g_last_error.c_str(); }
+PD_EXPORT unsigned pfdsp_hip_error_count(void) { return pd::g_error_count.load(); }
