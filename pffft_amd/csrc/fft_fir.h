@@ -190,3 +190,191 @@ struct FirCfg {
 };
 
 }  // namespace pf
+
+namespace pf {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Uniformly partitioned overlap-save in ONE kernel (round 2) — long filters on long signals / many signals.
+//
+// Reference: pffastconv_apply's block loop (src/pffastconv.c:207-261) transforms Nfft = 2 next_pow2(taps - 1) samples per
+// block; pffft_zconvolve_accumulate exists for exactly the partitioned form ("multiple convolutions ... accumulate",
+// README.md:273-275).  What a caller observes is only how many samples a call produces (fc_schedule) and the values of the
+// exact convolution — so the same outputs are computed here with the filter cut into P partitions of B = n taps:
+//     y[kB + m] = sum_p IFFT( X_{k+p} . H_p )[m],  m < B,   X_s = FFT_2B( x[sB .. sB + 2B) ),  H_p = FFT_2B of partition p's
+// correlation image.  Why: the 8192-point transforms of the long-block kernels run in workgroup-wide lock-step phases
+// (~33 k cycles per block and CU whatever the filter), while a 2048-sample block is ONE WAVEFRONT's
+// transform — wave-local exchanges, no workgroup barrier in the loop, wavefronts de-phase and overlap VALU with LDS like
+// the headline kernel.  Each wavefront owns a run of consecutive output blocks of one signal:
+//   * HBM traffic is the algorithmic 8 bytes per output sample: the first half of a block's input is the second half of
+//     the previous block's and is kept in registers (the operand layout makes them the same thread's chunks), the new
+//     half is prefetched one block ahead;
+//   * the last P packed spectra live in registers (P x 16 bins per lane);
+//   * the two pair passes and the product with H_p between the transforms are folded into two coefficients per bin and
+//     partition (see the kernel), built once per workgroup in LDS in the threads' own bin order (conflict-free 8-byte
+//     reads): ~1900 -> ~1150 VALU instructions per block for P = 1;
+//   * per output block: one forward and one inverse 1024-point complex transform + P x 16 x 2 complex multiply-adds per lane.
+// A run of K output blocks needs K + P - 1 forward transforms (the first P - 1 fill the ring).
+template <class C, int P, int OCC = (P > 2 ? 1 : 2)>
+__global__ void __launch_bounds__(C::WG_THREADS, OCC)
+fastconv_part_kernel(const float* __restrict__ x, float* __restrict__ y, const cx<float>* __restrict__ Hp,
+                     int nblk, int inputLen, int lastOut, int kchunk,
+                     const cx<float>* __restrict__ twg, const cx<float>* __restrict__ twrg,
+                     int nsig, size_t xstride, size_t ystride) {
+    typedef float T;
+    typedef cx<T> CX;
+    typedef Tiled<C, FWD, 1> KF;
+    typedef Tiled<C, BWD, 1> KB;
+    constexpr int n = C::n, E = C::E, TPT = C::TPT, NS = C::NS, WAVES = C::T_PER_WG;
+    constexpr int R0 = C::rad(0), RL = C::rad(NS - 1), HALF = R0 / 2, RS = RL;
+    constexpr int B = n;                                      // output samples per block, taps per partition
+    static_assert(TPT == 64 && R0 == RL && E / R0 == 2 && C::VEC == 2, "one wavefront per block, two butterflies per thread, float");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int slot = threadIdx.x / TPT, t = threadIdx.x % TPT;
+    CX* img = reinterpret_cast<CX*>(smem_raw) + (size_t)slot * C::IMG;
+    CX* AB = reinterpret_cast<CX*>(smem_raw) + (size_t)WAVES * C::IMG;          // [P][E][2][64]: coefficients A, B per lane
+
+    typename KF::Tw wf;
+    typename KB::Tw wb;
+    KF::load_tw(wf, t, twg, twrg);
+    KB::load_tw(wb, t, twg, twrg);
+    // ---- coefficients.  Between the two transforms the reference does: packed spectrum Z -> half-complex X (real finalize,
+    // src/pffft_priv_impl.h:1330-1372), X . H (zconvolve, :1632-1684), half-complex -> packed Z' (real preprocess, :1423-1462).
+    // All three are linear in the mirror pair (Z[k], conj Z[n-k]) that one thread owns, so they fold into
+    //     Z'[k]   = A  Z[k]   + B  conj Z[n-k]          A  = g Hk a + d conj(Hm) b      B  = g Hk b + d conj(Hm) a
+    //     Z'[n-k] = A' Z[n-k] + B' conj Z[k]            A' = conj(d Hk b + g conj(Hm) a)   B' = conj(d Hk a + g conj(Hm) b)
+    // with a = (1 - i w)/2, b = (1 + i w)/2, g = 1 + i conj(w), d = 1 - i conj(w), w = W_N^k, Hk = H[k], Hm = H[n-k];
+    // bin 0 = (DC, Nyquist): A = Hx + Hy, B = i (Hx - Hy) on itself; bin n/2: A = 2 conj(H), B = 0.
+    // Computed once per workgroup by its first wavefront (the lane -> bin map is the same in every wavefront).
+    if (slot == 0) {
+        auto bin_of_slot = [&](int i) { return KF::template jm<NS - 1>(t, i / RL) + (i % RL) * (n / RL); };
+        auto put = [&](int p, int i, CX a, CX b) { AB[((p * E + i) * 2 + 0) * 64 + t] = a; AB[((p * E + i) * 2 + 1) * 64 + t] = b; };
+        auto pair_coef = [&](int p, int ia, int ib, CX w) {       // slot ia holds bin k, slot ib its mirror n - k
+            const CX Hk = Hp[(size_t)p * n + bin_of_slot(ia)], Hm = Hp[(size_t)p * n + bin_of_slot(ib)];
+            const CX iw = mk<T>(-w.y, w.x), iwc = mk<T>(w.y, w.x);   // i w, i conj(w)
+            const CX al = mk<T>(0.5f * (1.f - iw.x), -0.5f * iw.y), be = mk<T>(0.5f * (1.f + iw.x), 0.5f * iw.y);
+            const CX ga = mk<T>(1.f + iwc.x, iwc.y), de = mk<T>(1.f - iwc.x, -iwc.y);
+            const CX gH = cmul(ga, Hk), dHm = cmul(de, conj(Hm)), dH = cmul(de, Hk), gHm = cmul(ga, conj(Hm));
+            put(p, ia, cmul(gH, al) + cmul(dHm, be), cmul(gH, be) + cmul(dHm, al));
+            put(p, ib, conj(cmul(dH, be) + cmul(gHm, al)), conj(cmul(dH, al) + cmul(gHm, be)));
+        };
+#pragma unroll 1
+        for (int p = 0; p < P; ++p) {
+            if (t != 0) {
+                for (int d = 0; d < RS; ++d) pair_coef(p, d, RS + (RS - 1 - d), wf.p[d]);
+            } else {
+                const CX H0 = Hp[(size_t)p * n], Hh = Hp[(size_t)p * n + n / 2];
+                put(p, 0, mk<T>(H0.x + H0.y, 0.f), mk<T>(0.f, H0.x - H0.y));
+                put(p, RS / 2, mk<T>(2.f * Hh.x, -2.f * Hh.y), mk<T>(0.f, 0.f));
+                for (int d = 1; d < RS / 2; ++d) pair_coef(p, d, RS - d, wf.p[d]);
+                for (int d = 0; d < RS / 2; ++d) pair_coef(p, RS + d, RS + (RS - 1 - d), wf.p[RS / 2 + d]);
+            }
+        }
+    }
+    __syncthreads();
+
+    const long ntask_sig = (nblk + kchunk - 1) / kchunk;
+    const long ntask = ntask_sig * nsig;
+    const long gw = (long)blockIdx.x * WAVES + slot, nw = (long)gridDim.x * WAVES;
+    typedef vec4<float> F4;
+    // 4 consecutive samples of the signal starting at e (zero beyond the end: src/pffastconv.c:231-233)
+    auto load4 = [&](const float* xs, long e) -> F4 {
+        F4 r;
+        if (e + 3 < inputLen) {
+            const F4u q4 = *reinterpret_cast<const F4u*>(xs + e);
+            r.x = q4.a; r.y = q4.b; r.z = q4.c; r.w = q4.d;
+        } else {
+            r.x = e < inputLen ? xs[e] : 0.f; r.y = e + 1 < inputLen ? xs[e + 1] : 0.f;
+            r.z = e + 2 < inputLen ? xs[e + 2] : 0.f; r.w = e + 3 < inputLen ? xs[e + 3] : 0.f;
+        }
+        return r;
+    };
+    const bool first = t == 0;
+    for (long task = gw; task < ntask; task += nw) {
+        const int sig = (int)(task / ntask_sig);
+        const int k0 = (int)(task - (long)sig * ntask_sig) * kchunk;
+        const int k1 = k0 + kchunk < nblk ? k0 + kchunk : nblk;
+        const float* xs = x + (size_t)sig * xstride;
+        float* ys = y + (size_t)sig * ystride;
+        CX ring[P][E];                                        // packed spectra Z of the last P blocks
+        // chunk q of a block: samples 4 (t + q n / (2 R0)) .. + 3; chunks HALF .. R0-1 are the block's new half and become
+        // chunks 0 .. HALF-1 of the next block
+        F4 hi[HALF], nx[HALF];
+#pragma unroll
+        for (int q = 0; q < HALF; ++q) hi[q] = load4(xs, (long)k0 * B + 4 * (t + q * (n / (2 * R0))));
+#pragma unroll
+        for (int q = 0; q < HALF; ++q) nx[q] = load4(xs, (long)(k0 + 1) * B + 4 * (t + q * (n / (2 * R0))));
+        for (int s = k0; s < k1 + P - 1; ++s) {
+            CX v[E];
+#pragma unroll
+            for (int q = 0; q < HALF; ++q) {
+                v[q] = mk<T>(hi[q].x, hi[q].y); v[R0 + q] = mk<T>(hi[q].z, hi[q].w);
+                v[HALF + q] = mk<T>(nx[q].x, nx[q].y); v[R0 + HALF + q] = mk<T>(nx[q].z, nx[q].w);
+                hi[q] = nx[q];
+            }
+#pragma unroll
+            for (int q = 0; q < HALF; ++q) nx[q] = load4(xs, (long)(s + 2) * B + 4 * (t + q * (n / (2 * R0))));   // next block's new half
+            // ---- forward transform of x[sB .. sB + 2B) -> packed spectrum Z_s (no pair pass: folded into A, B)
+            KF::template butterflies<0>(v, t, wf, twg);
+            KF::template xwrite<0>(v, t, img); KF::xsync();
+            KF::template xread<0>(v, t, img); KF::xsync(); KF::template butterflies<1>(v, t, wf, twg);
+            if constexpr (NS > 2) { KF::template xwrite<1>(v, t, img); KF::xsync(); KF::template xread<1>(v, t, img); KF::xsync(); KF::template butterflies<2>(v, t, wf, twg); }
+            if constexpr (NS > 3) { KF::template xwrite<2>(v, t, img); KF::xsync(); KF::template xread<2>(v, t, img); KF::xsync(); KF::template butterflies<3>(v, t, wf, twg); }
+#pragma unroll
+            for (int p = 0; p + 1 < P; ++p)
+#pragma unroll
+                for (int i = 0; i < E; ++i) ring[p][i] = ring[p + 1][i];
+#pragma unroll
+            for (int i = 0; i < E; ++i) ring[P - 1][i] = v[i];
+            if (s - k0 < P - 1) continue;                     // the ring is still filling
+            // ---- Z'_k = sum_p (A_p Z_{k+p} + B_p conj(mirror of Z_{k+p})): the mirror of slot i sits in slot pi(i) of the same
+            //      thread — RS + (RS-1-d) <-> d, except in thread 0, whose two butterflies are self-mirrored
+            const int k = s - (P - 1);
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                constexpr int dummy = 0; (void)dummy;
+                const int u = i / RS, d = i % RS;
+                const int pi1 = u == 0 ? RS + (RS - 1 - d) : (RS - 1 - d);                       // threads 1 .. 63
+                const int pi0 = u == 0 ? (d == 0 || d == RS / 2 ? d : RS - d) : RS + (RS - 1 - d);   // thread 0
+                CX acc = mk<T>(0.f, 0.f);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const CX a = AB[((p * E + i) * 2 + 0) * 64 + t], bq = AB[((p * E + i) * 2 + 1) * 64 + t];
+                    const CX z = ring[p][i], zm = KF::sel(first, ring[p][pi0], ring[p][pi1]);
+                    // acc += a z + bq conj(zm)
+                    acc = mk<T>(fma_(a.x, z.x, fma_(-a.y, z.y, fma_(bq.x, zm.x, fma_(bq.y, zm.y, acc.x)))),
+                                fma_(a.x, z.y, fma_(a.y, z.x, fma_(bq.y, zm.x, fma_(-bq.x, zm.y, acc.y)))));
+                }
+                v[i] = acc;
+            }
+            // ---- inverse transform; its first B samples are the block's outputs (src/pffastconv.c:255)
+            KB::template butterflies<0>(v, t, wb, twg);
+            KB::template xwrite<0>(v, t, img); KB::xsync();
+            KB::template xread<0>(v, t, img); KB::xsync(); KB::template butterflies<1>(v, t, wb, twg);
+            if constexpr (NS > 2) { KB::template xwrite<1>(v, t, img); KB::xsync(); KB::template xread<1>(v, t, img); KB::xsync(); KB::template butterflies<2>(v, t, wb, twg); }
+            if constexpr (NS > 3) { KB::template xwrite<2>(v, t, img); KB::xsync(); KB::template xread<2>(v, t, img); KB::xsync(); KB::template butterflies<3>(v, t, wb, twg); }
+            const int numOut = (k == nblk - 1) ? lastOut : B;
+            float* dst = ys + (size_t)k * B;
+#pragma unroll
+            for (int d = 0; d < HALF; ++d) {
+                const int e0 = 4 * (t + d * (n / (2 * RL)));
+                const CX a = v[d], bb = v[RL + d];
+                if (e0 + 3 < numOut) {
+                    F4u q4; q4.a = a.x; q4.b = a.y; q4.c = bb.x; q4.d = bb.y;
+                    *reinterpret_cast<F4u*>(dst + e0) = q4;
+                } else {
+                    if (e0 < numOut) dst[e0] = a.x;
+                    if (e0 + 1 < numOut) dst[e0 + 1] = a.y;
+                    if (e0 + 2 < numOut) dst[e0 + 2] = bb.x;
+                }
+            }
+            KB::xsync();
+        }
+    }
+}
+
+struct FirPartCfg {
+    // n = 1024 complex points = 2048-sample blocks, one wavefront per block, 4 wavefronts per workgroup
+    typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 0, 256, 1> C1024;
+};
+
+}  // namespace pf

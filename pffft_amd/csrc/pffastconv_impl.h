@@ -26,6 +26,8 @@ struct FastConv {
     float* d_Hc = nullptr;  // canonical-order filter spectrum * 1/Nfft for the fused kernel
     // throughput regime (many blocks): the same outputs through LARGER internal blocks (better overlap-save efficiency)
     PFFFT_Setup* st_big = nullptr; float* d_Hc_big = nullptr; int Nfft_big = 0;
+    // partitioned path (fft_fir.h fastconv_part_kernel): P spectra of 1024-tap partitions on 2048-sample blocks
+    PFFFT_Setup* st_part = nullptr; float* d_Hp = nullptr; int part_P = 0;
     std::vector<float> h_td;  // y[m] = sum_i h_td[i] x[m + i]: the filter as the time-domain kernel applies it (zero padded to 8)
     float* d_td = nullptr;
     // work image of the composed path: one per stream (two streams running one setup must not share scratch)
@@ -251,6 +253,64 @@ static int fc_ensure_big(FastConv* s, int Nfft_big) {
     return 0;
 }
 
+// ---- partitioned path: the filter as P partitions of PART_B taps on blocks of 2 PART_B samples (fft_fir.h) ----
+constexpr int PART_B = 1024, PART_MAXP = 4;
+static int fc_ensure_part(FastConv* s) {
+    const int P = (s->filterLen + PART_B - 1) / PART_B;
+    if (s->part_P == P && s->d_Hp) return 0;
+    const int Nfft = 2 * PART_B;
+    if (!s->st_part) s->st_part = pffft_new_setup(Nfft, PFFFT_REAL);
+    if (!s->st_part) { g_last_error = "pffastconv: internal setup failed"; return (int)hipErrorInvalidValue; }
+    // correlation image of partition p (src/pffastconv.c:100-106 with the partition's taps): g[(Nfft - i) mod Nfft] = c[pB + i]
+    std::vector<float> img((size_t)P * Nfft, 0.f);
+    for (int i = 0; i < s->filterLen; ++i) img[(size_t)(i / PART_B) * Nfft + ((Nfft - i % PART_B) & (Nfft - 1))] = s->h_td[i];
+    float* d_tmp = nullptr;
+    if (s->d_Hp) { (void)hipFree(s->d_Hp); s->d_Hp = nullptr; s->part_P = 0; }
+    PF_CHECK(hipMalloc((void**)&d_tmp, sizeof(float) * P * Nfft));
+    PF_CHECK(hipMalloc((void**)&s->d_Hp, sizeof(float) * P * Nfft));
+    PF_CHECK(hipMemcpy(d_tmp, img.data(), sizeof(float) * P * Nfft, hipMemcpyHostToDevice));
+    int rc = transform_batch<float>(s->st_part, d_tmp, d_tmp, P, PFFFT_FORWARD, 0, nullptr);
+    if (!rc) rc = zreorder_batch<float>(s->st_part, d_tmp, s->d_Hp, P, PFFFT_FORWARD, nullptr);
+    if (!rc) {
+        hipLaunchKernelGGL(fastconv_scale_kernel, dim3(64), dim3(256), 0, nullptr, s->d_Hp, s->d_Hp, P * Nfft, 1.0f / (float)Nfft);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) rc = (int)hipErrorUnknown;
+    }
+    (void)hipFree(d_tmp);
+    if (rc) { (void)hipFree(s->d_Hp); s->d_Hp = nullptr; return rc; }
+    s->part_P = P;
+    return 0;
+}
+
+template <int P, int OCC = (P > 2 ? 1 : 2)>
+static int fc_launch_part(FastConv* s, const float* d_x, float* d_y, long produced, int inputLen, hipStream_t st, const FcBatch& fb) {
+    typedef FirPartCfg::C1024 C;
+    auto k = fastconv_part_kernel<C, P, OCC>;
+    const size_t lds = ((size_t)C::T_PER_WG * C::IMG + (size_t)P * C::E * 2 * 64) * sizeof(cx<float>);
+    int rc = allow_big_lds(k, lds);
+    if (rc) return rc;
+    int per_cu = 0;
+    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, lds));
+    if (per_cu < 1) per_cu = 1;
+    const int nblk = (int)((produced + PART_B - 1) / PART_B);
+    const int lastOut = (int)(produced - (long)(nblk - 1) * PART_B);
+    const long waves = (long)num_cus() * per_cu * C::T_PER_WG;
+    // runs of consecutive output blocks per wavefront task: ~4 tasks per wavefront, never so short that filling the ring
+    // (P - 1 extra forward transforms per run) costs more than ~10 %
+    long kchunk = ((long)nblk * fb.nsig + 4 * waves - 1) / (4 * waves);
+    if (kchunk < 10 * (P - 1)) kchunk = 10 * (P - 1);
+    if (kchunk < 4) kchunk = 4;
+    if (kchunk > nblk) kchunk = nblk;
+    const long ntask = ((nblk + kchunk - 1) / kchunk) * fb.nsig;
+    long grid = (ntask + C::T_PER_WG - 1) / C::T_PER_WG;
+    if (grid > (long)num_cus() * per_cu) grid = (long)num_cus() * per_cu;
+    Setup* ps = s->st_part;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), lds, st, d_x, d_y, (const cx<float>*)s->d_Hp, nblk, inputLen,
+                       lastOut, (int)kchunk, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, fb.nsig, fb.xstride, fb.ystride);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+static int g_fir_part = [] { const char* e = getenv("PFFASTCONV_HIP_PART"); return e ? atoi(e) : -1; }();   // -1 = default
+
 // Block schedule of src/pffastconv.c:156-166 / :204-210.  Returns the number of time blocks and the
 // number of outputs of the last one; *produced = value returned by pffastconv_apply (in real samples).
 static int fc_schedule(const FastConv* s, int inputLen, int flush, int* lastOut, int* produced) {
@@ -297,6 +357,28 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     const int nblk = mode ? 2 * nbt : nbt;
     const int Nfft = s->Nfft;
     const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
+    if (mode == 0 && s->cplxFactor == 1 && g_variant != 30 && s->filterLen > TD_MAX_TAPS / 4 && s->filterLen <= PART_B * PART_MAXP) {
+        // many blocks of a long filter: the partitioned one-wavefront-per-block kernel (variant 88 forces it,
+        // PFFASTCONV_HIP_PART=0 switches it off)
+        // Measured (MI355X, tools/fir_quick.py, fraction of the 8 B / sample roofline on 2^26 samples / 256 signals of 2^20;
+        // best other path -> this kernel): 200 taps 0.26 / 0.31 -> 0.30 / 0.30, 600 taps 0.26 / 0.30 -> 0.33 / 0.31, 1024 taps
+        // 0.26 / 0.29 -> 0.34 / 0.32 (one partition, three wavefronts per SIMD), 2048 taps 0.25 / 0.28 -> 0.26 / 0.28 (two
+        // partitions); three and four partitions keep their ring in > 256 registers, run one wavefront per SIMD (0.12-0.23)
+        // and lose to the long-block kernels (0.21-0.26): default up to two partitions.
+        const long blocks = ((long)produced + PART_B - 1) / PART_B * fb.nsig;
+        const int P = (s->filterLen + PART_B - 1) / PART_B;
+        const bool want = g_variant == 88 || (g_variant == 0 && g_fir_part != 0 && (g_fir_part > 0 || (P <= 2 && blocks >= 8L * num_cus())));
+        if (want && produced > 0) {
+            if ((rc = fc_ensure_part(s))) return rc;
+            switch (s->part_P) {
+                case 1: return fc_launch_part<1, 3>(s, d_x, d_y, produced, inputLen, st, fb);
+                case 2: return fc_launch_part<2, 2>(s, d_x, d_y, produced, inputLen, st, fb);
+                case 3: return fc_launch_part<3, 1>(s, d_x, d_y, produced, inputLen, st, fb);
+                case 4: return fc_launch_part<4, 1>(s, d_x, d_y, produced, inputLen, st, fb);
+                default: break;
+            }
+        }
+    }
     if (mode == 0 && s->cplxFactor == 1 && g_variant != 30) {
         const int nbig = fc_big_nfft(s, produced, fb.nsig);
         if (nbig) {
@@ -416,7 +498,8 @@ PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
     if (!s) return;
     pffft_destroy_setup(s->st);
     if (s->st_big) pffft_destroy_setup(s->st_big);
-    for (float* p : {s->d_Hf, s->d_Hc, s->d_Hc_big, s->d_td, s->d_x, s->d_y}) if (p) (void)hipFree(p);
+    for (float* p : {s->d_Hf, s->d_Hc, s->d_Hc_big, s->d_Hp, s->d_td, s->d_x, s->d_y}) if (p) (void)hipFree(p);
+    if (s->st_part) pffft_destroy_setup(s->st_part);
     for (auto& kv : s->work) if (kv.second.p) (void)hipFree(kv.second.p);
     for (float* p : {s->h_x, s->h_y}) if (p) (void)hipHostFree(p);
     s->magic = 0;

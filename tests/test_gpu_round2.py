@@ -327,3 +327,31 @@ def test_fastconv_dma_block_kernel_on_a_long_signal(ref, flush):
     assert np.abs(y.cpu().numpy() - yw).max() <= lim
     assert np.abs(y0.cpu().numpy() - yw).max() <= lim
     fc.close()
+
+
+@pytest.mark.parametrize("taps,L,nsig", [(1024, 1 << 22, 2), (600, 3000001, 1), (2048, 1 << 22, 2), (130, 1 << 21, 3),
+                                        (3000, 1 << 21, 2), (4096, 1 << 21, 2)])
+@pytest.mark.parametrize("flush", [1, 0])
+def test_fastconv_partitioned_kernel(ref, taps, L, nsig, flush):
+    """fastconv_part_kernel (fft_fir.h): uniformly partitioned overlap-save, one wavefront per 2048-sample block, the pair
+    passes and the product with H folded into two coefficients per bin.  Default for <= 2048 taps when a call spans many
+    blocks; variant 88 forces it for up to 4096 taps (1 .. 4 partitions).  Same count as the reference's block schedule,
+    values within the reference test's limit over the WHOLE signals, samples beyond the produced ones untouched."""
+    rng = np.random.default_rng(taps + nsig)
+    xs = rng.uniform(-1, 1, (nsig, L)).astype(np.float32)
+    h = rng.uniform(-1, 1, taps).astype(np.float32)
+    fc = pa.FastConv(h, 0, 0)
+    xd = torch.from_numpy(xs).cuda()
+    yd = torch.full_like(xd, 7.0)
+    try:
+        pa.set_variant(88)
+        y, n = fc.apply_batch(xd, bool(flush), out=yd)
+    finally:
+        pa.set_variant(0)
+    got = y.cpu().numpy()
+    for i in range(nsig):
+        yw, nw, _ = ref.fastconv(xs[i], h, 0, 0, flush)
+        assert n == nw
+        assert np.abs(got[i] - yw).max() <= (yw.max() - yw.min()) / 1e5, i
+    assert bool((yd[:, n:] == 7.0).all())
+    fc.close()
