@@ -312,11 +312,36 @@ fastconv_dma_kernel(const float* __restrict__ x, float* __restrict__ y, const cx
     typename KB::Tw wb;
     KF::load_tw(wf, t, twg, twrg);
     KB::load_tw(wb, t, twg, twrg);
-    CX h[E];   // filter spectrum of the bins this thread owns after the forward transform: k = jm(t,u) + d n/R
+    // Between the two transforms the reference does real finalize -> X . H -> real preprocess (src/pffft_priv_impl.h:1330-1372,
+    // :1632-1684, :1423-1462).  All three are linear in the mirror pair (Z[k], conj Z[n-k]) this thread owns, so they fold
+    // into two coefficients per bin (derivation: fft_fir.h fastconv_part_kernel):  Z'[k] = A Z[k] + B conj Z[n-k].
+    constexpr int RS = RL;
+    CX cA[E], cB[E];
+    {
+        auto bin_of_slot = [&](int i) { return KF::template jm<NS - 1>(t, i / RL) + (i % RL) * (n / RL); };
+        auto pair_coef = [&](int ia, int ib, CX w) {              // slot ia holds bin k, slot ib its mirror n - k
+            const CX Hk = Hc[bin_of_slot(ia)], Hm = Hc[bin_of_slot(ib)];
+            const CX iw = mk<T>(-w.y, w.x), iwc = mk<T>(w.y, w.x);   // i w, i conj(w)
+            const CX al = mk<T>(0.5f * (1.f - iw.x), -0.5f * iw.y), be = mk<T>(0.5f * (1.f + iw.x), 0.5f * iw.y);
+            const CX ga = mk<T>(1.f + iwc.x, iwc.y), de = mk<T>(1.f - iwc.x, -iwc.y);
+            const CX gH = cmul(ga, Hk), dHm = cmul(de, conj(Hm)), dH = cmul(de, Hk), gHm = cmul(ga, conj(Hm));
+            cA[ia] = cmul(gH, al) + cmul(dHm, be); cB[ia] = cmul(gH, be) + cmul(dHm, al);
+            cA[ib] = conj(cmul(dH, be) + cmul(gHm, al)); cB[ib] = conj(cmul(dH, al) + cmul(gHm, be));
+        };
+        // every thread evaluates the regular pairing; thread 0 (both butterflies self-mirrored) overrides its own
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+        for (int d = 0; d < RS; ++d) pair_coef(d, RS + (RS - 1 - d), wf.p[d]);
+        if (t == 0) {
+            const CX H0 = Hc[0], Hh = Hc[n / 2];
+            cA[0] = mk<T>(H0.x + H0.y, 0.f); cB[0] = mk<T>(0.f, H0.x - H0.y);                 // (DC, Nyquist) on itself
+            cA[RS / 2] = mk<T>(2.f * Hh.x, -2.f * Hh.y); cB[RS / 2] = mk<T>(0.f, 0.f);        // bin n/2
 #pragma unroll
-        for (int d = 0; d < RL; ++d) h[u * RL + d] = Hc[KF::template jm<NS - 1>(t, u) + d * (n / RL)];
+            for (int d = 1; d < RS / 2; ++d) pair_coef(d, RS - d, wf.p[d]);
+#pragma unroll
+            for (int d = 0; d < RS / 2; ++d) pair_coef(RS + d, RS + (RS - 1 - d), wf.p[RS / 2 + d]);
+        }
+    }
+    const bool first = t == 0;
 
     const bool dyn = ctr != nullptr;
     unsigned pend = 0;
@@ -396,19 +421,21 @@ fastconv_dma_kernel(const float* __restrict__ x, float* __restrict__ y, const cx
         KF::template xread<0>(v, t, img); wg_sync_raw(); KF::template butterflies<1>(v, t, wf, twg);
         if constexpr (NS > 2) { KF::template xwrite<1>(v, t, img); wg_sync_raw(); KF::template xread<1>(v, t, img); wg_sync_raw(); KF::template butterflies<2>(v, t, wf, twg); }
         if constexpr (NS > 3) { KF::template xwrite<2>(v, t, img); wg_sync_raw(); KF::template xread<2>(v, t, img); wg_sync_raw(); KF::template butterflies<3>(v, t, wf, twg); }
-        KF::pair_regs(v, t, wf);                       // packed spectrum -> half-complex spectrum X[k]
-        // ---- X[k] * H[k] (scaled by 1/Nfft, src/pffastconv.c:97,238); bin 0 carries (DC, Nyquist): two real products
+        // ---- Z'[k] = A Z[k] + B conj Z[mirror]: the mirror of slot i sits in slot pi(i) of the same thread
+        {
+            CX z[E];
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const CX p = cmul(v[i], h[i]);
-            if (i == 0) {
-                const CX r = mk<T>(v[0].x * h[0].x, v[0].y * h[0].y);
-                v[0] = KF::sel(t == 0, r, p);
-            } else {
-                v[i] = p;
+            for (int i = 0; i < E; ++i) z[i] = v[i];
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int u = i / RS, d = i % RS;
+                const int pi1 = u == 0 ? RS + (RS - 1 - d) : (RS - 1 - d);                           // threads != 0
+                const int pi0 = u == 0 ? (d == 0 || d == RS / 2 ? d : RS - d) : RS + (RS - 1 - d);   // thread 0
+                const CX zm = KF::sel(first, z[pi0], z[pi1]), a = cA[i], bq = cB[i], zz = z[i];
+                v[i] = mk<T>(fma_(a.x, zz.x, fma_(-a.y, zz.y, fma_(bq.x, zm.x, bq.y * zm.y))),
+                             fma_(a.x, zz.y, fma_(a.y, zz.x, fma_(bq.y, zm.x, -(bq.x * zm.y)))));
             }
         }
-        KB::pair_regs(v, t, wb);                       // half-complex spectrum -> packed spectrum of the inverse
         // ---- backward transform (first-stage operands are already in place) ----
         KB::template butterflies<0>(v, t, wb, twg);
         KB::template xwrite<0>(v, t, img); wg_sync_raw();

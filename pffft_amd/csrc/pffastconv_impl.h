@@ -362,12 +362,12 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         // PFFASTCONV_HIP_PART=0 switches it off)
         // Measured (MI355X, tools/fir_quick.py, fraction of the 8 B / sample roofline on 2^26 samples / 256 signals of 2^20;
         // best other path -> this kernel): 200 taps 0.26 / 0.31 -> 0.30 / 0.30, 600 taps 0.26 / 0.30 -> 0.33 / 0.31, 1024 taps
-        // 0.26 / 0.29 -> 0.34 / 0.32 (one partition, three wavefronts per SIMD), 2048 taps 0.25 / 0.28 -> 0.26 / 0.28 (two
-        // partitions); three and four partitions keep their ring in > 256 registers, run one wavefront per SIMD (0.12-0.23)
-        // and lose to the long-block kernels (0.21-0.26): default up to two partitions.
+        // 0.27 / 0.31 -> 0.34 / 0.32 (one partition, three wavefronts per SIMD); two partitions (2048 taps: 0.25 / 0.26) lose to
+        // the long-block DMA kernel with its folded coefficients (0.26 / 0.30); three and four partitions keep their ring in
+        // > 256 registers, run one wavefront per SIMD (0.12-0.23): default for filters of up to 1024 taps only.
         const long blocks = ((long)produced + PART_B - 1) / PART_B * fb.nsig;
         const int P = (s->filterLen + PART_B - 1) / PART_B;
-        const bool want = g_variant == 88 || (g_variant == 0 && g_fir_part != 0 && (g_fir_part > 0 || (P <= 2 && blocks >= 8L * num_cus())));
+        const bool want = g_variant == 88 || (g_variant == 0 && g_fir_part != 0 && (g_fir_part > 0 || (P <= 1 && blocks >= 8L * num_cus())));
         if (want && produced > 0) {
             if ((rc = fc_ensure_part(s))) return rc;
             switch (s->part_P) {
