@@ -4,6 +4,7 @@
 #include "../../include/pffft_hip.h"
 #include "pf_host.h"
 #include "fft_dma.h"
+#include "fft_split.h"
 
 namespace pf {
 
@@ -66,6 +67,34 @@ int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, i
         case 8192: return fir_dma_cfg<DmaCfgF32::D8192>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
         default: return -1;
     }
+}
+
+
+int launch_split(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st, int prefetch) {
+    if (s->is_double || s->transform != PFFFT_REAL || s->n != SplitC3::n || dir != PFFFT_FORWARD) return -1;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!s->d_tw_sub) {
+            std::vector<cx<float>> tw(SplitC3::M);
+            for (int j = 0; j < SplitC3::M; ++j) {
+                long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)SplitC3::M;
+                tw[j].x = (float)cosl(a); tw[j].y = (float)sinl(a);
+            }
+            PF_CHECK(hipMalloc(&s->d_tw_sub, sizeof(cx<float>) * SplitC3::M));
+            PF_CHECK(hipMemcpy(s->d_tw_sub, tw.data(), sizeof(cx<float>) * SplitC3::M, hipMemcpyHostToDevice));
+        }
+    }
+    // one workgroup per CU, 180 VGPRs (two workgroups per CU need <= 128: 192 bytes of scratch per lane, 0.49-0.51)
+    auto k = prefetch ? fft_split_real_fwd_kernel<1, 2> : fft_split_real_fwd_kernel<0, 2>;
+    int rc = allow_big_lds(k, SplitC3::LDS_BYTES);
+    if (rc) return rc;
+    size_t grid = (size_t)num_cus();
+    if (grid > batch) grid = batch;
+    unsigned* ctr = batch <= grid ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(SplitC3::WG), SplitC3::LDS_BYTES, st, in, out, (unsigned)batch,
+                       ordered ? 0 : 2, (const cx<float>*)s->d_tw, (const cx<float>*)s->d_tw_sub, (const cx<float>*)s->d_twr, ctr);
+    PF_CHECK(hipGetLastError());
+    return 0;
 }
 
 }  // namespace pf

@@ -223,6 +223,7 @@ static void destroy_setup(Setup* s) {
         for (void* q : s->d_twc) if (q) (void)hipFree(q);
     }
     if (s->d_ctr) (void)hipFree(s->d_ctr);
+    if (s->d_tw_sub) (void)hipFree(s->d_tw_sub);
     if (s->sub) destroy_setup(s->sub);
     for (void* p : s->d_bigtw) if (p) (void)hipFree(p);
     for (auto& kv : s->big_scratch) for (void* p : kv.second.buf) if (p) (void)hipFree(p);
@@ -812,6 +813,12 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         const int dma = g_variant == 95 ? 1 : g_variant == 96 ? 2 : g_variant == 98 ? 3 : (g_variant == 0 ? g_dma_mode : 0);
         if (s->kernel == K_TILED && dma > 0 && batch < (1ull << 32) && s->n >= 2048 && s->n <= 8192)
             return launch_dma(s, in, out, batch, dir, ordered, st, dma);
+    }
+    if constexpr (sizeof(T) == 4) {
+        // variants 89 / 90: the split kernel (fft_split.h), with / without register prefetch (A/B)
+        if ((g_variant == 89 || g_variant == 90) && s->kernel == K_TILED && s->n == 8192 && s->transform == PFFFT_REAL &&
+            dir == PFFFT_FORWARD && batch < (1ull << 32))
+            return launch_split(s, in, out, batch, dir, ordered, st, g_variant == 89);
     }
     if (s->kernel == K_TILED && g_variant != 1 && g_variant != 50 && batch < (1ull << 32)) {
         // power-of-two sizes where the Stockham kernel instantiated on its compile-time plan measured faster than

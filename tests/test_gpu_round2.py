@@ -355,3 +355,29 @@ def test_fastconv_partitioned_kernel(ref, taps, L, nsig, flush):
         assert np.abs(got[i] - yw).max() <= (yw.max() - yw.min()) / 1e5, i
     assert bool((yd[:, n:] == 7.0).all())
     fc.close()
+
+
+def test_split_kernel_c3_against_reference(ref):
+    """fft_split.h (variant 89): real forward N = 16384 as a cross-wave radix-8 stage + one wave-local 1024-point transform
+    per wavefront + block-gather pair pass.  Opt-in (measured on par with the default kernel); same parity bar, both
+    layouts, ragged batches, in place, and bit-identical between its two layouts through zreorder."""
+    N = 16384
+    s = pa.Setup(N, pa.REAL)
+    rs = ref.setup(N, pa.REAL)
+    try:
+        for B in (1, 3, 259, 1031):
+            x = _uniform((B, N), 300 + B)
+            idx = sorted({0, B // 2, B - 1})
+            xh = x[idx].cpu().numpy()
+            pa.set_variant(89)
+            yu = s.transform_batch(x, None, pa.FORWARD, False)
+            yo = s.transform_batch(x, None, pa.FORWARD, True)
+            z = x.clone(); s.transform_batch(z, z, pa.FORWARD, False)
+            pa.set_variant(0)
+            assert relerr(yu[idx].cpu().numpy(), rs.batch(xh, 0, False)) <= 1e-5, B
+            assert relerr(yo[idx].cpu().numpy(), rs.batch(xh, 0, True)) <= 1e-5, B
+            assert torch.equal(z, yu)
+            assert torch.equal(s.zreorder_batch(yu, None, pa.FORWARD), yo)
+    finally:
+        pa.set_variant(0)
+    s.close(); rs.close()
