@@ -294,11 +294,15 @@ static int fc_launch_part(FastConv* s, const float* d_x, float* d_y, long produc
     const int nblk = (int)((produced + PART_B - 1) / PART_B);
     const int lastOut = (int)(produced - (long)(nblk - 1) * PART_B);
     const long waves = (long)num_cus() * per_cu * C::T_PER_WG;
-    // runs of consecutive output blocks per wavefront task: ~4 tasks per wavefront, never so short that filling the ring
-    // (P - 1 extra forward transforms per run) costs more than ~10 %
-    long kchunk = ((long)nblk * fb.nsig + 4 * waves - 1) / (4 * waves);
+    // runs of consecutive output blocks per wavefront task: ~2 tasks per wavefront (measured on 2^26 samples: runs of 8-16
+    // blocks 0.34, 4: 0.32, 32: 0.30, 64: 0.22; on 256 signals of 2^20: 32-64 best — both ~1.3-2.7 tasks per wavefront; the
+    // first loads of a run are not prefetched), never so short that filling the ring (P - 1 extra forward transforms per
+    // run) costs more than ~10 %
+    long kchunk = ((long)nblk * fb.nsig + 2 * waves - 1) / (2 * waves);
     if (kchunk < 10 * (P - 1)) kchunk = 10 * (P - 1);
-    if (kchunk < 4) kchunk = 4;
+    if (kchunk < 8) kchunk = 8;
+    static const int k_env = [] { const char* e = getenv("PFFASTCONV_HIP_PART_K"); return e ? atoi(e) : 0; }();   // A/B
+    if (k_env > 0) kchunk = k_env;
     if (kchunk > nblk) kchunk = nblk;
     const long ntask = ((nblk + kchunk - 1) / kchunk) * fb.nsig;
     long grid = (ntask + C::T_PER_WG - 1) / C::T_PER_WG;
