@@ -10,8 +10,11 @@ R = oref.get()
 dev = "cuda"
 
 
-def timed(fn, reps=10):
-    fn(); torch.cuda.synchronize()
+def timed(fn, reps=10, warm=None):
+    # the first ~15 launches of a kernel climb to the steady rate (tools/c3_ramp.py): warm up ~30 ms before timing
+    for _ in range(warm if warm is not None else max(3, 2 * reps)):
+        fn()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):

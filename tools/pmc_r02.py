@@ -48,7 +48,7 @@ for key, sub, alg, what in CASES:
     disp = big_dispatches(trace, sub, "Kernel_Name", "Grid_Size_X")
     if not disp or key not in vals:
         continue
-    disp = disp[4:] if len(disp) > 6 else disp[1:]       # the first launches carry first-touch faults and the clock ramp
+    disp = disp[-12:] if len(disp) > 24 else disp[1:]    # the first ~15 launches carry first-touch faults and the clock / TLB ramp
     durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in disp]
     krow = {"Name": disp[0]["Kernel_Name"], "Calls": len(disp), "AverageNs": sum(durs) / len(durs)}
     a = {k: sum(v) / len(v) for k, v in vals[key].items()}

@@ -5,7 +5,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pffft_amd as pa
-reps = 12
+reps = 40   # the first ~15 launches of a kernel climb to the steady rate (tools/c3_ramp.py); pmc_r02.py averages the last ones
 def fft(N, tr, dtype, B, ordered=False):
     s = pa.Setup(N, tr, dtype)
     tdt = torch.float64 if dtype == np.float64 else torch.float32
