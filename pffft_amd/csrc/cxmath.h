@@ -221,6 +221,7 @@ template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a
     else if constexpr (R == 12) dft_pfa<4, 3, DIR>(a);
     else if constexpr (R == 15) dft_pfa<3, 5, DIR>(a);
     else if constexpr (R == 16) dft16<DIR>(a);
+    else if constexpr (R == 24) dft_pfa<8, 3, DIR>(a);
     else if constexpr (R == 32) dft32<DIR>(a);
 }
 

@@ -28,6 +28,7 @@
 //   * the backward transform is conj o forward o conj, so there is one set of stage bodies per precision;
 //   * groups of G consecutive vectors are pulled in order from the work counter (see fft_c1024.h).
 #pragma once
+#include <type_traits>
 #include "cxmath.h"
 #include "fft_generic.h"  // fdiv
 
@@ -400,8 +401,13 @@ __device__ __forceinline__ void sk_first_real(const StockStage& st, const SkArgs
     }
 }
 
-template <typename T, int SRC, int DST>
+// RC > 0: the radix as a compile-time constant (compile-time plans: one instantiation per stage); RC == 0: run-time dispatch
+template <typename T, int SRC, int DST, int RC = 0>
 __device__ __forceinline__ void sk_run(const StockStage& st, const SkArgs<T>& a) {
+    if constexpr (RC > 0) {
+        if constexpr (sizeof(T) == 4 || RC <= 12) sk_stage<T, RC, SRC, DST>(st, a);
+        return;
+    }
     switch (st.R) {
         case 3: sk_stage<T, 3, SRC, DST>(st, a); break;
         case 4: sk_stage<T, 4, SRC, DST>(st, a); break;
@@ -413,6 +419,7 @@ __device__ __forceinline__ void sk_run(const StockStage& st, const SkArgs<T>& a)
         default:
             if constexpr (sizeof(T) == 4) {  // double stops at radix 12 (register budget)
                 if (st.R == 15) sk_stage<T, 15, SRC, DST>(st, a);
+                else if (st.R == 24) sk_stage<T, 24, SRC, DST>(st, a);
                 else if (st.R == 32) sk_stage<T, 32, SRC, DST>(st, a);
                 else sk_stage<T, 16, SRC, DST>(st, a);
             }
@@ -421,8 +428,12 @@ __device__ __forceinline__ void sk_run(const StockStage& st, const SkArgs<T>& a)
 }
 
 
-template <typename T, int DST>
+template <typename T, int DST, int RC = 0>
 __device__ __forceinline__ void sk_run_last_real(const StockStage& st, const SkArgs<T>& a) {
+    if constexpr (RC > 0) {
+        if constexpr (sizeof(T) == 4 || RC <= 12) sk_last_real<T, RC, DST>(st, a);
+        return;
+    }
     switch (st.R) {
         case 3: sk_last_real<T, 3, DST>(st, a); break;
         case 4: sk_last_real<T, 4, DST>(st, a); break;
@@ -439,8 +450,12 @@ __device__ __forceinline__ void sk_run_last_real(const StockStage& st, const SkA
             break;
     }
 }
-template <typename T, int SRC>
+template <typename T, int SRC, int RC = 0>
 __device__ __forceinline__ void sk_run_first_real(const StockStage& st, const SkArgs<T>& a) {
+    if constexpr (RC > 0) {
+        if constexpr (sizeof(T) == 4 || RC <= 12) sk_first_real<T, RC, SRC>(st, a);
+        return;
+    }
     switch (st.R) {
         case 3: sk_first_real<T, 3, SRC>(st, a); break;
         case 4: sk_first_real<T, 4, SRC>(st, a); break;
@@ -476,7 +491,14 @@ template <typename T> struct SkCtx {
     const cx<T>* twrg;
 };
 
-template <typename T, bool WL>
+template <int I> struct SkIdx { static constexpr int value = I; };
+// radix of stage S of a compile-time plan (-1: the plan has no such stage); 0 for a run-time plan (PT = void)
+template <class PT, int S> constexpr int sk_ct_radix() {
+    if constexpr (std::is_void<PT>::value) return 0;
+    else return S < PT::value.ns ? PT::value.st[S].R : -1;
+}
+
+template <typename T, bool WL, class PT = void>
 __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStage& st0, const StockStage& st1,
                                              const StockStage& st2, const StockStage& st3, const SkCtx<T>& c,
                                              int wtid, int wn, int slot0, int cnt, int maxcnt, cx<T>* gout, int& w) {
@@ -541,31 +563,43 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
         a.cj_out = bwd;
         a.twrg = c.twrg; a.twr_off = c.twr_off; a.twr_lds = c.twr_lds; a.sym_items = p.sym_items; a.m_sym = p.m_sym;
         a.cnt = cnt; a.maxcnt = maxcnt;
-#pragma unroll
-        for (int s = 0; s < SK_MAX_STAGES; ++s) {
-            if (s < ns) {
-                const StockStage& st = s == 0 ? st0 : s == 1 ? st1 : s == 2 ? st2 : st3;
-                a.total = cnt * st.nb; a.maxtotal = maxcnt * st.nb;
-                a.src_off = (w ^ 1) * bufsz; a.dst_off = w * bufsz;
-                a.cj_in = (s == 0) && bwd && !real;   // real backward: the pair pass / symmetric first stage conjugates
-                if (s < ns - 1) {
-                    if (s == 0 && real && bwd && p.sym) {   // half-complex spectrum -> first butterflies, pairs in registers
-                        if (in_int) sk_run_first_real<T, SK_I>(st, a); else sk_run_first_real<T, SK_L>(st, a);
+        // RC: the stage's radix where the plan is a compile-time constant (one instantiation per stage instead of one per
+        // radix: with radices 20 / 24 / 25 the run-time dispatch outgrew the unroller's budget), 0 = run-time dispatch
+        auto stage = [&](auto RCt, int s) __attribute__((always_inline)) {
+            constexpr int RC = decltype(RCt)::value;
+            if constexpr (RC >= 0) {
+                if (s < ns) {
+                    const StockStage& st = s == 0 ? st0 : s == 1 ? st1 : s == 2 ? st2 : st3;
+                    a.total = cnt * st.nb; a.maxtotal = maxcnt * st.nb;
+                    a.src_off = (w ^ 1) * bufsz; a.dst_off = w * bufsz;
+                    a.cj_in = (s == 0) && bwd && !real;   // real backward: the pair pass / symmetric first stage conjugates
+                    if (s < ns - 1) {
+                        if (s == 0 && real && bwd && p.sym) {   // half-complex spectrum -> first butterflies, pairs in registers
+                            if (in_int) sk_run_first_real<T, SK_I, RC>(st, a); else sk_run_first_real<T, SK_L, RC>(st, a);
+                        }
+                        else if (s == 0 && in_int && !real) sk_run<T, SK_I, SK_L, RC>(st, a);
+                        else sk_run<T, SK_L, SK_L, RC>(st, a);
+                        w ^= 1;
+                        sk_sync<WL>();
+                    } else if (real && !bwd && p.sym) {    // last butterflies -> half-complex spectrum, pairs in registers
+                        if (out_int) { sk_run_last_real<T, SK_I, RC>(st, a); w ^= 1; sk_sync<WL>(); }
+                        else sk_run_last_real<T, SK_G, RC>(st, a);
+                    } else if (real && !bwd) {             // natural image for the pair phase below
+                        sk_run<T, SK_L, SK_L, RC>(st, a); w ^= 1; sk_sync<WL>();
+                    } else {
+                        if (out_int) { sk_run<T, SK_L, SK_I, RC>(st, a); w ^= 1; sk_sync<WL>(); }
+                        else sk_run<T, SK_L, SK_G, RC>(st, a);
                     }
-                    else if (s == 0 && in_int && !real) sk_run<T, SK_I, SK_L>(st, a);
-                    else sk_run<T, SK_L, SK_L>(st, a);
-                    w ^= 1;
-                    sk_sync<WL>();
-                } else if (real && !bwd && p.sym) {    // last butterflies -> half-complex spectrum, pairs in registers
-                    if (out_int) { sk_run_last_real<T, SK_I>(st, a); w ^= 1; sk_sync<WL>(); }
-                    else sk_run_last_real<T, SK_G>(st, a);
-                } else if (real && !bwd) {             // natural image for the pair phase below
-                    sk_run<T, SK_L, SK_L>(st, a); w ^= 1; sk_sync<WL>();
-                } else {
-                    if (out_int) { sk_run<T, SK_L, SK_I>(st, a); w ^= 1; sk_sync<WL>(); }
-                    else sk_run<T, SK_L, SK_G>(st, a);
                 }
             }
+        };
+        static_assert(SK_MAX_STAGES == 4, "one call per stage below");
+        if constexpr (std::is_void<PT>::value) {
+#pragma unroll
+            for (int s = 0; s < SK_MAX_STAGES; ++s) stage(SkIdx<0>{}, s);
+        } else {
+            stage(SkIdx<sk_ct_radix<PT, 0>()>{}, 0); stage(SkIdx<sk_ct_radix<PT, 1>()>{}, 1);
+            stage(SkIdx<sk_ct_radix<PT, 2>()>{}, 2); stage(SkIdx<sk_ct_radix<PT, 3>()>{}, 3);
         }
     }
     // ---- real forward: packed spectrum Z (natural image) -> half-complex spectrum X:
@@ -681,7 +715,7 @@ template <typename T> __device__ __forceinline__ int sk_chunk_off(int g, int cc,
 //
 // Workgroup-phase kernel: C compute threads share every stage of the G vectors of a group; P producer wavefronts
 // hold the next group in registers across the iteration's barriers.
-template <typename T>
+template <typename T, class PT = void>
 __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, const StockPlan& p, int flags,
                                            const cx<T>* __restrict__ twg, const cx<T>* __restrict__ twrg, unsigned* ctr,
                                            unsigned kchunk) {
@@ -723,7 +757,7 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
 
     if (tid >= C) {
         // ======================================================================= producer wavefronts
-        const int pl = tid - C, PT = 64 * p.P;
+        const int pl = tid - C, NPT = 64 * p.P;
         const chunk16* s16 = reinterpret_cast<const chunk16*>(in);
         chunk16 raw[SK_NCHP];
         // unconditional loads (a predicated load costs a branch and pins its address): chunks beyond the
@@ -735,7 +769,7 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
             const chunk16* s = cnt ? s16 + t0 * nchk : s16;
 #pragma unroll
             for (int i = 0; i < SK_NCHP; ++i) {
-                const int cix = pl + PT * i;
+                const int cix = pl + NPT * i;
                 raw[i] = __builtin_nontemporal_load(s + (cix < lastc ? cix : lastc));
             }
         };
@@ -744,7 +778,7 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
             const int tot = G * nchk;  // chunks beyond the group's vectors hold stale values nobody reads
 #pragma unroll
             for (int i = 0; i < SK_NCHP; ++i) {
-                const int cix = pl + PT * i;
+                const int cix = pl + NPT * i;
                 if (cix < tot) {
                     const int g = udiv(cix, p.m_nchk), cc = cix - g * nchk;
                     d16[sk_chunk_off<T>(g, cc, img16, c.in_int, p.ibs)] = raw[i];
@@ -778,7 +812,7 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
         sch.top(false);
         const int g_here = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);
         CX* gout = reinterpret_cast<CX*>(out) + t0 * n;
-        sk_iteration<T, false>(p, st0, st1, st2, st3, c, tid, C, 0, g_here, G, gout, w);
+        sk_iteration<T, false, PT>(p, st0, st1, st2, st3, c, tid, C, 0, g_here, G, gout, w);
         // ---- closing barrier: the producers have deposited the next group into image w
         w ^= 1;
         __syncthreads();
@@ -792,7 +826,7 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
 // per lane.  One __syncthreads per iteration hands the next group index over.
 constexpr int SK_NCHW = 8;
 constexpr int SK_WL_WAVES = 4;  // wavefronts per workgroup of the wave-local kernel
-template <typename T>
+template <typename T, class PT = void>
 __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, const StockPlan& p, int flags,
                                            const cx<T>* __restrict__ twg, const cx<T>* __restrict__ twrg, unsigned* ctr,
                                            unsigned kchunk) {
@@ -868,7 +902,7 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
         issue(sch.gnx);
         const int cnt = mine(sch.gcur);
         CX* gout = reinterpret_cast<CX*>(out) + (size_t)sch.gcur * G * n;
-        sk_iteration<T, true>(p, st0, st1, st2, st3, c, lane, 64, slot0, cnt, Gw, gout, w);
+        sk_iteration<T, true, PT>(p, st0, st1, st2, st3, c, lane, 64, slot0, cnt, Gw, gout, w);
         sk_sync<true>();          // the last phase's LDS reads are done before ...
         deposit(w * c.bufsz);     // ... the next group lands in the free image
         w ^= 1;
@@ -916,7 +950,7 @@ __global__ void __launch_bounds__(256, sk_waves_per_simd<T>(PT::value, 256, SkWp
 fft_stock_wl_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
                        const cx<T>* __restrict__ twrg, unsigned* ctr, unsigned kchunk) {
     constexpr StockPlan p = PT::value;
-    sk_wl_body<T>(in, out, batch, p, FLAGS, twg, twrg, ctr, kchunk);
+    sk_wl_body<T, PT>(in, out, batch, p, FLAGS, twg, twrg, ctr, kchunk);
 }
 
 template <typename T, class PT, int FLAGS>
@@ -924,7 +958,7 @@ __global__ void __launch_bounds__(PT::value.C + 64 * PT::value.P, sk_waves_per_s
 fft_stock_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
                     const cx<T>* __restrict__ twrg, unsigned* ctr, unsigned kchunk) {
     constexpr StockPlan p = PT::value;
-    sk_wg_body<T>(in, out, batch, p, FLAGS, twg, twrg, ctr, kchunk);
+    sk_wg_body<T, PT>(in, out, batch, p, FLAGS, twg, twrg, ctr, kchunk);
 }
 
 }  // namespace pf

@@ -134,6 +134,18 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
     static const std::vector<int> setd = {12, 10, 8, 6, 5, 4, 3};
     std::vector<int> cur, best;
     sk_search(n, 0, is_double ? setd : setf, cur, best);
+    if (!is_double && (size_t)n * esz > 4096 && !(real && (size_t)n * esz >= 64 * 1024)) {
+        // radix 24 (8 x 3, 48 registers per butterfly) where it saves a whole stage, i.e. one LDS exchange, in the workgroup
+        // kernel: n = 576 -> 24 24 (complex float 0.64 -> 0.72, real N = 1152 0.49 -> 0.60), n = 9216 -> 24 16 24 (0.53 -> 0.58,
+        // ordered 0.61 -> 0.66).  Measured and NOT adopted: the wave-local kernel (n <= 512: 288 .. 480 fell from 0.66-0.76 to
+        // 0.49-0.61 with 16 x 24 / 20 x 24 plans - it lives on resident wavefronts, not on short phases), radices 20 and 25
+        // (n = 2000 / 4000 / 6000 as 10 10 20 / 20 10 20 / 20 15 20: -0.02 .. +0.01), n = 4608 as 16 12 24 (+0.006 complex,
+        // -0.011 real), n = 768 as 24 32 (complex -0.01 .. +0.02, real N = 1536 -0.04), and the two-butterfly symmetric stage of the largest real transforms (register budget).
+        static const std::vector<int> setf24 = {24, 16, 15, 12, 10, 8, 6, 5, 4, 3};
+        std::vector<int> cur2, best2;
+        sk_search(n, 0, setf24, cur2, best2);
+        if (!best2.empty() && best2.size() < best.size() && (best2.size() == 2 || n >= 8192)) best = best2;
+    }
     if (!is_double && !real && n >= 8192 && best.size() > 3) {
         // radix 32 (64 registers per butterfly) where it saves a whole stage: n = 8192 -> 16 16 32 (complex float
         // 0.64-0.68 -> 0.69-0.72).  Not for real transforms: next to the two-butterfly symmetric stage it spills
