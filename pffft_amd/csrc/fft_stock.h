@@ -498,7 +498,8 @@ template <class PT, int S> constexpr int sk_ct_radix() {
     else return S < PT::value.ns ? PT::value.st[S].R : -1;
 }
 
-template <typename T, bool WL, class PT = void>
+// DF: the first stage ran outside (operands straight from HBM, sk_*_df_body) and its results sit in image w ^ 1
+template <typename T, bool WL, class PT = void, bool DF = false>
 __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStage& st0, const StockStage& st1,
                                              const StockStage& st2, const StockStage& st3, const SkCtx<T>& c,
                                              int wtid, int wn, int slot0, int cnt, int maxcnt, cx<T>* gout, int& w) {
@@ -598,7 +599,8 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
 #pragma unroll
             for (int s = 0; s < SK_MAX_STAGES; ++s) stage(SkIdx<0>{}, s);
         } else {
-            stage(SkIdx<sk_ct_radix<PT, 0>()>{}, 0); stage(SkIdx<sk_ct_radix<PT, 1>()>{}, 1);
+            if constexpr (!DF) stage(SkIdx<sk_ct_radix<PT, 0>()>{}, 0);
+            stage(SkIdx<sk_ct_radix<PT, 1>()>{}, 1);
             stage(SkIdx<sk_ct_radix<PT, 2>()>{}, 2); stage(SkIdx<sk_ct_radix<PT, 3>()>{}, 3);
         }
     }
@@ -914,6 +916,101 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
     sch.finish(tid == 0);
 }
 
+
+// ---- "direct first stage" variants (compile-time plans, natural-layout input, not the real backward transform):
+// every work item of the FIRST stage loads its R operands straight from HBM into registers - one group ahead, the loads
+// fly during the remaining phases - and the first stage runs from those registers.  Against the bodies above this saves
+// the producer wavefronts, the deposit into LDS, the first stage's LDS reads and two of the workgroup barriers per
+// iteration (deposit hand-over and closing barrier: the next first stage writes the image the last phase does not read).
+// Consecutive work items read consecutive points (one 8 / 16-byte load per lane, 512 / 1024 contiguous bytes per
+// wavefront and operand as long as n / R >= 64).  Static group assignment only.
+template <typename T, class PT, bool WL>
+__device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, int flags, const cx<T>* __restrict__ twg,
+                                           const cx<T>* __restrict__ twrg) {
+    typedef cx<T> CX;
+    constexpr StockPlan p = PT::value;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr StockLds<T> L = stock_lds<T>(p);
+    SkCtx<T> c;
+    c.lds = reinterpret_cast<CX*>(smem_raw);
+    CX* const lds = c.lds;
+    c.bufsz = p.G * p.img;
+    c.tab_off = (int)(L.tab / sizeof(CX)); c.twr_off = (int)(L.twr / sizeof(CX));
+    c.in_int = false; c.out_int = flags & 2; c.bwd = flags & 4; c.real = flags & 8;
+    c.twg = twg; c.twrg = twrg;
+    c.twr_lds = p.twr_lds && c.real;
+    constexpr int n = p.n, G = p.G, R0 = p.st[0].R, nb0 = p.st[0].nb, wblk0 = p.st[0].wblk;
+    constexpr int NT = WL ? 64 * SK_WL_WAVES : p.C;        // threads of the workgroup
+    constexpr int W = WL ? 64 : p.C;                       // threads of one worker (a wavefront / the workgroup)
+    constexpr int GV = WL ? G / SK_WL_WAVES : G;           // vectors per worker and group
+    constexpr int ROUNDS = (GV * nb0 + W - 1) / W;
+    const int tid = threadIdx.x;
+    const int wtid = WL ? (tid & 63) : tid;
+    const int slot0 = WL ? (tid >> 6) * GV : 0;
+    if (p.twmode == 0)
+        for (int i = tid; i < n; i += NT) lds[c.tab_off + tpad(i)] = twg[i];
+    if (p.twmode == 2)
+        for (int i = tid; i < p.ctab; i += NT) lds[c.tab_off + i] = twg[i];
+    if (c.twr_lds)
+        for (int i = tid; i <= n / 2; i += NT) lds[c.twr_off + i] = twrg[i];
+    const StockStage st0 = p.st[0], st1 = p.st[1], st2 = p.st[2], st3 = p.st[3];
+    const CX* gin = reinterpret_cast<const CX*>(in);
+    const bool cj = c.bwd && !c.real;
+
+    CX pre[ROUNDS][R0];
+    // this worker's vectors of group grp
+    auto mine = [&](size_t grp) -> int {
+        const size_t t0 = grp * G + slot0;
+        return t0 < batch ? (int)((batch - t0) < (size_t)GV ? (batch - t0) : (size_t)GV) : 0;
+    };
+    // unconditional loads: work items beyond the group's vectors re-read operand 0 of its first vector, groups beyond
+    // the batch the first vector of the input
+    auto issue = [&](size_t grp) {
+        const int cnt = mine(grp);
+        const CX* base = cnt ? gin + (grp * G + slot0) * n : gin;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int i = wtid + r * W;
+            const int ii = i < cnt * nb0 ? i : 0;
+            const int g = ii / nb0, j = ii - g * nb0;
+            const CX* src = base + g * n + j;
+#pragma unroll
+            for (int q = 0; q < R0; ++q) pre[r][q] = __builtin_nontemporal_load(src + q * nb0);
+        }
+    };
+    auto stage0 = [&](int cnt, int w) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int i = wtid + r * W;
+            if (i < cnt * nb0) {
+                const int g = i / nb0, j = i - g * nb0;
+                CX v[R0];
+#pragma unroll
+                for (int q = 0; q < R0; ++q) { v[q] = pre[r][q]; if (cj) v[q].y = -v[q].y; }
+                dftR<R0, FWD>(v);
+                CX* pd = lds + w * c.bufsz + (slot0 + g) * p.img + j * wblk0;
+#pragma unroll
+                for (int d = 0; d < R0; ++d) pd[d] = v[d];
+            }
+        }
+    };
+    size_t gcur = blockIdx.x;
+    const size_t gstep = gridDim.x;
+    int w = 0;
+    issue(gcur);
+    __syncthreads();   // tables
+    while (gcur * G < batch) {
+        const int cnt = mine(gcur);
+        CX* gout = reinterpret_cast<CX*>(out) + gcur * G * n;
+        stage0(cnt, w);
+        issue(gcur + gstep);
+        w ^= 1;
+        sk_sync<WL>();
+        sk_iteration<T, WL, PT, true>(p, st0, st1, st2, st3, c, wtid, W, slot0, cnt, GV, gout, w);
+        gcur += gstep;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(1024)
 fft_stock_kernel(const T* in, T* out, size_t batch, StockPlan p, int flags, const cx<T>* __restrict__ twg,
@@ -959,6 +1056,21 @@ fft_stock_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__
                     const cx<T>* __restrict__ twrg, unsigned* ctr, unsigned kchunk) {
     constexpr StockPlan p = PT::value;
     sk_wg_body<T, PT>(in, out, batch, p, FLAGS, twg, twrg, ctr, kchunk);
+}
+
+// direct-first-stage variants: FLAGS carries bit 4 (16) so that the occupancy overrides of stock_wpe_gen.h tell them apart
+template <typename T, class PT, int FLAGS>
+__global__ void __launch_bounds__(256, sk_waves_per_simd<T>(PT::value, 256, SkWpeCap<PT, FLAGS>::v))
+fft_stock_wl_df_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
+                          const cx<T>* __restrict__ twrg, unsigned*, unsigned) {
+    sk_df_body<T, PT, true>(in, out, batch, FLAGS & 15, twg, twrg);
+}
+
+template <typename T, class PT, int FLAGS>
+__global__ void __launch_bounds__(PT::value.C, sk_waves_per_simd<T>(PT::value, PT::value.C, SkWpeCap<PT, FLAGS>::v))
+fft_stock_df_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
+                       const cx<T>* __restrict__ twrg, unsigned*, unsigned) {
+    sk_df_body<T, PT, false>(in, out, batch, FLAGS & 15, twg, twrg);
 }
 
 }  // namespace pf

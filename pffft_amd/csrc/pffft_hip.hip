@@ -23,6 +23,7 @@
 #include "fft_stock.h"
 #include "stock_plan.h"
 #include "stock_ct.h"
+#include "stock_df_gen.h"
 #include "fft_aux.h"
 #include "fft_tiny.h"
 #include "pfdsp_mix.h"
@@ -598,8 +599,19 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
     // the same kernel body instantiated on this very plan as a compile-time constant, when there is one
     // (stock_plans_gen.h; variant 53 = always the run-time plan, A/B)
     {
-        auto cf = g_variant != 53 ? stock_ct_lookup(sp, flags, wl, (const T*)nullptr) : nullptr;
+        // direct-first-stage variant of the same plan (fft_stock.h sk_df_body) for natural-layout input
+        // (PFFFT_HIP_STOCK_DF=0/1 forces it off / on wherever it exists, A/B)
+        // adopted per plan from a measured table (stock_df_gen.h, written by tools/tune_stock_df.py on the GPU);
+        // variants 54 / 55 force it on / off at run time for that measurement
+        static const int df_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_DF"); return e ? atoi(e) : -1; }();
+        const bool df_ok = !(flags & 1) && !((flags & 8) && bwd) && g_variant != 53;
+        const bool want_df = df_ok && (g_variant == 54 ? true : g_variant == 55 ? false : df_env >= 0 ? df_env != 0
+                                       : stock_df_adopted(sizeof(T) == 8, (flags & 8) != 0, sp.n, (flags & 2) != 0, bwd));
+        auto cf = want_df ? stock_ct_lookup(sp, flags | 16, wl, (const T*)nullptr) : nullptr;
+        const bool df = cf != nullptr;
+        if (!cf && g_variant != 53) cf = stock_ct_lookup(sp, flags, wl, (const T*)nullptr);
         if (cf) {
+            const int threads = df ? (wl ? 256 : sp.C) : (wl ? s->skw_threads : s->sk_threads);
             int rc = allow_big_lds(cf, lds);
             if (rc) return rc;
             int per_cu = 0;

@@ -8,7 +8,7 @@ import threading
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import relerr, tol_for
 
 pytestmark = pytest.mark.gpu
 
@@ -378,6 +378,43 @@ def test_split_kernel_c3_against_reference(ref):
             assert relerr(yo[idx].cpu().numpy(), rs.batch(xh, 0, True)) <= 1e-5, B
             assert torch.equal(z, yu)
             assert torch.equal(s.zreorder_batch(yu, None, pa.FORWARD), yo)
+    finally:
+        pa.set_variant(0)
+    s.close(); rs.close()
+
+
+# ------------------------------------------------------------------ Stockham kernels, direct first stage (fft_stock.h sk_df_body)
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("tr,N", [(pa.COMPLEX, 96), (pa.COMPLEX, 288), (pa.COMPLEX, 640), (pa.COMPLEX, 960), (pa.COMPLEX, 2592),
+                                  (pa.COMPLEX, 9216), (pa.REAL, 96), (pa.REAL, 576), (pa.REAL, 1280), (pa.REAL, 1920),
+                                  (pa.REAL, 4800), (pa.REAL, 12000)])
+def test_stockham_direct_first_stage(ref, dt, tr, N):
+    """The direct-first-stage variant of every compile-time Stockham plan (first-stage operands straight from HBM into
+    registers, no producer wavefronts / deposit) is adopted per plan from a measured table (stock_df_gen.h); variants 54 / 55
+    force it on / off.  Both must meet the parity bar on ragged batches and in place, and - same butterflies on the same
+    operands - agree bit for bit."""
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    tol = tol_for("f32" if dt == np.float32 else "f64", N)   # (the reference's double build: radix-3/5 constants in float)
+    s = pa.Setup(N, tr, dt)
+    rs = ref.setup(N, tr, dt)
+    try:
+        for B in (1, 3, 7, 1031):
+            x = _uniform((B, s.vec_scalars), 400 + B, tdt)
+            idx = sorted({0, B // 2, B - 1})
+            xh = x[idx].cpu().numpy()
+            modes = [(pa.FORWARD, False), (pa.FORWARD, True)] + ([(pa.BACKWARD, True)] if tr == pa.COMPLEX else [])
+            for d, o in modes:
+                pa.set_variant(54)
+                y = s.transform_batch(x, None, d, o)
+                z = x.clone(); s.transform_batch(z, z, d, o)
+                pa.set_variant(55)
+                y0 = s.transform_batch(x, None, d, o)
+                pa.set_variant(0)
+                yd = s.transform_batch(x, None, d, o)
+                assert relerr(y[idx].cpu().numpy(), rs.batch(xh, d, o)) <= tol, (B, d, o)
+                assert torch.equal(z, y), (B, d, o)
+                assert torch.equal(y0, y), (B, d, o)
+                assert torch.equal(yd, y), (B, d, o)
     finally:
         pa.set_variant(0)
     s.close(); rs.close()
