@@ -498,8 +498,9 @@ template <class PT, int S> constexpr int sk_ct_radix() {
     else return S < PT::value.ns ? PT::value.st[S].R : -1;
 }
 
-// DF: the first stage ran outside (operands straight from HBM, sk_*_df_body) and its results sit in image w ^ 1
-template <typename T, bool WL, class PT = void, bool DF = false>
+// DF = 1: the first stage ran outside (operands straight from HBM, sk_df_body) and its results sit in image w ^ 1;
+// DF = 2: the pair pass of the real backward transform ran outside, the packed spectrum sits in image w ^ 1
+template <typename T, bool WL, class PT = void, int DF = 0>
 __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStage& st0, const StockStage& st1,
                                              const StockStage& st2, const StockStage& st3, const SkCtx<T>& c,
                                              int wtid, int wn, int slot0, int cnt, int maxcnt, cx<T>* gout, int& w) {
@@ -517,7 +518,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
     // ---- real backward: half-complex spectrum X -> conj of the packed spectrum Z' (the stages then run
     //      a forward transform; the final conjugation happens on the store):
     //      Z'[k] = S + D, Z'[n-k] = conj(S - D), S = A + B, D = i conj(W_N^k) (A - B), A = X[k], B = conj X[n-k]
-    if (real && bwd && !p.sym) {
+    if (DF != 2 && real && bwd && !p.sym) {
 #pragma unroll
         for (int id0 = 0; id0 < maxcnt * per; id0 += wn) {
             const int id = id0 + wtid;
@@ -599,7 +600,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
 #pragma unroll
             for (int s = 0; s < SK_MAX_STAGES; ++s) stage(SkIdx<0>{}, s);
         } else {
-            if constexpr (!DF) stage(SkIdx<sk_ct_radix<PT, 0>()>{}, 0);
+            if constexpr (DF != 1) stage(SkIdx<sk_ct_radix<PT, 0>()>{}, 0);
             stage(SkIdx<sk_ct_radix<PT, 1>()>{}, 1);
             stage(SkIdx<sk_ct_radix<PT, 2>()>{}, 2); stage(SkIdx<sk_ct_radix<PT, 3>()>{}, 3);
         }
@@ -922,6 +923,7 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
 // fly during the remaining phases - and the first stage runs from those registers.  Against the bodies above this saves
 // the producer wavefronts, the deposit into LDS, the first stage's LDS reads and two of the workgroup barriers per
 // iteration (deposit hand-over and closing barrier: the next first stage writes the image the last phase does not read).
+// The real backward transform (canonical input) does the same with its pair pass, which is its first phase.
 // Consecutive work items read consecutive points (one 8 / 16-byte load per lane, 512 / 1024 contiguous bytes per
 // wavefront and operand as long as n / R >= 64).  Static group assignment only.
 template <typename T, class PT, bool WL>
@@ -957,12 +959,72 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, in
     const CX* gin = reinterpret_cast<const CX*>(in);
     const bool cj = c.bwd && !c.real;
 
-    CX pre[ROUNDS][R0];
     // this worker's vectors of group grp
     auto mine = [&](size_t grp) -> int {
         const size_t t0 = grp * G + slot0;
         return t0 < batch ? (int)((batch - t0) < (size_t)GV ? (batch - t0) : (size_t)GV) : 0;
     };
+    size_t gcur = blockIdx.x;
+    const size_t gstep = gridDim.x;
+    int w = 0;
+    if (c.real && c.bwd) {
+        // ---- real backward, canonical half-complex input: the work items of the PAIR pass load X[k] and X[n-k] straight from
+        // HBM (ascending / descending runs) one group ahead; the pass writes the packed spectrum into image w, all stages follow
+        constexpr int per = n / 2 + 1, half = n / 2;
+        constexpr int RP = (GV * per + W - 1) / W;
+        CX pa[RP], pb[RP];
+        auto issue = [&](size_t grp) {
+            const int cnt = mine(grp);
+            const CX* base = cnt ? gin + (grp * G + slot0) * n : gin;
+#pragma unroll
+            for (int r = 0; r < RP; ++r) {
+                const int i = wtid + r * W;
+                const int ii = i < cnt * per ? i : 0;
+                const int g = ii / per, k = ii - g * per;
+                pa[r] = __builtin_nontemporal_load(base + g * n + k);
+                pb[r] = __builtin_nontemporal_load(base + g * n + (k ? n - k : 0));
+            }
+        };
+        auto pairs = [&](int cnt, int w) {
+#pragma unroll
+            for (int r = 0; r < RP; ++r) {
+                const int i = wtid + r * W;
+                if (i < cnt * per) {
+                    const int g = i / per, k = i - g * per;
+                    const CX A = pa[r];
+                    CX* pd = lds + w * c.bufsz + (slot0 + g) * p.img;
+                    if (k == 0) {
+                        pd[0] = mk<T>(A.x + A.y, -(A.x - A.y));
+                    } else if (k == half) {
+                        pd[half] = mk<T>((T)2 * A.x, (T)2 * A.y);
+                    } else {
+                        const CX B = conj(pb[r]);
+                        CX wk;
+                        if (c.twr_lds) wk = lds[c.twr_off + k];
+                        else { wk = twrg[k]; asm volatile(""); }
+                        const CX S = A + B, Dm = cmulc(A - B, wk);
+                        const CX D = mk<T>(-Dm.y, Dm.x);
+                        pd[k] = conj(S + D);
+                        pd[n - k] = S - D;
+                    }
+                }
+            }
+        };
+        issue(gcur);
+        __syncthreads();   // tables
+        while (gcur * G < batch) {
+            const int cnt = mine(gcur);
+            CX* gout = reinterpret_cast<CX*>(out) + gcur * G * n;
+            pairs(cnt, w);
+            issue(gcur + gstep);
+            w ^= 1;
+            sk_sync<WL>();
+            sk_iteration<T, WL, PT, 2>(p, st0, st1, st2, st3, c, wtid, W, slot0, cnt, GV, gout, w);
+            gcur += gstep;
+        }
+        return;
+    }
+    CX pre[ROUNDS][R0];
     // unconditional loads: work items beyond the group's vectors re-read operand 0 of its first vector, groups beyond
     // the batch the first vector of the input
     auto issue = [&](size_t grp) {
@@ -994,9 +1056,6 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, in
             }
         }
     };
-    size_t gcur = blockIdx.x;
-    const size_t gstep = gridDim.x;
-    int w = 0;
     issue(gcur);
     __syncthreads();   // tables
     while (gcur * G < batch) {
@@ -1006,7 +1065,7 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, in
         issue(gcur + gstep);
         w ^= 1;
         sk_sync<WL>();
-        sk_iteration<T, WL, PT, true>(p, st0, st1, st2, st3, c, wtid, W, slot0, cnt, GV, gout, w);
+        sk_iteration<T, WL, PT, 1>(p, st0, st1, st2, st3, c, wtid, W, slot0, cnt, GV, gout, w);
         gcur += gstep;
     }
 }

@@ -604,7 +604,7 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
         // adopted per plan from a measured table (stock_df_gen.h, written by tools/tune_stock_df.py on the GPU);
         // variants 54 / 55 force it on / off at run time for that measurement
         static const int df_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_DF"); return e ? atoi(e) : -1; }();
-        const bool df_ok = !(flags & 1) && !((flags & 8) && bwd) && g_variant != 53;
+        const bool df_ok = !(flags & 1) && g_variant != 53;
         const bool want_df = df_ok && (g_variant == 54 ? true : g_variant == 55 ? false : df_env >= 0 ? df_env != 0
                                        : stock_df_adopted(sizeof(T) == 8, (flags & 8) != 0, sp.n, (flags & 2) != 0, bwd));
         auto cf = want_df ? stock_ct_lookup(sp, flags | 16, wl, (const T*)nullptr) : nullptr;

@@ -402,7 +402,7 @@ def test_stockham_direct_first_stage(ref, dt, tr, N):
             x = _uniform((B, s.vec_scalars), 400 + B, tdt)
             idx = sorted({0, B // 2, B - 1})
             xh = x[idx].cpu().numpy()
-            modes = [(pa.FORWARD, False), (pa.FORWARD, True)] + ([(pa.BACKWARD, True)] if tr == pa.COMPLEX else [])
+            modes = [(pa.FORWARD, False), (pa.FORWARD, True), (pa.BACKWARD, True)]
             for d, o in modes:
                 pa.set_variant(54)
                 y = s.transform_batch(x, None, d, o)
