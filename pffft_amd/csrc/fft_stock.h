@@ -503,10 +503,14 @@ template <class PT, int S> constexpr int sk_ct_radix() {
 template <typename T, bool WL, class PT = void, int DF = 0>
 __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStage& st0, const StockStage& st1,
                                              const StockStage& st2, const StockStage& st3, const SkCtx<T>& c,
-                                             int wtid, int wn, int slot0, int cnt, int maxcnt, cx<T>* gout, int& w) {
+                                             int wtid, int wn, int slot0, int cnt, int maxcnt, cx<T>* gout, int& w,
+                                             int stid = -1, int sn = 0) {
     typedef cx<T> CX;
     typedef vec4<float> chunk16;
     constexpr int CH = 16 / (int)sizeof(T), CPB = 32 / CH;
+    // worker index / count of the phases that STORE TO HBM (sk_df_body: the wavefronts that hold prefetched loads never
+    // store, so their s_waitcnt vmcnt for the loads does not wait for store acknowledgements); default: all of them
+    if (sn == 0) { stid = wtid; sn = wn; }
     const int BCH = p.ibs / CH;
     CX* const lds = c.lds;
     const int n = p.n, ns = p.ns, bufsz = c.bufsz;
@@ -585,12 +589,12 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
                         sk_sync<WL>();
                     } else if (real && !bwd && p.sym) {    // last butterflies -> half-complex spectrum, pairs in registers
                         if (out_int) { sk_run_last_real<T, SK_I, RC>(st, a); w ^= 1; sk_sync<WL>(); }
-                        else sk_run_last_real<T, SK_G, RC>(st, a);
+                        else { a.tid = stid; a.nthr = sn; sk_run_last_real<T, SK_G, RC>(st, a); a.tid = wtid; a.nthr = wn; }
                     } else if (real && !bwd) {             // natural image for the pair phase below
                         sk_run<T, SK_L, SK_L, RC>(st, a); w ^= 1; sk_sync<WL>();
                     } else {
                         if (out_int) { sk_run<T, SK_L, SK_I, RC>(st, a); w ^= 1; sk_sync<WL>(); }
-                        else sk_run<T, SK_L, SK_G, RC>(st, a);
+                        else { a.tid = stid; a.nthr = sn; sk_run<T, SK_L, SK_G, RC>(st, a); a.tid = wtid; a.nthr = wn; }
                     }
                 }
             }
@@ -608,9 +612,10 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
     // ---- real forward: packed spectrum Z (natural image) -> half-complex spectrum X:
     //      X[k] = S + D, X[n-k] = conj(S - D), S = (A+B)/2, D = -(i/2) W_N^k (A-B), A = Z[k], B = conj Z[n-k]
     if (real && !bwd && !p.sym) {
+        const int ptid = out_int ? wtid : stid, pn = out_int ? wn : sn;   // canonical output: this phase stores to HBM
 #pragma unroll
-        for (int id0 = 0; id0 < maxcnt * per; id0 += wn) {
-            const int id = id0 + wtid;
+        for (int id0 = 0; id0 < maxcnt * per; id0 += pn) {
+            const int id = id0 + ptid;
             if (id >= cnt * per) continue;
             const int gl = udiv(id, p.m_per), k = id - gl * per, g = slot0 + gl;
             const CX* ps = lds + (w ^ 1) * bufsz + g * p.img;
@@ -653,8 +658,8 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
         const chunk16* s16 = reinterpret_cast<const chunk16*>(lds + (w ^ 1) * bufsz);
         chunk16* d16 = reinterpret_cast<chunk16*>(gout);
 #pragma unroll
-        for (int cb = 0; cb < maxcnt * nchk; cb += wn) {
-            const int cc0 = cb + wtid;
+        for (int cb = 0; cb < maxcnt * nchk; cb += sn) {
+            const int cc0 = cb + stid;
             if (cc0 >= cnt * nchk) continue;
             const int gl = udiv(cc0, p.m_nchk), cc = cc0 - gl * nchk, g = slot0 + gl;
             __builtin_nontemporal_store(s16[g * img16 + (cc / CPB) * BCH + (cc % CPB)], d16 + (size_t)g * nchk + cc);
@@ -926,8 +931,25 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
 // The real backward transform (canonical input) does the same with its pair pass, which is its first phase.
 // Consecutive work items read consecutive points (one 8 / 16-byte load per lane, 512 / 1024 contiguous bytes per
 // wavefront and operand as long as n / R >= 64).  Static group assignment only.
-template <typename T, class PT, bool WL>
-__device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, int flags, const cx<T>* __restrict__ twg,
+// threads of the first stage that carry prefetched loads when the roles are split (0: not split): single-vector groups of
+// the workgroup kernel, one round, not the real backward transform (its pair pass loads on every wavefront)
+__host__ __device__ constexpr int sk_df_loaders(const StockPlan& p, int flags, bool wl) {
+    if (wl || p.G != 1 || ((flags & 8) && (flags & 4))) return 0;
+    const int s0 = (p.st[0].nb + 63) / 64 * 64;
+    return (s0 <= p.C && s0 + 128 <= 1024) ? s0 : 0;
+}
+// workgroup size of the direct-first-stage kernels
+__host__ __device__ constexpr int sk_df_threads(const StockPlan& p, int flags, bool wl) {
+    if (wl) return 64 * SK_WL_WAVES;
+    const int s0 = sk_df_loaders(p, flags, wl);
+    if (!s0) return p.C;
+    // loaders + as many storing threads as the last stage has butterflies (at least the plan's compute threads)
+    const int want = s0 + (p.st[p.ns - 1].nb + 63) / 64 * 64;
+    return want > 1024 ? 1024 : (want < p.C ? p.C : want);
+}
+
+template <typename T, class PT, bool WL, int flags>
+__device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
                                            const cx<T>* __restrict__ twrg) {
     typedef cx<T> CX;
     constexpr StockPlan p = PT::value;
@@ -942,10 +964,17 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, in
     c.twg = twg; c.twrg = twrg;
     c.twr_lds = p.twr_lds && c.real;
     constexpr int n = p.n, G = p.G, R0 = p.st[0].R, nb0 = p.st[0].nb, wblk0 = p.st[0].wblk;
-    constexpr int NT = WL ? 64 * SK_WL_WAVES : p.C;        // threads of the workgroup
-    constexpr int W = WL ? 64 : p.C;                       // threads of one worker (a wavefront / the workgroup)
+    constexpr int NT = sk_df_threads(p, flags, WL);         // threads of the workgroup
+    constexpr int W = WL ? 64 : NT;                        // threads of one worker (a wavefront / the workgroup)
     constexpr int GV = WL ? G / SK_WL_WAVES : G;           // vectors per worker and group
     constexpr int ROUNDS = (GV * nb0 + W - 1) / W;
+    // split roles (workgroup kernel, single-vector groups): the wavefronts of the first stage's work items - the ones with
+    // loads in flight - never store to HBM; every storing phase runs on the others.  Otherwise the compiler's s_waitcnt for
+    // the prefetched operands (stores are conditional, so it must assume none were issued: vmcnt(0)) waits for the previous
+    // iteration's store acknowledgements at the top of every iteration (n = 4000: 0.48 against 0.59 with producers).
+    constexpr int S0 = sk_df_loaders(p, flags, WL);
+    const int stid = S0 ? (threadIdx.x >= S0 ? (int)threadIdx.x - S0 : (1 << 28)) : -1;
+    const int sn = S0 ? NT - S0 : 0;
     const int tid = threadIdx.x;
     const int wtid = WL ? (tid & 63) : tid;
     const int slot0 = WL ? (tid >> 6) * GV : 0;
@@ -1019,7 +1048,7 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, in
             issue(gcur + gstep);
             w ^= 1;
             sk_sync<WL>();
-            sk_iteration<T, WL, PT, 2>(p, st0, st1, st2, st3, c, wtid, W, slot0, cnt, GV, gout, w);
+            sk_iteration<T, WL, PT, 2>(p, st0, st1, st2, st3, c, wtid, W, slot0, cnt, GV, gout, w, stid, sn);
             gcur += gstep;
         }
         return;
@@ -1028,6 +1057,7 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, in
     // unconditional loads: work items beyond the group's vectors re-read operand 0 of its first vector, groups beyond
     // the batch the first vector of the input
     auto issue = [&](size_t grp) {
+        if (S0 && (int)threadIdx.x >= S0) return;   // split roles: the storing wavefronts carry no loads
         const int cnt = mine(grp);
         const CX* base = cnt ? gin + (grp * G + slot0) * n : gin;
 #pragma unroll
@@ -1065,7 +1095,7 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, in
         issue(gcur + gstep);
         w ^= 1;
         sk_sync<WL>();
-        sk_iteration<T, WL, PT, 1>(p, st0, st1, st2, st3, c, wtid, W, slot0, cnt, GV, gout, w);
+        sk_iteration<T, WL, PT, 1>(p, st0, st1, st2, st3, c, wtid, W, slot0, cnt, GV, gout, w, stid, sn);
         gcur += gstep;
     }
 }
@@ -1122,14 +1152,15 @@ template <typename T, class PT, int FLAGS>
 __global__ void __launch_bounds__(256, sk_waves_per_simd<T>(PT::value, 256, SkWpeCap<PT, FLAGS>::v))
 fft_stock_wl_df_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
                           const cx<T>* __restrict__ twrg, unsigned*, unsigned) {
-    sk_df_body<T, PT, true>(in, out, batch, FLAGS & 15, twg, twrg);
+    sk_df_body<T, PT, true, (FLAGS & 15)>(in, out, batch, twg, twrg);
 }
 
 template <typename T, class PT, int FLAGS>
-__global__ void __launch_bounds__(PT::value.C, sk_waves_per_simd<T>(PT::value, PT::value.C, SkWpeCap<PT, FLAGS>::v))
+__global__ void __launch_bounds__(sk_df_threads(PT::value, FLAGS & 15, false),
+                                  sk_waves_per_simd<T>(PT::value, sk_df_threads(PT::value, FLAGS & 15, false), SkWpeCap<PT, FLAGS>::v))
 fft_stock_df_ct_kernel(const T* in, T* out, size_t batch, const cx<T>* __restrict__ twg,
                        const cx<T>* __restrict__ twrg, unsigned*, unsigned) {
-    sk_df_body<T, PT, false>(in, out, batch, FLAGS & 15, twg, twrg);
+    sk_df_body<T, PT, false, (FLAGS & 15)>(in, out, batch, twg, twrg);
 }
 
 }  // namespace pf

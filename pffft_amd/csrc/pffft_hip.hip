@@ -611,7 +611,7 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
         const bool df = cf != nullptr;
         if (!cf && g_variant != 53) cf = stock_ct_lookup(sp, flags, wl, (const T*)nullptr);
         if (cf) {
-            const int threads = df ? (wl ? 256 : sp.C) : (wl ? s->skw_threads : s->sk_threads);
+            const int threads = df ? sk_df_threads(sp, flags & 15, wl) : (wl ? s->skw_threads : s->sk_threads);
             int rc = allow_big_lds(cf, lds);
             if (rc) return rc;
             int per_cu = 0;
