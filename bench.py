@@ -280,6 +280,27 @@ def fft_config_run(torch, pa, dev, cfg, batch, steps, warmup, in_place, dist, ra
     return elapsed, kernel_s, kname, parity
 
 
+def nonpow2_sweep(torch, pa, dev, timer):
+    """The non-power-of-two sizes of the reference's benchmark list (benchmarks/bench_pffft.c:445) that VERDICT r01 named:
+    forward, unordered, float, 512 MiB of vectors per launch, 30 untimed + 30 timed launches; fraction of 8 TB/s on
+    2 x vector bytes.  Not a headline - a measured line per size for the mixed-radix (Stockham) kernel family."""
+    out = {"workload": "forward unordered float, 512 MiB per launch, roofline fraction per size"}
+    for tr, name, sizes in ((pa.COMPLEX, "complex", (96, 480, 800, 2400, 4000, 9216)), (pa.REAL, "real", (96, 480, 1600, 4000, 12000))):
+        row = {}
+        for N in sizes:
+            s = pa.Setup(N, tr, np.float32)
+            batch = (1 << 29) // (s.vec_scalars * 4)
+            x = make_input(torch, dev, batch, s.vec_scalars, torch.float32, seed=7)
+            y = torch.empty_like(x)
+            t = timer(lambda: s.transform_batch(x, y, pa.FORWARD, ordered=False), 30, warm=30)
+            row[str(N)] = round(2 * x.numel() * 4 / t / HBM_PEAK, 3)
+            s.close()
+            del x, y
+            torch.cuda.empty_cache()
+        out[name] = row
+    return out
+
+
 def fir_config(torch, pa, dev, timer, cpu_seconds):
     """BASELINE configs[3].  The single 2^20-sample call is latency-bound (255 blocks); the throughput regime is
     measured on (i) a batch of independent 2^20-sample signals through pffastconv_hip_apply_batch and (ii) one
@@ -498,6 +519,10 @@ def main():
                 configs["c4"] = fir_config(torch, pa, dev, timer, min(cpu_s, 5.0))
             except Exception as e:
                 configs["c4"] = {"error": str(e)[:300]}
+            try:
+                configs["nonpow2"] = nonpow2_sweep(torch, pa, dev, timer)
+            except Exception as e:
+                configs["nonpow2"] = {"error": str(e)[:300]}
         else:
             # BASELINE configs[4]: the double-precision config sharded over the same ranks, weak and strong
             for name, sc, st in (("c5_weak", "weak", 40), ("c5_strong", "strong", 8)):
