@@ -343,7 +343,7 @@ def fir_config(torch, pa, dev, timer, cpu_seconds):
     out["value"] = round(nl / t / 1e9, 2)
     out["unit"] = "G output samples/s"
     out["long_signal"] = f"2^{FIR['long_log2']} samples, {taps} taps"
-    out["roofline"] = roofline(8 * nl, t)
+    out["roofline"] = roofline(8 * nl, t, _traffic("c4_long_bytes_per_launch"))
     fc.close()
     del xl, yl, sig, y
     torch.cuda.empty_cache()

@@ -63,7 +63,7 @@ for key, sub, alg, what in CASES:
          "valu_active_over_wave_cycles": a.get("SQ_ACTIVE_INST_VALU", 0) / max(a.get("SQ_WAVE_CYCLES", 1), 1),
          "dispatch": meta.get(key)}
     out[key] = d
-    if key in ("c2", "c3", "c5"):
+    if key in ("c2", "c3", "c5", "c4_long"):
         traffic_json[key + "_bytes_per_launch"] = tr
     m = meta.get(key, {})
     lines.append(f"| {what} | `{krow['Name'][:70]}` | {ns/1e6:.4f} | {d['frac_of_8TBps']:.3f} | {d['traffic_over_algorithmic']:.3f} | "
