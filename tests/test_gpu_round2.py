@@ -418,3 +418,37 @@ def test_stockham_direct_first_stage(ref, dt, tr, N):
     finally:
         pa.set_variant(0)
     s.close(); rs.close()
+
+
+@pytest.mark.parametrize("dt,tr,N", [(np.float32, pa.COMPLEX, 96), (np.float32, pa.COMPLEX, 480), (np.float32, pa.COMPLEX, 640),
+                                     (np.float32, pa.COMPLEX, 960), (np.float32, pa.COMPLEX, 2000), (np.float32, pa.COMPLEX, 4000),
+                                     (np.float32, pa.REAL, 192), (np.float32, pa.REAL, 1280), (np.float32, pa.REAL, 1920),
+                                     (np.float32, pa.REAL, 4000), (np.float32, pa.REAL, 8000),
+                                     (np.float64, pa.COMPLEX, 160), (np.float64, pa.COMPLEX, 1536), (np.float64, pa.REAL, 480)])
+def test_stockham_direct_first_stage_steady_state(ref, dt, tr, N):
+    """Long batches: every workgroup runs MANY iterations, so the image ping-pong ACROSS iterations (the direct variant has no
+    closing barrier: the next first stage writes the image the last phase does not read) and the split loader / storer
+    wavefronts are exercised in steady state.  Direct (54) and producer (55) variants must agree bit for bit over the whole
+    batch; a few transforms are checked against the reference."""
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    s = pa.Setup(N, tr, dt)
+    rs = ref.setup(N, tr, dt)
+    vec_bytes = s.vec_scalars * (4 if dt == np.float32 else 8)
+    B = ((4 << 30) if vec_bytes <= 4096 else (1 << 30)) // vec_bytes + 3      # ragged tail
+    x = _uniform((B, s.vec_scalars), 500 + N, tdt)
+    idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1})
+    xh = x[idx].cpu().numpy()
+    tol = tol_for("f32" if dt == np.float32 else "f64", N)
+    try:
+        for d, o in ((pa.FORWARD, False), (pa.FORWARD, True), (pa.BACKWARD, True)):
+            pa.set_variant(54)
+            y = s.transform_batch(x, None, d, o)
+            pa.set_variant(55)
+            y0 = s.transform_batch(x, None, d, o)
+            pa.set_variant(0)
+            assert torch.equal(y0, y), (d, o)
+            assert relerr(y[idx].cpu().numpy(), rs.batch(xh, d, o)) <= tol, (d, o)
+            del y, y0
+    finally:
+        pa.set_variant(0)
+    s.close(); rs.close()
