@@ -452,3 +452,45 @@ def test_stockham_direct_first_stage_steady_state(ref, dt, tr, N):
     finally:
         pa.set_variant(0)
     s.close(); rs.close()
+
+
+def _smooth5(m):
+    for q in (2, 3, 5):
+        while m % q == 0:
+            m //= q
+    return m == 1
+
+
+# every size tools/gen_stock_plans.hip instantiates a compile-time plan for (complex points n; real N = 2 n)
+_CT_SIZES = [n for n in range(48, 1025, 16) if _smooth5(n) and (n & (n - 1))] + [1200, 1536, 2000, 2400, 2592, 4000, 4608, 6000, 9216]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("tr", [pa.COMPLEX, pa.REAL])
+def test_every_compile_time_stockham_plan_against_reference(ref, dt, tr):
+    """Every generated plan (not only the sizes of the reference's lists): all four direction / layout combinations of a
+    ragged batch against the reference, and the direct-first-stage variant bit-identical to the producer variant wherever
+    the size runs on the Stockham kernels."""
+    dtype = np.float32 if dt == "f32" else np.float64
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    try:
+        for n in _CT_SIZES:
+            N = n if tr == pa.COMPLEX else 2 * n
+            s = pa.Setup(N, tr, dtype)
+            rs = ref.setup(N, tr, dtype)
+            tol = tol_for(dt, N)
+            x = _uniform((7, s.vec_scalars), 600 + n, tdt)
+            xl = _uniform((2051, s.vec_scalars), 601 + n, tdt)
+            xh = x.cpu().numpy()
+            for d in (pa.FORWARD, pa.BACKWARD):
+                for o in (False, True):
+                    got = s.transform_batch(x, None, d, o).cpu().numpy()
+                    assert relerr(got, rs.batch(xh, d, o)) <= tol, (dt, tr, N, d, o)
+                    if "stock" in pa.kernel_name(s):
+                        pa.set_variant(54); a = s.transform_batch(xl, None, d, o)
+                        pa.set_variant(55); b = s.transform_batch(xl, None, d, o)
+                        pa.set_variant(0)
+                        assert torch.equal(a, b), (dt, tr, N, d, o)
+            s.close(); rs.close()
+    finally:
+        pa.set_variant(0)
