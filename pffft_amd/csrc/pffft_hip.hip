@@ -116,6 +116,18 @@ static void aligned_free64(void* p) {
 
 static void destroy_setup(Setup* s);
 
+// does the canonical complex transform of this (sub-)setup run on one of the fast kernels: register-tiled power-of-two
+// sizes, or a Stockham plan that exists as a compile-time constant (the run-time-plan twin runs at 0.3)
+static bool sub_is_fast(const Setup* q) {
+    if (q->kernel == K_TILED || q->kernel == K_C1024_F32) return true;
+    if (q->kernel != K_GENERIC) return false;
+    if (q->is_double)
+        return (q->skw_ok && stock_ct_lookup(q->skw[0], 0, true, (const double*)nullptr)) ||
+               (q->sk_ok && stock_ct_lookup(q->sk[0], 0, false, (const double*)nullptr));
+    return (q->skw_ok && stock_ct_lookup(q->skw[0], 0, true, (const float*)nullptr)) ||
+           (q->sk_ok && stock_ct_lookup(q->sk[0], 0, false, (const float*)nullptr));
+}
+
 static Setup* new_setup(int N, int transform, int is_double) {
     // validation: src/pffft_priv_impl.h:1066-1078 and :1105-1109
     if (N <= 0 || N > (1 << 26)) return nullptr;
@@ -148,10 +160,23 @@ static Setup* new_setup(int N, int transform, int is_double) {
     int th = (int)(((size_t)gp.G * s->n / 8 + 63) / 64 * 64);
     s->gthreads = th < 64 ? 64 : (th > 1024 ? 1024 : th);
     s->kernel = K_GENERIC;
-    if (s->glds > LDS_MAX) {
+    // mixed-radix Stockham plans (fft_stock.h) for every size whose two exchange images fit LDS
+    {
+        bool wl = false;
+        s->sk_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->sk, &s->sk_threads, &wl, false, LDS_MAX);
+        s->skw_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->skw, &s->skw_threads, &wl, true, LDS_MAX) && wl;
+    }
+    const bool pow2_tiled = (s->n & (s->n - 1)) == 0 && s->n >= 16 && s->n <= 16384 && (size_t)s->n * esz <= 128 * 1024;
+    // sizes with ONE image in LDS (two do not fit: complex float n = 9600 .. 20480) would run the radix 2-5 in-place kernel
+    // of fft_generic.h at 0.10-0.14 of the roofline; as R x N2 with the rows on a fast kernel the three streaming passes
+    // below measure 0.17-0.24
+    const bool single_image = s->glds <= LDS_MAX && !s->sk_ok && !s->skw_ok && !pow2_tiled;
+    if (s->glds > LDS_MAX || single_image) {
         // four-step plan: split the prime factors of n into two balanced products
         s->kernel = K_BIG;
         // ... unless n = R x N2 with a register-sized R and an N2 the LDS-resident batched kernels take (fft_big.h)
+        // (the first R whose N2 runs on a fast kernel: N = 20480 as 4 x 5120 put the rows on the run-time-plan Stockham
+        //  kernel and measured 0.04 of the roofline, as 32 x 640 it has a compile-time plan)
         for (int R : {2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 32}) {
             if (s->n % R) continue;
             const int N2 = s->n / R;
@@ -159,11 +184,19 @@ static Setup* new_setup(int N, int transform, int is_double) {
             Setup* sub = new_setup(N2, PFFFT_COMPLEX, is_double);
             if (!sub) continue;
             if (sub->kernel == K_BIG || (sub->kernel == K_GENERIC && !sub->sk_ok)) { destroy_setup(sub); continue; }
+            const bool fast = sub_is_fast(sub);
+            if (s->sub && !fast) { destroy_setup(sub); continue; }      // keep the first usable one as the fallback
+            if (s->sub) destroy_setup(s->sub);
             s->sub = sub; s->bigR = R;
-            break;
+            if (fast) break;
+        }
+        if (single_image && !(s->sub && sub_is_fast(s->sub))) {   // no fast factorization: stays on the in-place kernel
+            if (s->sub) destroy_setup(s->sub);
+            s->sub = nullptr; s->bigR = 0;
+            s->kernel = K_GENERIC;
         }
         // larger still: peel the largest register-sized factor and recurse (n = R x (R' x N2')): five passes, seven, ...
-        if (!s->sub) {
+        if (!s->sub && s->kernel == K_BIG) {
             for (int R : {32, 16, 15, 12, 10, 8, 6, 5, 4, 3, 2}) {
                 if (s->n % R) continue;
                 const int N2 = s->n / R;
@@ -207,12 +240,7 @@ static Setup* new_setup(int N, int transform, int is_double) {
         s->kernel = K_TILED;  // power-of-two sizes: register-tiled kernels (fft_tiled.h)
     // every other size that fits: mixed-radix Stockham kernel (fft_stock.h); the in-place kernel of
     // fft_generic.h keeps the sizes whose two images exceed LDS
-    if (s->kernel != K_BIG)
-    {
-        bool wl = false;
-        s->sk_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->sk, &s->sk_threads, &wl, false, LDS_MAX);
-        s->skw_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->skw, &s->skw_threads, &wl, true, LDS_MAX) && wl;
-    }
+    if (s->kernel == K_BIG) s->sk_ok = s->skw_ok = false;
     return s;
 }
 
