@@ -116,16 +116,17 @@ static void aligned_free64(void* p) {
 
 static void destroy_setup(Setup* s);
 
-// does the canonical complex transform of this (sub-)setup run on one of the fast kernels: register-tiled power-of-two
+// does the canonical forward transform of this (sub-)setup run on one of the fast kernels: register-tiled power-of-two
 // sizes, or a Stockham plan that exists as a compile-time constant (the run-time-plan twin runs at 0.3)
 static bool sub_is_fast(const Setup* q) {
     if (q->kernel == K_TILED || q->kernel == K_C1024_F32) return true;
     if (q->kernel != K_GENERIC) return false;
+    const int flags = q->transform == PFFFT_REAL ? 8 : 0;   // forward, canonical layouts (fft_stock.h)
     if (q->is_double)
-        return (q->skw_ok && stock_ct_lookup(q->skw[0], 0, true, (const double*)nullptr)) ||
-               (q->sk_ok && stock_ct_lookup(q->sk[0], 0, false, (const double*)nullptr));
-    return (q->skw_ok && stock_ct_lookup(q->skw[0], 0, true, (const float*)nullptr)) ||
-           (q->sk_ok && stock_ct_lookup(q->sk[0], 0, false, (const float*)nullptr));
+        return (q->skw_ok && stock_ct_lookup(q->skw[0], flags, true, (const double*)nullptr)) ||
+               (q->sk_ok && stock_ct_lookup(q->sk[0], flags, false, (const double*)nullptr));
+    return (q->skw_ok && stock_ct_lookup(q->skw[0], flags, true, (const float*)nullptr)) ||
+           (q->sk_ok && stock_ct_lookup(q->sk[0], flags, false, (const float*)nullptr));
 }
 
 static Setup* new_setup(int N, int transform, int is_double) {
@@ -170,7 +171,9 @@ static Setup* new_setup(int N, int transform, int is_double) {
     // sizes with ONE image in LDS (two do not fit: complex float n = 9600 .. 20480) would run the radix 2-5 in-place kernel
     // of fft_generic.h at 0.10-0.14 of the roofline; as R x N2 with the rows on a fast kernel the three streaming passes
     // below measure 0.17-0.24
-    const bool single_image = s->glds <= LDS_MAX && !s->sk_ok && !s->skw_ok && !pow2_tiled;
+    // (the same holds for a size whose Stockham plan fits but has no compile-time twin: the run-time-plan kernel measured 0.07
+    //  at n = 9600)
+    const bool single_image = s->glds <= LDS_MAX && !pow2_tiled && !sub_is_fast(s) && s->n >= 2048;
     if (s->glds > LDS_MAX || single_image) {
         // four-step plan: split the prime factors of n into two balanced products
         s->kernel = K_BIG;
@@ -1287,7 +1290,8 @@ PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
         case pf::K_C1024_F32: return "c1024_f32";
         case pf::K_TILED: return "tiled";
         case pf::K_BIG: return "fourstep";
-        default: return (s->sk_ok && pf::g_variant != 51) ? "stockham" : "generic";
+        // "stockham_rt": the plan has no compile-time twin and runs the run-time-plan kernel (0.3 of the roofline and less)
+        default: return (s->sk_ok && pf::g_variant != 51) ? (pf::sub_is_fast(s) ? "stockham" : "stockham_rt") : "generic";
     }
 }
 PF_EXPORT const char* pffft_hip_last_error(void) { return pf::g_last_error.c_str(); }

@@ -41,3 +41,38 @@ def test_direct_first_stage_table_is_well_formed():
         assert 16 <= n <= 20480 and n % 16 == 0
         assert not (out_int and bwd), "the internal layout is the OUTPUT of forward transforms only"
         assert k >> 24 == 0
+
+
+def test_every_lds_resident_size_has_a_fast_kernel():
+    """Routing (no GPU needed: plans are host data).  Every legal non-power-of-two size whose Stockham images fit LDS must find
+    its compile-time plan ("stockham", not the run-time-plan twin "stockham_rt" at 0.3 of the roofline and less), and the
+    sizes beyond must take the streaming passes ("fourstep") rather than the in-place radix 2-5 kernel whenever they factor
+    into a register-sized radix times a fast row size."""
+    import numpy as np
+    import pffft_amd as pa
+
+    def smooth5(m):
+        for q in (2, 3, 5):
+            while m % q == 0:
+                m //= q
+        return m == 1
+
+    slow = []
+    for dt in (np.float32, np.float64):
+        for tr, mul in ((pa.COMPLEX, 1), (pa.REAL, 2)):
+            for n in range(48, 10241, 16):
+                if not smooth5(n) or (n & (n - 1)) == 0:
+                    continue
+                s = pa.Setup(n * mul, tr, dt)
+                name = pa.kernel_name(s)
+                s.close()
+                if name not in ("stockham", "fourstep", "tiny", "tiled"):
+                    slow.append((np.dtype(dt).name, tr, n * mul, name))
+    # sizes with too few small factors for four Stockham stages AND no R x N2 factorization (3^5 / 3^6 multiples): known, rare
+    known = {3888, 7776, 5832, 11664, 9720, 19440, 15552, 2 * 3888, 2 * 7776}
+    assert [x for x in slow if x[2] not in known] == [], slow
+    for N, tr, want in ((12000, pa.COMPLEX, "fourstep"), (20480, pa.COMPLEX, "fourstep"), (36864, pa.REAL, "fourstep"),
+                        (8000, pa.REAL, "stockham"), (9600, pa.COMPLEX, "stockham")):
+        s = pa.Setup(N, tr, np.float32)
+        assert pa.kernel_name(s) == want, (N, tr, pa.kernel_name(s))
+        s.close()

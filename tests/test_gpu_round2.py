@@ -462,7 +462,7 @@ def _smooth5(m):
 
 
 # every size tools/gen_stock_plans.hip instantiates a compile-time plan for (complex points n; real N = 2 n)
-_CT_SIZES = [n for n in range(48, 1025, 16) if _smooth5(n) and (n & (n - 1))] + [n for n in range(1040, 9217, 16) if _smooth5(n) and (n & (n - 1))]
+_CT_SIZES = [n for n in range(48, 1025, 16) if _smooth5(n) and (n & (n - 1))] + [n for n in range(1040, 10241, 16) if _smooth5(n) and (n & (n - 1))]
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
