@@ -183,7 +183,7 @@ static Setup* new_setup(int N, int transform, int is_double) {
         for (int R : {2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 32}) {
             if (s->n % R) continue;
             const int N2 = s->n / R;
-            if ((size_t)N2 * esz > 64 * 1024 || N2 % (SIMD * SIMD)) continue;
+            if ((size_t)N2 * esz > 80 * 1024 || N2 % (SIMD * SIMD)) continue;   // (Stockham plans reach n = 10000 float)
             Setup* sub = new_setup(N2, PFFFT_COMPLEX, is_double);
             if (!sub) continue;
             if (sub->kernel == K_BIG || (sub->kernel == K_GENERIC && !sub->sk_ok)) { destroy_setup(sub); continue; }
