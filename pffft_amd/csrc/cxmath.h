@@ -210,6 +210,51 @@ template <int P, int Q, int DIR, typename V> __device__ __forceinline__ void dft
     }
 }
 
+// Radix P*Q with a common factor (9 = 3 x 3, 25 = 5 x 5, 27 = 3 x 9) as Cooley-Tukey: P-point transforms, constant twiddles
+// W_R^(b k1) from a compile-time table, Q-point transforms across them.  Used by the column kernels
+// of fft_big.h, where a register-sized factor must leave a row length that is a multiple of 16.
+template <int R> struct CtTab;
+template <> struct CtTab<9> {
+    static constexpr long double C[9] = {1L, 0.766044443118978013452L, 0.173648177666930358942L, -0.5L, -0.939692620785908427905L, -0.939692620785908427905L, -0.5L, 0.173648177666930358942L, 0.766044443118978013452L};
+    static constexpr long double S[9] = {0L, 0.642787609686539362919L, 0.984807753012208020316L, 0.866025403784438596588L, 0.342020143325668712908L, -0.342020143325668712908L, -0.866025403784438596588L, -0.984807753012208020316L, -0.642787609686539362919L};
+};
+template <> struct CtTab<25> {
+    static constexpr long double C[25] = {1L, 0.968583161128631076053L, 0.87630668004386358394L, 0.728968627421411552447L, 0.53582679497899665666L, 0.309016994374947451263L, 0.062790519529313373881L, -0.18738131458572462873L, -0.425779291565072659509L, -0.637423989748689745483L, -0.809016994374947451263L, -0.929776485888251458256L, -0.992114701314477875904L, -0.992114701314477875904L, -0.929776485888251458256L, -0.809016994374947451263L, -0.637423989748689745483L, -0.425779291565072659509L, -0.18738131458572462873L, 0.062790519529313373881L, 0.309016994374947451263L, 0.53582679497899665666L, 0.728968627421411552447L, 0.87630668004386358394L, 0.968583161128631076053L};
+    static constexpr long double S[25] = {0L, 0.248689887164854794843L, 0.481753674101715267941L, 0.684547105928688726095L, 0.84432792550201507531L, 0.951056516295153531182L, 0.998026728428271558968L, 0.982287250728688721146L, 0.904827052466019576826L, 0.770513242775789253258L, 0.587785252292473137103L, 0.368124552684677974757L, 0.125333233564304258323L, -0.125333233564304258323L, -0.368124552684677974757L, -0.587785252292473137103L, -0.770513242775789253258L, -0.904827052466019576826L, -0.982287250728688721146L, -0.998026728428271558968L, -0.951056516295153531182L, -0.84432792550201507531L, -0.684547105928688726095L, -0.481753674101715267941L, -0.248689887164854794843L};
+};
+template <> struct CtTab<27> {
+    static constexpr long double C[27] = {1L, 0.973044870579823806267L, 0.893632640323412275052L, 0.766044443118978013452L, 0.597158591702786178956L, 0.396079766039156844215L, 0.173648177666930358942L, -0.0581448289104758292423L, -0.286803232711090261287L, -0.5L, -0.686241637868733600492L, -0.835487811412936376421L, -0.939692620785908427905L, -0.993238357741943023171L, -0.993238357741943023171L, -0.939692620785908427905L, -0.835487811412936376421L, -0.686241637868733600492L, -0.5L, -0.286803232711090261287L, -0.0581448289104758292423L, 0.173648177666930358942L, 0.396079766039156844215L, 0.597158591702786178956L, 0.766044443118978013452L, 0.893632640323412275052L, 0.973044870579823806267L};
+    static constexpr long double S[27] = {0L, 0.230615870742440165486L, 0.448799180200462166646L, 0.642787609686539362919L, 0.802123192755043734614L, 0.918216106880273996715L, 0.984807753012208020316L, 0.998308158271268175632L, 0.957989512315488900285L, 0.866025403784438596588L, 0.727373641573048734799L, 0.549508978070806008986L, 0.342020143325668712908L, 0.116092914125230234346L, -0.116092914125230234346L, -0.342020143325668712908L, -0.549508978070806008986L, -0.727373641573048734799L, -0.866025403784438596588L, -0.957989512315488900285L, -0.998308158271268175632L, -0.984807753012208020316L, -0.918216106880273996715L, -0.802123192755043734614L, -0.642787609686539362919L, -0.448799180200462166646L, -0.230615870742440165486L};
+};
+// input n = Q a + b (a < P, b < Q): P-point transforms over a for every b -> t_b[k1]; times W_R^(b k1); Q-point transforms
+// over b for every k1 -> X[k1 + P k2]
+template <int P, int Q, int DIR, typename V> __device__ __forceinline__ void dft_ct(V (&a)[P * Q]) {
+    typedef sc<V> T;
+    constexpr int R = P * Q;
+    V y[P][Q];
+#pragma unroll
+    for (int b = 0; b < Q; ++b) {
+        V t[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) t[i] = a[Q * i + b];
+        dftR<P, DIR>(t);
+#pragma unroll
+        for (int k1 = 0; k1 < P; ++k1) {
+            const int m = (b * k1) % R;
+            y[k1][b] = m == 0 ? t[k1] : twmul<DIR>(t[k1], mk<T>((T)CtTab<R>::C[m], (T)-CtTab<R>::S[m]));
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < P; ++k1) {
+        V u[Q];
+#pragma unroll
+        for (int b = 0; b < Q; ++b) u[b] = y[k1][b];
+        dftR<Q, DIR>(u);
+#pragma unroll
+        for (int k2 = 0; k2 < Q; ++k2) a[k1 + P * k2] = u[k2];
+    }
+}
+
 template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a)[R]) {
     if constexpr (R == 2) dft2<DIR>(a[0], a[1]);
     else if constexpr (R == 3) dft3<DIR>(a[0], a[1], a[2]);
@@ -217,11 +262,14 @@ template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a
     else if constexpr (R == 5) dft5<DIR>(a[0], a[1], a[2], a[3], a[4]);
     else if constexpr (R == 6) dft_pfa<2, 3, DIR>(a);
     else if constexpr (R == 8) dft8<DIR>(a);
+    else if constexpr (R == 9) dft_ct<3, 3, DIR>(a);
     else if constexpr (R == 10) dft_pfa<2, 5, DIR>(a);
     else if constexpr (R == 12) dft_pfa<4, 3, DIR>(a);
     else if constexpr (R == 15) dft_pfa<3, 5, DIR>(a);
     else if constexpr (R == 16) dft16<DIR>(a);
     else if constexpr (R == 24) dft_pfa<8, 3, DIR>(a);
+    else if constexpr (R == 25) dft_ct<5, 5, DIR>(a);
+    else if constexpr (R == 27) dft_ct<3, 9, DIR>(a);
     else if constexpr (R == 32) dft32<DIR>(a);
 }
 

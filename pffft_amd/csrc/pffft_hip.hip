@@ -180,7 +180,7 @@ static Setup* new_setup(int N, int transform, int is_double) {
         // ... unless n = R x N2 with a register-sized R and an N2 the LDS-resident batched kernels take (fft_big.h)
         // (the first R whose N2 runs on a fast kernel: N = 20480 as 4 x 5120 put the rows on the run-time-plan Stockham
         //  kernel and measured 0.04 of the roofline, as 32 x 640 it has a compile-time plan)
-        for (int R : {2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 32}) {
+        for (int R : {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 25, 27, 32}) {
             if (s->n % R) continue;
             const int N2 = s->n / R;
             if ((size_t)N2 * esz > 80 * 1024 || N2 % (SIMD * SIMD)) continue;   // (Stockham plans reach n = 10000 float)
@@ -733,7 +733,8 @@ static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, 
         return 0;                                                                                                  \
     }
     switch (R) {
-        PF_BIG_R(2) PF_BIG_R(3) PF_BIG_R(4) PF_BIG_R(5) PF_BIG_R(6) PF_BIG_R(8) PF_BIG_R(10) PF_BIG_R(12) PF_BIG_R(15) PF_BIG_R(16) PF_BIG_R(32)
+        PF_BIG_R(2) PF_BIG_R(3) PF_BIG_R(4) PF_BIG_R(5) PF_BIG_R(6) PF_BIG_R(8) PF_BIG_R(9) PF_BIG_R(10) PF_BIG_R(12) PF_BIG_R(15) PF_BIG_R(16)
+        PF_BIG_R(25) PF_BIG_R(27) PF_BIG_R(32)
     }
 #undef PF_BIG_R
     g_last_error = "pffft_hip: unsupported small factor";

@@ -494,3 +494,27 @@ def test_every_compile_time_stockham_plan_against_reference(ref, dt, tr):
             s.close(); rs.close()
     finally:
         pa.set_variant(0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("tr,N", [(pa.COMPLEX, 11664), (pa.COMPLEX, 50000), (pa.COMPLEX, 58320), (pa.COMPLEX, 172800),
+                                  (pa.COMPLEX, 200000), (pa.COMPLEX, 12000), (pa.COMPLEX, 20480), (pa.REAL, 23328),
+                                  (pa.REAL, 100000), (pa.REAL, 345600), (pa.REAL, 19200), (pa.REAL, 40960)])
+def test_streaming_passes_for_sizes_beyond_the_stockham_plans(ref, dt, tr, N):
+    """n = R x N2 with R in registers (now also 9, 25, 27: Cooley-Tukey with constant twiddles) and the rows on a fast kernel:
+    the route of every non-power-of-two size beyond the Stockham plans, including the sizes with ONE image in LDS that used to
+    run the in-place radix 2-5 kernel.  All directions / layouts against the reference, ragged batch, in place."""
+    dtype = np.float32 if dt == "f32" else np.float64
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    s = pa.Setup(N, tr, dtype)
+    rs = ref.setup(N, tr, dtype)
+    tol = tol_for(dt, N) * (4 if dt == "f32" else 1)      # float error grows ~ sqrt(log N); the bar stays 1e-5-class
+    x = _uniform((3, s.vec_scalars), 700 + N % 997, tdt)
+    xh = x.cpu().numpy()
+    for d in (pa.FORWARD, pa.BACKWARD):
+        for o in (False, True):
+            got = s.transform_batch(x, None, d, o)
+            assert relerr(got.cpu().numpy(), rs.batch(xh, d, o)) <= tol, (dt, tr, N, d, o)
+            z = x.clone(); s.transform_batch(z, z, d, o)
+            assert torch.equal(z, got), (dt, tr, N, d, o)
+    s.close(); rs.close()
