@@ -16,8 +16,19 @@
  * no CPU arithmetic path in this library: without a usable HIP device (or on any HIP error) a
  * transform entry FAILS SOFT — one line on stderr, the output vector filled with NaN, the failure
  * counted in pffft_hip_error_count() and described by pffft_hip_last_error(); PFFFT_HIP_ABORT=1 in
- * the environment turns that into abort().  `work` is accepted and ignored (reference: scratch of N / 2N scalars or NULL,
- * include/pffft/pffft.h:137-142).
+ * the environment turns that into abort().  A call on an invalid handle (NULL, destroyed, wrong precision) writes
+ * nothing.  `work` is accepted and ignored (reference: scratch of N / 2N scalars or NULL, include/pffft/pffft.h:137-142).
+ *
+ * COST OF THE LEGACY SINGLE-VECTOR ENTRIES.  One call = one kernel launch + one stream synchronisation: 17-29 us per call
+ * with host pointers (N = 64 ... 16384; the reference's SSE path: 0.1-30 us), i.e. a program that links this library and
+ * keeps calling pffft_transform() vector by vector runs 10-20 x SLOWER than on the CPU for N <= 4096.  The throughput of
+ * this library is in PART 2 (batched entries on device-resident data): move the loop over vectors into `batch`.
+ *
+ * ACCURACY OF pffftd_* AGAINST THE REFERENCE.  The reference's double build keeps float-suffixed radix-3 / radix-5
+ * constants (src/pffft_priv_impl.h:154,259-262,389,431-432,636-639 survive `#define float double`), so for every N with a
+ * factor 3 or 5 the reference's own pffftd_* result is only ~1e-8 accurate.  This library uses full-precision constants:
+ * for those sizes it agrees with a float64 DFT to 1e-12 and with the reference to ~1e-8 (tests: 2e-7); power-of-two sizes
+ * agree with the reference to 1e-15.
  */
 #ifndef PFFFT_HIP_H
 #define PFFFT_HIP_H
@@ -88,6 +99,10 @@ enum {
 };
 PFFASTCONV_Setup *pffastconv_new_setup(const float *filterCoeffs, int filterLen, int *blockLen, int flags);
 void pffastconv_destroy_setup(PFFASTCONV_Setup *);
+/* Returns the number of output samples produced, as the reference does (src/pffastconv.c:133-263).  ADDITION: -1 when the
+ * HIP path failed (no device, HIP error, invalid setup) - the reference cannot fail here, and 0 would be indistinguishable
+ * from "not enough input yet" for a streaming caller.  On failure at most inputLen - filterLen + 1 samples of `output`
+ * (what include/pffft/pffastconv.h:159 guarantees to be writable) are filled with NaN. */
 int pffastconv_apply(PFFASTCONV_Setup *, const float *input, int inputLen, float *output, int applyFlush);
 void *pffastconv_malloc(size_t nb_bytes);
 void pffastconv_free(void *);
@@ -139,7 +154,8 @@ int pffft_hip_shift_transform_batch(PFFFT_Setup *, const float *in, float *out, 
 int pffastconv_hip_apply_device(PFFASTCONV_Setup *, const float *d_input, int inputLen, float *d_output,
                                 int applyFlush, void *stream);
 /* The same filter over `nsignals` independent signals of `inputLen` samples each (complex I/O: complex samples), signal
- * i at d_input + i*inputStride and its output at d_output + i*outputStride (strides in floats, >= the signal's floats).
+ * i at d_input + i*inputStride and its output at d_output + i*outputStride (strides in floats; inputStride >= the signal's
+ * floats, outputStride >= the floats one signal produces - both checked, -1 otherwise; any nsignals).
  * Every signal is processed exactly as one pffastconv_hip_apply_device call would (src/pffastconv.c:133-263 per signal,
  * same block schedule, same number of outputs — the return value, per signal); all blocks of all signals share one
  * launch so that reference-sized calls (BASELINE configs[3]: 255 blocks) fill the chip.  -1 on error. */
@@ -156,7 +172,9 @@ const char *pffft_hip_last_error(void);
  * vector with NaN (all-ones bytes) and increments this counter.  PFFFT_HIP_ABORT=1 makes it abort() instead. */
 unsigned pffft_hip_error_count(void);
 int pffft_hip_device_count(void);
-/* 0 = default; other values select experimental variants of the headline kernel (bench A/B only) */
+/* 0 = default; other values select alternative kernels / work distributions for A/B measurements and for the parity
+ * tests that hold every alternative to the same bar.  The selector is THREAD-LOCAL: it affects only calls made by the
+ * thread that set it. */
 void pffft_hip_set_variant(int variant);
 
 #ifdef __cplusplus

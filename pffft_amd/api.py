@@ -334,6 +334,8 @@ class FastConv:
         n_in = xin.size // cpl
         y = _aligned_empty(max(xin.size, 1), np.float32)
         n = self._L.pffastconv_apply(self.handle, xin.ctypes.data, n_in, y.ctypes.data, int(bool(flush)))
+        if n < 0:   # the drop-in's failure value (include/pffft_hip.h): the C entry has already failed soft, the mirror returns it as is
+            return y[:0].copy(), n
         return y[:n * cpl].copy(), n
 
     def apply_batch(self, x, flush: bool = True, out=None):

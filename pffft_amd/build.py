@@ -14,12 +14,13 @@ OBJDIR = os.path.join(HERE, "..", "build", "obj")
 # the PFDSP mixers are their own library, like the reference's PFDSP target (CMakeLists.txt:206)
 DSP_LIB = os.path.join(HERE, "libpfdsp_hip.so")
 DSP_SRC = os.path.join(CSRC, "pfdsp_hip.hip")
-DSP_DEPS = [DSP_SRC, os.path.join(CSRC, "pfdsp_mix.h"), os.path.join(HERE, "..", "include", "pfdsp_hip.h")]
+DSP_DEPS = [DSP_SRC, os.path.join(CSRC, "pfdsp_mix.h"), os.path.join(HERE, "..", "include", "pfdsp_hip.h"),
+            os.path.join(CSRC, "exports_dsp.map")]
 
 
 def _deps():
     out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
-           if f.endswith((".h", ".hip")) and f != "pfdsp_hip.hip"]
+           if f.endswith((".h", ".hip", ".map")) and f not in ("pfdsp_hip.hip", "exports_dsp.map")]
     out.append(os.path.join(HERE, "..", "include", "pffft_hip.h"))
     return out
 
@@ -36,7 +37,7 @@ def _build_dsp(force: bool, verbose: bool) -> None:
         return
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
-           "-shared", "-o", DSP_LIB, DSP_SRC]
+           "-shared", "-Wl,--version-script=" + os.path.join(CSRC, "exports_dsp.map"), "-o", DSP_LIB, DSP_SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -77,7 +78,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    # only the C ABI of include/pffft_hip.h becomes a dynamic symbol (exports.map: the kernels' host stubs stay local)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+            "-o", LIB] + objs
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True, cwd=CSRC)

@@ -21,7 +21,7 @@
 namespace pf {
 
 extern thread_local std::string g_last_error;
-extern int g_variant;
+extern thread_local int g_variant;   // A/B selector (pffft_hip_set_variant): per calling thread
 int fail(hipError_t e, const char* what);
 #define PF_CHECK(expr)                                   \
     do {                                                 \
@@ -74,7 +74,7 @@ struct Setup {
     StridedPlan bigp[2];
     void* d_bigtw[2] = {nullptr, nullptr};
     // HBM work buffers of the beyond-LDS path: one pair PER STREAM (kernels of one stream serialise; two streams running
-    // the same setup concurrently must not share scratch).  big_mu guards the map, not the kernels.
+    // the same setup concurrently must not share scratch).  big_mu is held while a call enqueues its passes (launch_big).
     struct Scratch { void* buf[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; };
     std::mutex big_mu;
     std::map<hipStream_t, Scratch> big_scratch;

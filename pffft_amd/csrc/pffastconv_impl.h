@@ -417,10 +417,16 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         const int flen8 = (int)s->h_td.size();
         const bool cplx = mode == 1 || s->cplxFactor == 2;
         const long out_f = mode == 1 ? 2L * produced : produced, in_f = mode == 1 ? 2L * inputLen : inputLen;
-        const dim3 grid((unsigned)((out_f + TD_TILE - 1) / TD_TILE), (unsigned)fb.nsig);
         const size_t lds = sizeof(float) * (TD_TILE + (cplx ? 2 : 1) * flen8 + 8);
-        if (cplx) hipLaunchKernelGGL(fastconv_td_kernel<2>, grid, dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, out_f, in_f, fb.xstride, fb.ystride);
-        else hipLaunchKernelGGL(fastconv_td_kernel<1>, grid, dim3(TD_THREADS), lds, st, d_x, d_y, (const float*)s->d_td, flen8, out_f, in_f, fb.xstride, fb.ystride);
+        // the signal index is blockIdx.y (<= 65535): longer batches go out in slices of 65535 signals on the same stream
+        for (int s0 = 0; s0 < fb.nsig; s0 += 65535) {
+            const int ns = fb.nsig - s0 < 65535 ? fb.nsig - s0 : 65535;
+            const dim3 grid((unsigned)((out_f + TD_TILE - 1) / TD_TILE), (unsigned)ns);
+            const float* xs = d_x + (size_t)s0 * fb.xstride;
+            float* ys = d_y + (size_t)s0 * fb.ystride;
+            if (cplx) hipLaunchKernelGGL(fastconv_td_kernel<2>, grid, dim3(TD_THREADS), lds, st, xs, ys, (const float*)s->d_td, flen8, out_f, in_f, fb.xstride, fb.ystride);
+            else hipLaunchKernelGGL(fastconv_td_kernel<1>, grid, dim3(TD_THREADS), lds, st, xs, ys, (const float*)s->d_td, flen8, out_f, in_f, fb.xstride, fb.ystride);
+        }
         PF_CHECK(hipGetLastError());
         return 0;
     }
@@ -440,6 +446,10 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         }
     }
     // composed path (complex-I/O modes with long filters): signal by signal on the same stream through one work image
+    if (s->work.size() >= 8 && !s->work.count(st)) {   // idle streams do not pin their work image for ever (hipFree waits for their kernels)
+        for (auto& kv : s->work) if (kv.second.p) (void)hipFree(kv.second.p);
+        s->work.clear();
+    }
     FastConv::Work& wk = s->work[st];
     rc = fc_grow(&wk.p, &wk.floats, (size_t)nblk * Nfft);
     if (rc) return rc;
@@ -524,6 +534,12 @@ PF_EXPORT int pffastconv_hip_apply_batch(PFFASTCONV_Setup* s, const float* d_inp
     const size_t fl = (size_t)inputLen * ((s->flags & PFFASTCONV_HIP_CPLX_INP_OUT) ? 2 : 1);
     if (nsignals > 1 && (inputStride < fl || outputStride == 0)) { pf::g_last_error = "pffastconv_hip_apply_batch: stride smaller than a signal"; return -1; }
     int produced = 0;
+    if (nsignals > 1) {   // rows of the output must not overlap: outputStride >= the floats one signal produces
+        int lastOut = 0, prod = 0;
+        (void)pf::fc_schedule(s, s->cplxFactor * inputLen, applyFlush, &lastOut, &prod);
+        const size_t out_floats = (size_t)(prod / s->cplxFactor) * ((s->flags & PFFASTCONV_HIP_CPLX_INP_OUT) ? 2 : 1);
+        if (outputStride < out_floats) { pf::g_last_error = "pffastconv_hip_apply_batch: outputStride smaller than the samples one signal produces"; return -1; }
+    }
     if (nsignals == 0) {   // nothing to do, but the count a call would produce is still defined
         int lastOut = 0;
         (void)pf::fc_schedule(s, s->cplxFactor * inputLen, applyFlush, &lastOut, &produced);
@@ -549,13 +565,13 @@ static int fc_pinned(float** p, size_t* have, size_t want) {
 // is copied by the CPU into a pinned host image that the kernel reads over PCIe directly, the kernel writes its outputs
 // into another pinned image, one stream synchronisation, CPU copy out (the same scheme as the transform entries,
 // pffft_hip.hip legacy_run).  Larger signals are staged through device buffers.  Failure: fail-soft like the transform
-// entries (stderr, pffft_hip_last_error(), returns 0 samples produced), abort() only under PFFFT_HIP_ABORT=1.
+// entries (stderr, pffft_hip_last_error(), error counter) and the return value -1, abort() only under PFFFT_HIP_ABORT=1.
 PF_EXPORT int pffastconv_apply(PFFASTCONV_Setup* s, const float* input, int cplxInputLen, float* output, int applyFlush) {
     using namespace pf;
     if (!s || s->magic != FC_MAGIC) {
         g_last_error = "pffastconv_apply: bad setup";
         legacy_fatal((int)hipErrorInvalidHandle, "pffastconv_apply", nullptr, 0, true);
-        return 0;
+        return -1;
     }
     constexpr size_t FC_ZC_LIMIT = (size_t)64 << 20;
     const bool in_dev = is_device_ptr(input), out_dev = is_device_ptr(output);
@@ -591,9 +607,15 @@ PF_EXPORT int pffastconv_apply(PFFASTCONV_Setup* s, const float* input, int cplx
             if (out_pinned && produced > 0) memcpy(output, d_out, (size_t)produced * cpl * sizeof(float));
         }
     } while (0);
-    if (rc) {   // the reference cannot fail here: NaN over the caller's output vector, 0 samples produced
-        legacy_fatal(rc, "pffastconv_apply", output, in_floats * sizeof(float), !out_dev);
-        return 0;
+    if (rc) {
+        // The reference cannot fail here.  Fail soft: NaN over the part of `output` the reference's contract guarantees to be
+        // writable - inputLen - filterLen + 1 samples (include/pffft/pffastconv.h:159), never the whole input length - and
+        // -1 as the return value: 0 would be indistinguishable from "not enough input yet" and a streaming loop waiting for
+        // progress would spin forever (documented in include/pffft_hip.h).
+        const int taps = s->cplxFactor == 2 ? (s->filterLen + 1) / 2 : s->filterLen;   // the caller's filter length
+        const long writable = (long)cplxInputLen - taps + 1;
+        legacy_fatal(rc, "pffastconv_apply", output, writable > 0 ? (size_t)writable * cpl * sizeof(float) : 0, !out_dev);
+        return -1;
     }
     return produced;
 }

@@ -34,7 +34,7 @@ namespace pf {
 // error plumbing
 // ------------------------------------------------------------------------------------------------
 thread_local std::string g_last_error;
-int g_variant = 0;
+thread_local int g_variant = 0;
 
 int fail(hipError_t e, const char* what) {
     char buf[512];
@@ -44,9 +44,11 @@ int fail(hipError_t e, const char* what) {
 }
 
 // Legacy void entries have no error channel (include/pffft/pffft.h:159).  A drop-in must not kill its caller where the
-// reference could not fail: the default is FAIL-SOFT — one line on stderr (the first 8 failures per process), the text in
-// pffft_hip_last_error(), the failure counted in pffft_hip_error_count(), and the output vector filled with NaN (all-ones
-// bytes; host or device memory alike) so that a failed call can never be mistaken for a spectrum.
+// reference could not fail: the default is FAIL-SOFT — one line on stderr (the first 8 failures per process, then every
+// 2^k-th: a long-running caller never goes fully silent), the text in pffft_hip_last_error(), the failure counted in
+// pffft_hip_error_count(), and the output vector filled with NaN (all-ones bytes; host or device memory alike) so that a
+// failed call can never be mistaken for a spectrum.  A call on an INVALID HANDLE (null, destroyed, wrong precision) writes
+// nothing: the vector length would have to be read from the very object that failed validation.
 // PFFFT_HIP_ABORT=1 restores fail-fast (abort()).
 static std::atomic<unsigned> g_error_count{0};
 static bool abort_on_error() {
@@ -55,9 +57,11 @@ static bool abort_on_error() {
 }
 static void legacy_fatal(int code, const char* entry, void* out, size_t out_bytes, bool out_is_host) {
     const unsigned nth = g_error_count.fetch_add(1);
-    if (nth < 8 || abort_on_error())
-        fprintf(stderr, "%s: HIP path failed (%d): %s%s\n", entry, code, g_last_error.c_str(),
-                abort_on_error() ? "" : " -- output filled with NaN (PFFFT_HIP_ABORT=1 aborts instead)");
+    const unsigned seq = nth + 1;
+    if (nth < 8 || (seq & (seq - 1)) == 0 || abort_on_error())
+        fprintf(stderr, "%s: HIP path failed (%d) [failure #%u of this process]: %s%s\n", entry, code, seq, g_last_error.c_str(),
+                abort_on_error() ? "" : (out && out_bytes) ? " -- output filled with NaN (PFFFT_HIP_ABORT=1 aborts instead)"
+                                                          : " -- output left untouched (PFFFT_HIP_ABORT=1 aborts instead)");
     if (abort_on_error()) abort();
     if (out && out_bytes) {
         if (out_is_host) memset(out, 0xFF, out_bytes);  // all-ones = NaN pattern
@@ -747,8 +751,17 @@ template <typename T>
 static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     const size_t bytes = batch * (size_t)s->n * sizeof(cx<T>);
     cx<T>*bufA, *bufB;
+    // big_mu is held until EVERY pass of this call is enqueued: it guards host-side enqueue only, and a second thread
+    // growing the same stream's scratch (hipFree synchronises with the device) can then never free buffers whose kernels
+    // are not yet in the stream.  Scratch of other streams is dropped once more than BIG_SCRATCH_STREAMS streams have used
+    // this setup (hipFree waits for their kernels), so idle streams do not pin 2 x batch x n x sizeof(cx) bytes each.
+    std::lock_guard<std::mutex> lk(s->big_mu);
     {
-        std::lock_guard<std::mutex> lk(s->big_mu);
+        constexpr size_t BIG_SCRATCH_STREAMS = 8;
+        if (s->big_scratch.size() >= BIG_SCRATCH_STREAMS && !s->big_scratch.count(st)) {
+            for (auto& kv : s->big_scratch) for (void* p : kv.second.buf) if (p) (void)hipFree(p);
+            s->big_scratch.clear();
+        }
         Setup::Scratch& sc = s->big_scratch[st];
         for (int i = 0; i < 2; ++i)
             if (sc.bytes[i] < bytes) {
@@ -1161,13 +1174,19 @@ static int legacy_run(Setup* s, const T* const* ins, int nin, T* out, bool out_i
     return 0;
 }
 
+// bytes of the caller's output vector the fail-soft path may overwrite: none unless the handle itself is valid
+template <typename T>
+static size_t legacy_out_bytes(const Setup* s) {
+    return (s && s->magic == MAGIC && s->is_double == (sizeof(T) == 8)) ? s->vec_scalars * sizeof(T) : 0;
+}
+
 template <typename T>
 static void legacy_transform(Setup* s, const T* in, T* out, int dir, int ordered, const char* name) {
     const T* ins[1] = {in};
     int rc = legacy_run<T>(s, ins, 1, out, false, [&](const T* const* di, T* dout) {
         return transform_batch<T>(s, di[0], dout, 1, dir, ordered, nullptr);
     });
-    if (rc) legacy_fatal(rc, name, out, s ? s->vec_scalars * sizeof(T) : 0, !is_device_ptr(out));
+    if (rc) legacy_fatal(rc, name, out, legacy_out_bytes<T>(s), !is_device_ptr(out));
 }
 
 template <typename T>
@@ -1176,7 +1195,7 @@ static void legacy_zreorder(Setup* s, const T* in, T* out, int dir, const char* 
     int rc = legacy_run<T>(s, ins, 1, out, false, [&](const T* const* di, T* dout) {
         return zreorder_batch<T>(s, di[0], dout, 1, dir, nullptr);
     });
-    if (rc) legacy_fatal(rc, name, out, s ? s->vec_scalars * sizeof(T) : 0, !is_device_ptr(out));
+    if (rc) legacy_fatal(rc, name, out, legacy_out_bytes<T>(s), !is_device_ptr(out));
 }
 
 template <typename T>
@@ -1185,7 +1204,7 @@ static void legacy_zconvolve(Setup* s, const T* a, const T* b, T* ab, T scaling,
     int rc = legacy_run<T>(s, ins, 2, ab, accumulate != 0, [&](const T* const* di, T* dout) {
         return zconvolve_batch<T>(s, di[0], di[1], dout, scaling, 1, accumulate, 0, nullptr);
     });
-    if (rc) legacy_fatal(rc, name, ab, s ? s->vec_scalars * sizeof(T) : 0, !is_device_ptr(ab));
+    if (rc) legacy_fatal(rc, name, ab, legacy_out_bytes<T>(s), !is_device_ptr(ab));
 }
 
 // Layout self-test standing in for validate_pffft_simd_ex (src/pffft_priv_impl.h:1889-2225, which

@@ -85,3 +85,21 @@ def tol_for(dt, N):
     while n % 2 == 0:
         n //= 2
     return 1e-12 if n == 1 else 2e-7
+
+
+def legal_sizes(transform, lo, hi):   # transform: 0 = PFFFT_REAL, 1 = PFFFT_COMPLEX
+    """N = nmin * 2^a * 3^b * 5^c in [lo, hi] (tests/test_fft_factors.c:36-61 walks the same set through is_valid_size)."""
+    nmin = 32 if transform == 0 else 16
+    out = []
+    a = 1
+    while nmin * a <= hi:
+        b = a
+        while nmin * b <= hi:
+            c = b
+            while nmin * c <= hi:
+                if nmin * c >= lo:
+                    out.append(nmin * c)
+                c *= 5
+            b *= 3
+        a *= 2
+    return sorted(out)

@@ -149,7 +149,18 @@ y = s.transform_ordered(x)
 assert np.isnan(y).all() and pa.error_count() == 2
 fc = pa.FastConv(np.ones(8, np.float32), 0, 0)
 yy, n = fc.apply(np.ones(100, np.float32))
-assert n == 0 and pa.error_count() == 3
+assert n == -1 and pa.error_count() == 3      # -1, never 0: a streaming caller must be able to tell failure from "no output yet"
+# a C caller that follows the reference's contract allocates inputLen - filterLen + 1 outputs (include/pffft/pffastconv.h:159):
+# the fail-soft fill must stay inside them (ADVICE r02: it used to fill inputLen floats)
+import ctypes as C
+L = pa.lib()
+xin = np.ones(100, np.float32); out = np.zeros(100, np.float32)
+n = L.pffastconv_apply(fc.handle, xin.ctypes.data, 100, out.ctypes.data, 1)
+assert n == -1 and np.isnan(out[:93]).all() and (out[93:] == 0).all(), out
+# an invalid handle writes nothing (the vector length would have to be read from the object that failed validation)
+z = np.zeros(64, np.float32)
+L.pffft_transform(None, x.ctypes.data, z.ctypes.data, None, 0)
+assert (z == 0).all() and pa.error_count() == 5
 print("FAILSOFT-OK")
 """
 
@@ -169,3 +180,18 @@ def test_legacy_entries_fail_soft_without_a_device():
     env["PFFFT_HIP_ABORT"] = "1"
     p = subprocess.run([sys.executable, "-c", _FAILSOFT], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode < 0 and "FAILSOFT-OK" not in p.stdout     # killed by SIGABRT: fail-fast on request only
+
+
+def test_legal_size_enumeration_matches_the_library():
+    """tests/test_gpu_round3.py walks conftest.legal_sizes(): exactly what the drop-in's is_valid_size accepts, which is
+    the reference's set (tests/test_fft_factors.c:36-61; the reference program itself runs in test_reference_programs)."""
+    from conftest import legal_sizes
+    L = pa.lib()
+    for tr in (pa.REAL, pa.COMPLEX):
+        nmin = 32 if tr == pa.REAL else 16
+        mine = set(legal_sizes(tr, 0, 1 << 16))
+        assert mine == {N for N in range(nmin, (1 << 16) + 1, nmin) if L.pffft_is_valid_size(N, tr)}
+        for N in sorted(mine)[::9]:
+            s = L.pffft_new_setup(N, tr)
+            assert s, N
+            L.pffft_destroy_setup(s)

@@ -37,7 +37,8 @@ def test_c5_full_batch_per_gpu(ref):
     s = pa.Setup(N, pa.COMPLEX, np.float64)
     x = _uniform((B, 2 * N), 5, torch.float64)
     y = s.transform_batch(x, None, pa.FORWARD, False)
-    idx = torch.tensor([0, 1, 7, 8, 9, 63, 64, 65, B // 2, B - 2, B - 1] + list(range(1000, B, 104729))).cuda()
+    idx = torch.tensor(sorted({0, 1, 7, 8, 9, 63, 64, 65, B // 2, B - 2, B - 1} | set(range(1000, B, 251)))).cuda()
+    assert idx.numel() >= 4096                                # >= 4096 sampled transforms
     rs = ref.setup(N, 1, np.float64)
     assert relerr(y[idx].cpu().numpy(), rs.batch(x[idx].cpu().numpy(), 0, False)) <= 1e-12
     # Parseval per transform over the WHOLE batch, in slices (layout independent)
@@ -62,7 +63,8 @@ def test_c5_strong_scaling_one_gpu_in_place(ref):
         pytest.fail(f"needs 128 GiB + margin of HBM, {free >> 30} GiB free")
     s = pa.Setup(N, pa.COMPLEX, np.float64)
     x = _uniform((B, 2 * N), 55, torch.float64)
-    idx = torch.tensor([0, 1, 2, B // 3, B // 2, B - 2, B - 1] + list(range(12345, B, 1000003))).cuda()
+    idx = torch.tensor(sorted({0, 1, 2, B // 3, B // 2, B - 2, B - 1} | set(range(12345, B, 2039)))).cuda()
+    assert idx.numel() >= 4096                                # >= 4096 sampled transforms
     keep = x[idx].cpu().numpy()
     e_in = (x[: 1 << 16] ** 2).sum(1)
     s.transform_batch(x, x, pa.FORWARD, False)
@@ -508,7 +510,7 @@ def test_streaming_passes_for_sizes_beyond_the_stockham_plans(ref, dt, tr, N):
     tdt = torch.float32 if dt == "f32" else torch.float64
     s = pa.Setup(N, tr, dtype)
     rs = ref.setup(N, tr, dtype)
-    tol = tol_for(dt, N) * (4 if dt == "f32" else 1)      # float error grows ~ sqrt(log N); the bar stays 1e-5-class
+    tol = tol_for(dt, N)                                  # north_star's bar, flat: 1e-5 float whatever N
     x = _uniform((3, s.vec_scalars), 700 + N % 997, tdt)
     xh = x.cpu().numpy()
     for d in (pa.FORWARD, pa.BACKWARD):

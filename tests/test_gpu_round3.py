@@ -1,0 +1,93 @@
+"""GPU parity tests (-m gpu), round 3: the whole accepted-size set.
+
+The reference accepts every N = nmin * 2^a * 3^b * 5^c (src/pffft_priv_impl.h:91-114; its own enumeration:
+tests/test_fft_factors.c:36-61).  Routing here is six kernel families plus a factor-choice heuristic, so hand-picked
+size lists leave room for a size that falls between the families: this file walks EVERY legal size up to 2^18 (and every
+7th legal size from there to 2^21), both precisions, real and complex, all four direction x layout combinations on a
+ragged batch, against oracle/_ref (the reference's own object code) — and asserts the kernel family each size is
+expected to run on, restated here from DESIGN.md §3 independently of the library's planner.
+Bars: 1e-5 float / 1e-12 double per transform (tests/conftest.py: tol_for states the one documented exception)."""
+import numpy as np
+import pytest
+
+from conftest import legal_sizes, relerr, tol_for
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import pffft_amd as pa  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available() or pa.device_count() < 1:
+        pytest.fail("GPU tests need a HIP device: the product has no CPU fallback")
+    torch.cuda.set_device(0)
+
+
+def expected_family(N, transform, dt):
+    """DESIGN.md §3, restated: which kernel family a size must run on (n = complex points of the core transform)."""
+    n = N if transform == pa.COMPLEX else N // 2
+    esz = 8 if dt == "f32" else 16
+    if n == 16 or (n == 32 and dt == "f32"):
+        return "tiny"
+    if dt == "f32" and transform == pa.COMPLEX and N == 1024:
+        return "c1024_f32"
+    if n & (n - 1) == 0:
+        return "tiled" if n * esz <= 128 * 1024 else "fourstep"
+    # mixed-radix Stockham plans: two exchange images in LDS (n * esz <= 80 000 B); n = 16 * 3^5 (* 2) has no plan in
+    # radices 3 .. 24 within four stages and takes the streaming passes
+    if n * esz <= 80000 and n not in (3888, 7776):
+        return "stockham"
+    return "fourstep"
+
+
+def _uniform(shape, seed, tdt):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    x = torch.empty(shape, device="cuda", dtype=tdt)
+    x.uniform_(-1.0, 1.0, generator=g)
+    return x
+
+
+def _check_size(ref, N, tr, dt, batch):
+    dtype = np.float32 if dt == "f32" else np.float64
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    s = pa.Setup(N, tr, dtype)
+    assert pa.kernel_name(s) == expected_family(N, tr, dt), (dt, tr, N, pa.kernel_name(s))
+    rs = ref.setup(N, tr, dtype)
+    tol = tol_for(dt, N)
+    x = _uniform((batch, s.vec_scalars), 3000 + N % 9973, tdt)
+    xh = x.cpu().numpy()
+    worst = 0.0
+    for d in (pa.FORWARD, pa.BACKWARD):
+        for o in (False, True):
+            got = s.transform_batch(x, None, d, o).cpu().numpy()
+            e = relerr(got, rs.batch(xh, d, o))
+            assert e <= tol, (dt, tr, N, d, o, e)
+            worst = max(worst, e)
+    s.close(); rs.close()
+    return worst
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("tr", [pa.COMPLEX, pa.REAL])
+def test_every_legal_size_up_to_2p18(ref, dt, tr):
+    sizes = legal_sizes(tr, 0, 1 << 18)
+    assert len(sizes) > 150 and sizes[0] == (32 if tr == pa.REAL else 16) and sizes[-1] == 1 << 18
+    fams = {}
+    for N in sizes:
+        _check_size(ref, N, tr, dt, batch=3 if N <= 65536 else 2)
+        f = expected_family(N, tr, dt)
+        fams[f] = fams.get(f, 0) + 1
+    # every family is exercised by the walk
+    want = {"tiny", "tiled", "stockham", "fourstep"} | ({"c1024_f32"} if (dt == "f32" and tr == pa.COMPLEX) else set())
+    assert set(fams) == want, fams
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("tr", [pa.COMPLEX, pa.REAL])
+def test_a_stride_of_legal_sizes_up_to_2p21(ref, dt, tr):
+    sizes = legal_sizes(tr, (1 << 18) + 1, 1 << 21)[::7]
+    assert len(sizes) >= 10
+    for N in sizes:
+        _check_size(ref, N, tr, dt, batch=2)
