@@ -24,7 +24,14 @@ Prints ONE JSON line on rank 0.  `value` = whole-job throughput with inputs resi
 8 B per FIR output sample) against 8 TB/s.  `cpu_baseline` times the real reference (oracle/_ref) on the
 host cores of this box on a bounded sample of the same workload (test infrastructure, never the product).
 At N = 1 the default line also carries `configs`: every other BASELINE config at its stated size, each with
-its own `roofline` and `cpu_baseline`; at N > 1 it carries the C5 sharded config, weak and strong.
+its own `roofline` and `cpu_baseline` (no warm-up beyond --warmup; the first launches of each are reported as
+`first_launches_ms` next to the timed region), and `sizes`: the reference's benchmark table
+(benchmarks/bench_pffft.c:445,547-550,1140-1150: every size of its lists, real and complex, float and double, ordered and
+unordered, forward and backward).  All GPU work runs back to back, the CPU baselines afterwards (an idle gap between
+configs lets the clocks drop and the next config starts cold).  At N > 1 the line carries the C5 sharded config, weak and
+strong, `ranks_seen` from the RCCL all-reduce and the fastest / slowest rank's ms_per_step.
+Inputs are a counter hash of (seed, GLOBAL element index) (pffft_amd/sharding.py): a shard holds the same data whatever
+the number of ranks, and the in-run parity check rebuilds its sampled vectors on the host from their indices.
 """
 from __future__ import annotations
 
@@ -206,112 +213,183 @@ class Timer:
         return a.elapsed_time(b) * 1e-3 / reps
 
 
-def roofline(alg_bytes_per_launch, kernel_s, traffic=None):
+def source_hash():
+    """sha256 over the kernel sources (pffft_amd/csrc/*.h, *.hip): identifies the build a PMC capture belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pffft_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def roofline(alg_bytes_per_launch, kernel_s, traffic_key=None):
+    """`traffic` cannot be measured inside this run (PMC counters need rocprofv3 around the process): it is the figure of
+    the last `rocprofv3 --pmc` capture of the same command (tools/profile_r03.sh -> profiles/pmc_traffic.json), and
+    `traffic_source` says so, with the source hash of the build it was captured on and whether that is this build."""
     ach = alg_bytes_per_launch / kernel_s
-    return {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK, 4), "traffic": traffic, "kernel_ms": round(kernel_s * 1e3, 4),
-            "algorithmic_bytes_per_launch": int(alg_bytes_per_launch)}
+    out = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK, 4), "traffic": None, "kernel_ms": round(kernel_s * 1e3, 4),
+           "algorithmic_bytes_per_launch": int(alg_bytes_per_launch)}
+    if traffic_key:
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            v = rec.get(traffic_key)
+            if v is not None:
+                cap = rec.get("source_hash")
+                out["traffic"] = int(round(v))
+                out["traffic_source"] = ("replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                         f"captured {rec.get('captured', '?')} on source hash {cap}); not measured in this run; "
+                                         f"this build: {source_hash()} ({'same build' if cap == source_hash() else 'DIFFERENT build'})")
+        except Exception:
+            pass
+    return out
 
 
-def _traffic(key):
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc
-    try:
-        return json.load(open(p)).get(key)
-    except Exception:
-        return None
-
-
-def make_input(torch, dev, batch, vec_scalars, tdt, seed):
-    """Uniform [-1, 1) from torch's counter-based (Philox) generator, generated on the device, in place."""
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
+def make_input(torch, dev, batch, vec_scalars, tdt, seed, first_vector=0):
+    """Uniform [-1, 1): counter hash of (seed, GLOBAL element index), generated on the device (pffft_amd/sharding.py).
+    `first_vector` = global index of this shard's first vector: the same vectors whatever the number of ranks."""
+    from pffft_amd.sharding import global_uniform_
     x = torch.empty(batch, vec_scalars, device=dev, dtype=tdt)
-    x.uniform_(-1.0, 1.0, generator=gen)
-    return x
+    return global_uniform_(x, first_vector * vec_scalars, seed)
 
 
-def fft_config_run(torch, pa, dev, cfg, batch, steps, warmup, in_place, dist, rank):
+def make_input_into(torch, x, seed, first_vector=0):
+    from pffft_amd.sharding import global_uniform_
+    return global_uniform_(x, first_vector * x.shape[1], seed)
+
+
+def sample_indices(batch, want=4096):
+    """>= `want` transforms of a batch: both ends, the middle, and a stride over everything."""
+    step = max(1, batch // want)
+    return sorted({0, 1, batch // 2, batch - 2, batch - 1} & set(range(batch)) | set(range(3, batch, step)))
+
+
+def fft_config_run(torch, pa, dev, cfg, batch, first_vector, steps, warmup, in_place, dist, rank, seed):
     """One FFT config on this rank's shard: W warm-up + K timed steps inside the barrier bracket.
-    Returns (elapsed_s of this rank, kernel_s from HIP events, kernel name, parity)."""
-    from pffft_amd.sharding import timed_steps
+    Returns (elapsed_s of this rank, kernel_s from HIP events, kernel name, parity, first launches in ms)."""
+    from pffft_amd.sharding import global_uniform_np, timed_steps
     dt = _np_dtype(cfg["dtype"])
     tdt = torch.float64 if cfg["dtype"] == "f64" else torch.float32
     setup = pa.Setup(cfg["N"], cfg["tr"], dt)
-    x = make_input(torch, dev, batch, setup.vec_scalars, tdt, seed=2 + rank)
+    vs = setup.vec_scalars
+    x = make_input(torch, dev, batch, vs, tdt, seed, first_vector)
     y = x if in_place else torch.empty_like(x)
-    # parity spot check against the real reference when it travelled (outside the timed region; tests/ are the gate)
-    parity = None
-    idx = sorted({0, 1, batch // 2, batch - 1})
-    x_keep = x[idx].cpu().numpy()
 
     def step():
         setup.transform_batch(x, y, pa.FORWARD, ordered=False)
 
-    if not in_place:
-        step()
-        torch.cuda.synchronize()
-        try:
-            from oracle import ref as oref
-            if oref.available():
-                rs = oref.get().setup(cfg["N"], cfg["tr"], dt)
-                want = rs.batch(x_keep, oref.FORWARD, False)
-                got = y[idx].cpu().numpy()
-                parity = float(max(np.abs(got[i] - want[i]).max() / np.abs(want[i]).max() for i in range(len(idx))))
-                rs.close()
-        except Exception as e:
-            parity = f"unchecked: {e}"
+    # the first launches of this kernel on these buffers, timed one by one (cold: clocks, TLBs).  They ARE the first warm-up
+    # steps: the untimed launches before the timed region add up to exactly `warmup`.
+    ncold = min(6, warmup)
+    first = []
+    for _ in range(ncold):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); step(); b.record()
+        first.append((a, b))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     count = [0]
+    rest = warmup - ncold
 
     def timed_step():
-        if count[0] == warmup:
+        if count[0] == rest:
             e0.record()
         step()
         count[0] += 1
-        if count[0] == warmup + steps:
+        if count[0] == rest + steps:
             e1.record()
 
-    elapsed = timed_steps(timed_step, steps, warmup, dist, torch.cuda.synchronize)
+    elapsed = timed_steps(timed_step, steps, rest, dist, torch.cuda.synchronize)
     kernel_s = e0.elapsed_time(e1) * 1e-3 / steps
+    first_ms = [round(a.elapsed_time(b), 4) for a, b in first]
+    # parity against the real reference when it travelled, AFTER the timed region (host work before it would leave the GPU
+    # idle and the timed region cold): >= 4096 sampled transforms whose inputs are rebuilt on the host from their GLOBAL
+    # indices.  In place: the buffer is regenerated and transformed once more.  (tests/ are the gate.)
+    parity = None
+    idx = sample_indices(batch)
+    try:
+        from oracle import ref as oref
+        if oref.available():
+            if in_place:
+                make_input_into(torch, x, seed, first_vector)
+                step()
+            torch.cuda.synchronize()
+            rs = oref.get().setup(cfg["N"], cfg["tr"], dt)
+            xin = np.stack([global_uniform_np((first_vector + i) * vs, vs, seed, dt) for i in idx])
+            want = rs.batch(xin, oref.FORWARD, False)
+            got = y[torch.tensor(idx, device=dev)].cpu().numpy()
+            num = np.abs(got.astype(np.float64) - want).max(axis=1)
+            parity = {"max_rel_err": float((num / np.abs(want).max(axis=1)).max()), "transforms_checked": len(idx)}
+            rs.close()
+    except Exception as e:
+        parity = f"unchecked: {e}"
     kname = pa.kernel_name(setup)
     setup.close()
     del x, y
     torch.cuda.empty_cache()
-    return elapsed, kernel_s, kname, parity
+    return elapsed, kernel_s, kname, parity, first_ms
 
 
-def nonpow2_sweep(torch, pa, dev, timer):
-    """The non-power-of-two sizes of the reference's benchmark list (benchmarks/bench_pffft.c:445) that VERDICT r01 named:
-    forward, unordered, float, 512 MiB of vectors per launch, 30 untimed + 30 timed launches; fraction of 8 TB/s on
-    2 x vector bytes.  Not a headline - a measured line per size for the mixed-radix (Stockham) kernel family."""
-    out = {"workload": "forward unordered float, 512 MiB per launch, roofline fraction per size"}
-    for tr, name, sizes in ((pa.COMPLEX, "complex", (96, 480, 800, 2400, 4000, 9216)), (pa.REAL, "real", (96, 480, 1600, 4000, 12000))):
-        row = {}
-        for N in sizes:
-            s = pa.Setup(N, tr, np.float32)
-            batch = (1 << 29) // (s.vec_scalars * 4)
-            x = make_input(torch, dev, batch, s.vec_scalars, torch.float32, seed=7)
-            y = torch.empty_like(x)
-            t = timer(lambda: s.transform_batch(x, y, pa.FORWARD, ordered=False), 30, warm=30)
-            row[str(N)] = round(2 * x.numel() * 4 / t / HBM_PEAK, 3)
-            s.close()
-            del x, y
-            torch.cuda.empty_cache()
-        out[name] = row
+# the reference's benchmark lists (benchmarks/bench_pffft.c:1140-1150 with powers of two, :1153-1171)
+REF_SIZES = [64, 96, 128, 160, 192, 256, 384, 480, 512, 640, 768, 800, 1024, 2048, 2400, 4096, 8192, 9216, 16384, 32768,
+             262144, 1048576]
+
+
+def sizes_table(torch, pa, dev, timer):
+    """The reference's benchmark table (benchmarks/bench_pffft.c:445,547-550: every size of its lists, real and complex,
+    "PFFFT" = ordered and "PFFFT-U" = unordered, forward and backward - the reference times the pair; both halves are listed
+    here) in float and double: 1 GiB of vectors per launch, 10 untimed + 20 timed launches, fraction of 8 TB/s on
+    2 x vector bytes per transform (a 256 MiB launch lasts ~80 us: start-up, tail and the gap to the next launch cost 15-20 %).  One line per kernel family and layout, so that a regression shows up in the driver's
+    record without profiles/."""
+    out = {"workload": "1 GiB of vectors per launch, 10 + 20 launches; [fwd ordered, fwd unordered, bwd ordered, bwd unordered] "
+                       "as fractions of 8 TB/s on 2 x vector bytes",
+           "sizes": REF_SIZES}
+    for tag, dt, tdt in (("f32", np.float32, torch.float32), ("f64", np.float64, torch.float64)):
+        isz = np.dtype(dt).itemsize
+        pool = make_input(torch, dev, 1, (1 << 30) // isz, tdt, seed=7).reshape(-1)
+        ypool = torch.empty_like(pool)
+        for tr, name in ((pa.COMPLEX, "complex"), (pa.REAL, "real")):
+            tab = {}
+            for N in REF_SIZES:
+                s = pa.Setup(N, tr, dt)
+                batch = max(1, pool.numel() // s.vec_scalars)
+                x = pool[: batch * s.vec_scalars].view(batch, s.vec_scalars)
+                y = ypool[: batch * s.vec_scalars].view(batch, s.vec_scalars)
+                row = []
+                for d in (pa.FORWARD, pa.BACKWARD):
+                    for o in (True, False):
+                        t = timer(lambda: s.transform_batch(x, y, d, ordered=o), 20, warm=10)
+                        row.append(round(2 * x.numel() * isz / t / HBM_PEAK, 3))
+                tab[str(N)] = row
+                s.close()
+            out[f"{tag}_{name}"] = tab
+        del pool, ypool
+        torch.cuda.empty_cache()
     return out
 
 
-def fir_config(torch, pa, dev, timer, cpu_seconds):
+VALU_PEAK = 108.0 * 256 * 2.4e9   # float results / s: 108 per clock and CU measured (profiles/r02_probes.md), 256 CUs, 2.4 GHz
+
+
+def fir_flops_per_output(nfft, taps):
+    """per block 2 x (2.5 Nfft log2 Nfft) + 6 (Nfft / 2) + Nfft flops, Nfft - taps + 1 outputs."""
+    return (5.0 * nfft * np.log2(nfft) + 3.0 * nfft + nfft) / (nfft - taps + 1)
+
+
+def fir_config(torch, pa, dev, timer, warmup):
     """BASELINE configs[3].  The single 2^20-sample call is latency-bound (255 blocks); the throughput regime is
     measured on (i) a batch of independent 2^20-sample signals through pffastconv_hip_apply_batch and (ii) one
-    2^26-sample signal — `roofline` is (ii): 8 B per output sample (read x once, write y once)."""
+    2^26-sample signal — `roofline` is (ii): 8 B per output sample (read x once, write y once), with a second leg
+    `roofline_valu` that prices the same run against the measured VALU peak (at 4096 taps the arithmetic binds before HBM).
+    Returns (record, closure that adds the CPU baseline later)."""
     taps, L = FIR["taps"], 1 << FIR["signal_log2"]
     h = np.random.default_rng(4).uniform(-1, 1, taps).astype(np.float32)
     out = {"workload": FIR["name"]}
     fc = pa.FastConv(h, 0, 0)
     sig = make_input(torch, dev, 1, L, torch.float32, seed=4).reshape(-1)
     y = torch.empty_like(sig)
-    t = timer(lambda: fc.apply(sig, True, out=y), 200, warm=3)
+    t = timer(lambda: fc.apply(sig, True, out=y), 200, warm=max(3, warmup))
     n_out = L - taps + 1
     out["single_call_us"] = round(t * 1e6, 2)
     out["single_call_Gsamples_per_s"] = round(n_out / t / 1e9, 2)
@@ -330,7 +408,7 @@ def fir_config(torch, pa, dev, timer, cpu_seconds):
         nsig = 256
         xs = make_input(torch, dev, nsig, L, torch.float32, seed=5)
         ys = torch.empty_like(xs)
-        t = timer(lambda: fc.apply_batch(xs, True, out=ys), 20, warm=8)
+        t = timer(lambda: fc.apply_batch(xs, True, out=ys), 20, warm=warmup)
         out["batch_signals"] = nsig
         out["batch_Gsamples_per_s"] = round(nsig * n_out / t / 1e9, 2)
         out["batch_frac"] = round(8 * nsig * n_out / t / HBM_PEAK, 4)
@@ -338,19 +416,31 @@ def fir_config(torch, pa, dev, timer, cpu_seconds):
     Ll = 1 << FIR["long_log2"]
     xl = make_input(torch, dev, 1, Ll, torch.float32, seed=6).reshape(-1)
     yl = torch.empty_like(xl)
-    t = timer(lambda: fc.apply(xl, True, out=yl), 40, warm=20)   # steady state: the first ~15 launches of a kernel ramp up
+    first = []
+    for _ in range(6):
+        first.append(round(timer(lambda: fc.apply(xl, True, out=yl), 1, warm=0) * 1e3, 4))
+    t = timer(lambda: fc.apply(xl, True, out=yl), 40, warm=warmup)
     nl = Ll - taps + 1
     out["value"] = round(nl / t / 1e9, 2)
     out["unit"] = "G output samples/s"
     out["long_signal"] = f"2^{FIR['long_log2']} samples, {taps} taps"
-    out["roofline"] = roofline(8 * nl, t, _traffic("c4_long_bytes_per_launch"))
+    out["first_launches_ms"] = first
+    out["roofline"] = roofline(8 * nl, t, "c4_long_bytes_per_launch")
+    nfft_used = 16384 if taps >= 1024 else 8192    # internal block of the throughput regime (pffastconv_impl.h fc_big_nfft)
+    fl = fir_flops_per_output(nfft_used, taps) * nl
+    out["roofline_valu"] = {"bound": "valu", "achieved": round(fl / t / 1e12, 2), "peak": round(VALU_PEAK / 1e12, 1), "unit": "TFLOP/s",
+                            "frac": round(fl / t / VALU_PEAK, 4), "flops_per_output_sample": round(fl / nl, 1),
+                            "note": f"SURVEY.md 8(d) C4 flop count at the internal block length {nfft_used}; peak = 108 float results "
+                                    "per clock and CU measured (profiles/r02_probes.md) x 256 CUs x 2.4 GHz, one flop per result"}
     fc.close()
     del xl, yl, sig, y
     torch.cuda.empty_cache()
-    cb = cpu_baseline_fir(x_host, h, cpu_seconds) if cpu_seconds > 0 else None
-    out["cpu_baseline"] = cb if cb else {"value": None, "unit": "G output samples/s", "cores": 0, "kind": "reference",
-                                         "sample": "oracle/_ref not present on this box"}
-    return out
+
+    def add_cpu(cpu_seconds):
+        cb = cpu_baseline_fir(x_host, h, cpu_seconds) if cpu_seconds > 0 else None
+        out["cpu_baseline"] = cb if cb else {"value": None, "unit": "G output samples/s", "cores": 0, "kind": "reference",
+                                             "sample": "oracle/_ref not present on this box"}
+    return out, add_cpu
 
 
 def fake_main(args, world, rank):
@@ -358,16 +448,20 @@ def fake_main(args, world, rank):
     itself has no CPU implementation in the product."""
     import torch
     import torch.distributed as dist
-    from pffft_amd.sharding import combine, timed_steps
+    from pffft_amd.sharding import combine_stats, timed_steps
     if world > 1:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     units = 1000.0
     x = np.random.default_rng(rank).standard_normal((64, 64))
     el = timed_steps(lambda: np.fft.fft(x, axis=1), args.steps, args.warmup, dist if world > 1 else None, None)
-    el, tot = combine(el, units, dist if world > 1 else None, torch.device("cpu"))
+    st = combine_stats(el, units, dist if world > 1 else None, torch.device("cpu"))
+    el, tot = st["elapsed_max"], st["units"]
     if rank == 0:
         print(json.dumps({"metric": "harness self-test (no transform ran)", "value": tot * args.steps / el, "unit": "units/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "selftest": True}), flush=True)
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "selftest": True,
+                          "ranks_seen": st["ranks_seen"],
+                          "ms_per_step_fastest_rank": round(st["elapsed_min"] / args.steps * 1e3, 4),
+                          "ms_per_step_slowest_rank": round(st["elapsed_max"] / args.steps * 1e3, 4)}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -422,38 +516,49 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
-    from pffft_amd.sharding import combine, shard_range
+    from pffft_amd.sharding import combine_stats, shard_range
     timer = Timer(torch)
     cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
+    SEEDS = {"c2": 2, "c3": 3, "c5": 5}
 
     def run_fft(key, scaling, steps, warmup, batch_log2=None):
         cfg = CONFIGS[key]
         if scaling == "strong":
             total = 1 << cfg["total_log2"]
-            _, batch = shard_range(total, rank, world)
+            first, batch = shard_range(total, rank, world)
             in_place = True
         else:
             batch = 1 << (batch_log2 if batch_log2 is not None else cfg["batch_log2"])
+            first = rank * batch                # weak scaling: rank r holds global vectors [r * batch, (r + 1) * batch)
             in_place = False
-        el, ks, kname, parity = fft_config_run(torch, pa, dev, cfg, batch, steps, warmup, in_place, dist, rank)
-        el, tot = combine(el, float(batch), dist, dev)
+        el, ks, kname, parity, first_ms = fft_config_run(torch, pa, dev, cfg, batch, first, steps, warmup, in_place, dist, rank,
+                                                         SEEDS[key])
+        st = combine_stats(el, float(batch), dist, dev)
+        el, tot = st["elapsed_max"], st["units"]
         tps = tot * steps / el
-        return {
+        rec = {
             "value": round(tps / 1e6, 3), "unit": "M transforms/s", "ms_per_step": round(el / steps * 1e3, 4),
-            "steps": steps, "scaling": scaling, "dtype": cfg["dtype"], "gflops": round(tps * cfg["flops"] / 1e9, 1),
+            "steps": steps, "warmup": warmup, "scaling": scaling, "dtype": cfg["dtype"], "gflops": round(tps * cfg["flops"] / 1e9, 1),
             "workload": f"{cfg['name']}, batch={'2^%d total / %d GPU(s), in place' % (cfg['total_log2'], world) if scaling == 'strong' else '2^%d per GPU, out of place' % int(np.log2(batch))}, "
                         "device-resident, internal-layout spectrum",
-            "kernel": kname, "batch_per_gpu": batch,
-            "roofline": roofline(batch * cfg["bytes"], ks, _traffic(key + "_bytes_per_launch")),
-            "parity_max_rel_err_vs_reference": parity,
+            "kernel": kname, "batch_per_gpu": batch, "first_global_vector_of_rank0": first,
+            "roofline": roofline(batch * cfg["bytes"], ks, key + "_bytes_per_launch"),
+            "first_launches_ms": first_ms,
+            "parity_vs_reference": parity,
         }
+        if world > 1:
+            rec["ranks_seen"] = st["ranks_seen"]
+            rec["ms_per_step_fastest_rank"] = round(st["elapsed_min"] / steps * 1e3, 4)
+            rec["ms_per_step_slowest_rank"] = round(st["elapsed_max"] / steps * 1e3, 4)
+        return rec
 
     if args.config == "c4":
         if world > 1:
             raise SystemExit("bench.py: c4 (one 8 MiB signal) does not shard: replicas only (DESIGN.md §5)")
-        res = fir_config(torch, pa, dev, timer, cpu_s)
+        res, add_cpu = fir_config(torch, pa, dev, timer, args.warmup)
+        add_cpu(cpu_s)
         line = {"metric": "G output samples/s, pffastconv overlap-save FIR, 4096 taps", "value": res["value"],
-                "unit": res["unit"], "n_gpus": 1, "steps": 10, "warmup": 2,
+                "unit": res["unit"], "n_gpus": 1, "steps": 40, "warmup": args.warmup,
                 "ms_per_step": res["roofline"]["kernel_ms"], "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": res.pop("workload")}}
         line.update(res)
@@ -470,13 +575,19 @@ def main():
             "value": head["value"], "unit": "M transforms/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": cfg["dtype"],
-            "data": "synthetic" + (" (HARNESS TEST: ranks share GPUs, not a reportable number)" if share else ""),
+            "data": "synthetic: counter hash of (seed, global element index), uniform [-1, 1)"
+                    + (" (HARNESS TEST: ranks share GPUs, not a reportable number)" if share else ""),
             "gflops": head["gflops"],
             "config": {"workload": head["workload"], "kernel": head["kernel"], "batch_per_gpu": head["batch_per_gpu"],
                        "sharding": "batch-split, no data-path collective; RCCL for the final MAX/SUM only"},
-            "roofline": head["roofline"], "parity_max_rel_err_vs_reference": head["parity_max_rel_err_vs_reference"],
+            "roofline": head["roofline"], "first_launches_ms": head["first_launches_ms"],
+            "parity_vs_reference": head["parity_vs_reference"], "source_hash": source_hash(),
         }
+        for k in ("ranks_seen", "ms_per_step_fastest_rank", "ms_per_step_slowest_rank"):
+            if k in head:
+                out[k] = head[k]
     extras, configs = {}, {}
+    cpu_jobs = []        # CPU baselines run AFTER all GPU work: an idle GPU between configs drops its clocks
     if not args.no_extras and args.config == "c2" and args.scaling == "weak":
         if world == 1:
             # side rates of the headline kernel family + every other BASELINE config at its stated size
@@ -500,15 +611,16 @@ def main():
             setup.close()
             del x, y
             torch.cuda.empty_cache()
-            # 20 untimed warm-up launches: the first ~15 launches of a kernel climb from ~0.55 to the steady rate
-            # (tools/c3_ramp.py: clocks / TLB reach steady state after ~30 ms), the timed region is steady state
+            # the other BASELINE configs: no warm-up beyond --warmup (their first launches are listed in first_launches_ms)
             for key, st in (("c3", 100), ("c5", 40)):
                 try:
-                    configs[key] = run_fft(key, "weak", st, 20)
-                    if cpu_s > 0:
+                    configs[key] = run_fft(key, "weak", st, args.warmup)
+
+                    def job(key=key):
                         cb = cpu_baseline(CONFIGS[key], 10 if key == "c3" else 14, min(cpu_s, 5.0))
                         configs[key]["cpu_baseline"] = cb if cb else {"value": None, "unit": "M transforms/s", "cores": 0,
                                                                       "kind": "reference", "sample": "oracle/_ref not present"}
+                    cpu_jobs.append(job)
                 except Exception as e:
                     configs[key] = {"error": str(e)[:300]}
             try:
@@ -516,22 +628,28 @@ def main():
             except Exception as e:
                 configs["c5_strong_1gpu"] = {"error": str(e)[:300]}
             try:
-                configs["c4"] = fir_config(torch, pa, dev, timer, min(cpu_s, 5.0))
+                configs["c4"], add_cpu = fir_config(torch, pa, dev, timer, args.warmup)
+                cpu_jobs.append(lambda: add_cpu(min(cpu_s, 5.0)))
             except Exception as e:
                 configs["c4"] = {"error": str(e)[:300]}
             try:
-                configs["nonpow2"] = nonpow2_sweep(torch, pa, dev, timer)
+                configs["sizes"] = sizes_table(torch, pa, dev, timer)
             except Exception as e:
-                configs["nonpow2"] = {"error": str(e)[:300]}
+                configs["sizes"] = {"error": str(e)[:300]}
         else:
             # BASELINE configs[4]: the double-precision config sharded over the same ranks, weak and strong
             for name, sc, st in (("c5_weak", "weak", 40), ("c5_strong", "strong", 8)):
-                configs[name] = run_fft("c5", sc, st, 10 if sc == "weak" else 2)   # collective inside: every rank runs it
+                configs[name] = run_fft("c5", sc, st, args.warmup if sc == "weak" else 2)   # collective inside: every rank runs it
     if rank == 0:
         out.update(extras)
         if configs:
             out["configs"] = configs
         if world == 1 and cpu_s > 0:
+            for job in cpu_jobs:
+                try:
+                    job()
+                except Exception as e:
+                    out.setdefault("cpu_baseline_errors", []).append(str(e)[:200])
             cb = cpu_baseline(cfg, 15 if cfg["N"] <= 1024 else 10, cpu_s)
             out["cpu_baseline"] = cb if cb else {"value": None, "unit": "M transforms/s", "cores": 0, "kind": "reference",
                                                  "sample": "oracle/_ref not present on this box"}

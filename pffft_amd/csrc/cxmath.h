@@ -38,21 +38,100 @@ template <typename V> __device__ __forceinline__ V conj(V a) { return mk<sc<V>>(
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// ---- packed FP32 with operand swizzles --------------------------------------------------------------------------------
+// gfx950's v_pk_{add,mul,fma}_f32 take, per source, which 32-bit half feeds the low / the high result (op_sel / op_sel_hi)
+// and a sign per half (neg_lo / neg_hi).  A complex product is then TWO instructions and "a +- i b" ONE; left to itself the
+// compiler packs the arithmetic but builds the swapped / negated operands with v_mov + v_xor first (n = 8192 real forward:
+// 219 v_mov + 148 v_xor next to 1045 packed operations).  Each helper computes exactly the operations of its scalar twin
+// below (same products, same fused multiply-adds, exact sign flips), so float results are bit-identical to the unfused form.
+#ifndef PF_NO_PK_SWIZZLE
+#define PF_PK(name, text)                                                                                   \
+    __device__ __forceinline__ vec2<float> name(vec2<float> a, vec2<float> b) {                             \
+        vec2<float> r;                                                                                      \
+        asm(text : "=v"(r) : "v"(a), "v"(b));                                                              \
+        return r;                                                                                           \
+    }
+PF_PK(pk_add_mib, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")   // a - i b = (a.x + b.y, a.y - b.x)
+PF_PK(pk_add_pib, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")   // a + i b = (a.x - b.y, a.y + b.x)
+PF_PK(pk_add_cj, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]")                                  // a + conj(b)
+PF_PK(pk_sub_cj, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]")                                  // a - conj(b)
+PF_PK(pk_mul_yy_yx_n, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]")   // (-a.y b.y, a.y b.x)
+PF_PK(pk_mul_yx_yy_n, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]")   // (a.y b.y, -a.x b.y)
+#undef PF_PK
+__device__ __forceinline__ vec2<float> pk_fma_xx_xy(vec2<float> a, vec2<float> b, vec2<float> c) {   // (a.x b.x + c.x, a.x b.y + c.y)
+    vec2<float> r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ vec2<float> pk_fma_xy_xx(vec2<float> a, vec2<float> b, vec2<float> c) {   // (a.x b.x + c.x, a.y b.x + c.y)
+    vec2<float> r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#endif
+
 // a * w
 template <typename V> __device__ __forceinline__ V cmul(V a, V w) {
+#ifndef PF_NO_PK_SWIZZLE
+    if constexpr (sizeof(sc<V>) == 4) return pk_fma_xx_xy(a, w, pk_mul_yy_yx_n(a, w));
+    else
+#endif
     return mk<sc<V>>(fma_(a.x, w.x, -(a.y * w.y)), fma_(a.x, w.y, a.y * w.x));
 }
 // a * conj(w)
 template <typename V> __device__ __forceinline__ V cmulc(V a, V w) {
+#ifndef PF_NO_PK_SWIZZLE
+    if constexpr (sizeof(sc<V>) == 4) return pk_fma_xy_xx(a, w, pk_mul_yx_yy_n(a, w));
+    else
+#endif
     return mk<sc<V>>(fma_(a.x, w.x, a.y * w.y), fma_(a.y, w.x, -(a.x * w.y)));
 }
 // a * w for the forward transform, a * conj(w) for the backward one (table holds exp(-i*theta))
 template <int DIR, typename V> __device__ __forceinline__ V twmul(V a, V w) {
     return DIR == FWD ? cmul(a, w) : cmulc(a, w);
 }
+// the same for a COMPILE-TIME constant w (the fixed twiddles inside radix 16 / 32 / 9 / 25 / 27): the scalar form lets the
+// compiler keep the constants in scalar registers / literals; an asm operand would pin each one in a VGPR pair.  Same
+// operations as cmul / cmulc.
+template <int DIR, typename V> __device__ __forceinline__ V twmul_c(V a, V w) {
+    return DIR == FWD ? mk<sc<V>>(fma_(a.x, w.x, -(a.y * w.y)), fma_(a.x, w.y, a.y * w.x))
+                      : mk<sc<V>>(fma_(a.x, w.x, a.y * w.y), fma_(a.y, w.x, -(a.x * w.y)));
+}
 // multiply by -i (forward) / +i (backward): the radix-4 "quarter turn"
 template <int DIR, typename V> __device__ __forceinline__ V rot(V a) {
     return DIR == FWD ? mk<sc<V>>(a.y, -a.x) : mk<sc<V>>(-a.y, a.x);
+}
+
+// a + rot<DIR>(b) and a - rot<DIR>(b) (forward: rot = -i): one packed add each in float
+template <int DIR, typename V> __device__ __forceinline__ V add_rot(V a, V b) {
+#ifndef PF_NO_PK_SWIZZLE
+    if constexpr (sizeof(sc<V>) == 4) return DIR == FWD ? pk_add_mib(a, b) : pk_add_pib(a, b);
+    else
+#endif
+    return a + rot<DIR>(b);
+}
+template <int DIR, typename V> __device__ __forceinline__ V sub_rot(V a, V b) {
+#ifndef PF_NO_PK_SWIZZLE
+    if constexpr (sizeof(sc<V>) == 4) return DIR == FWD ? pk_add_pib(a, b) : pk_add_mib(a, b);
+    else
+#endif
+    return a - rot<DIR>(b);
+}
+
+// a + conj(b), a - conj(b)
+template <typename V> __device__ __forceinline__ V add_conj(V a, V b) {
+#ifndef PF_NO_PK_SWIZZLE
+    if constexpr (sizeof(sc<V>) == 4) return pk_add_cj(a, b);
+    else
+#endif
+    return mk<sc<V>>(a.x + b.x, a.y - b.y);
+}
+template <typename V> __device__ __forceinline__ V sub_conj(V a, V b) {
+#ifndef PF_NO_PK_SWIZZLE
+    if constexpr (sizeof(sc<V>) == 4) return pk_sub_cj(a, b);
+    else
+#endif
+    return mk<sc<V>>(a.x - b.x, a.y + b.y);
 }
 
 template <int DIR, typename V> __device__ __forceinline__ void dft2(V& a0, V& a1) {
@@ -64,15 +143,22 @@ template <int DIR, typename V> __device__ __forceinline__ void dft3(V& a0, V& a1
     const T s3 = (T)0.86602540378443864676372317075294L;  // sin(2*pi/3)
     cx<T> t1 = a1 + a2;
     cx<T> m = mk<T>(fma_((T)-0.5, t1.x, a0.x), fma_((T)-0.5, t1.y, a0.y));
-    cx<T> d = rot<DIR>((a1 - a2) * s3);  // (-/+ i) * sin * (a1 - a2)
-    a0 = a0 + t1; a1 = m + d; a2 = m - d;
+    cx<T> e = (a1 - a2) * s3;            // d = (-/+ i) e
+    a0 = a0 + t1; a1 = add_rot<DIR>(m, e); a2 = sub_rot<DIR>(m, e);
 }
 
 template <int DIR, typename V>
 __device__ __forceinline__ void dft4(V& a0, V& a1, V& a2, V& a3) {
     typedef sc<V> T;
-    cx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<DIR>(a1 - a3);
-    a0 = t0 + t2; a1 = t1 + t3; a2 = t0 - t2; a3 = t1 - t3;
+    cx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d3 = a1 - a3;
+    a0 = t0 + t2; a1 = add_rot<DIR>(t1, d3); a2 = t0 - t2; a3 = sub_rot<DIR>(t1, d3);
+}
+// the same with the third input given BEFORE its quarter turn: transforms (a0, a1, rot(d2), a3)
+template <int DIR, typename V>
+__device__ __forceinline__ void dft4_r2(V& a0, V& a1, V& d2, V& a3) {
+    typedef sc<V> T;
+    cx<T> t0 = add_rot<DIR>(a0, d2), t1 = sub_rot<DIR>(a0, d2), t2 = a1 + a3, d3 = a1 - a3;
+    a0 = t0 + t2; a1 = add_rot<DIR>(t1, d3); d2 = t0 - t2; a3 = sub_rot<DIR>(t1, d3);
 }
 
 template <int DIR, typename V>
@@ -85,32 +171,43 @@ __device__ __forceinline__ void dft5(V& a0, V& a1, V& a2, V& a3, V& a4) {
     cx<T> p1 = a1 + a4, m1 = a1 - a4, p2 = a2 + a3, m2 = a2 - a3;
     cx<T> u1 = mk<T>(fma_(c2, p2.x, fma_(c1, p1.x, a0.x)), fma_(c2, p2.y, fma_(c1, p1.y, a0.y)));
     cx<T> u2 = mk<T>(fma_(c1, p2.x, fma_(c2, p1.x, a0.x)), fma_(c1, p2.y, fma_(c2, p1.y, a0.y)));
-    cx<T> v1 = rot<DIR>(mk<T>(fma_(s2, m2.x, s1 * m1.x), fma_(s2, m2.y, s1 * m1.y)));
-    cx<T> v2 = rot<DIR>(mk<T>(fma_(-s1, m2.x, s2 * m1.x), fma_(-s1, m2.y, s2 * m1.y)));
-    a0 = a0 + p1 + p2; a1 = u1 + v1; a4 = u1 - v1; a2 = u2 + v2; a3 = u2 - v2;
+    cx<T> e1 = mk<T>(fma_(s2, m2.x, s1 * m1.x), fma_(s2, m2.y, s1 * m1.y));      // v1 = (-/+ i) e1
+    cx<T> e2 = mk<T>(fma_(-s1, m2.x, s2 * m1.x), fma_(-s1, m2.y, s2 * m1.y));     // v2 = (-/+ i) e2
+    a0 = a0 + p1 + p2; a1 = add_rot<DIR>(u1, e1); a4 = sub_rot<DIR>(u1, e1); a2 = add_rot<DIR>(u2, e2); a3 = sub_rot<DIR>(u2, e2);
 }
 
 // a * exp(-/+ i*pi/4) and a * exp(-/+ 3i*pi/4)
 template <int DIR, typename V> __device__ __forceinline__ V mulw8_1(V a) {
     typedef sc<V> T;
     const T h = (T)0.70710678118654752440084436210485L;
+#ifndef PF_NO_PK_SWIZZLE
+    if constexpr (sizeof(T) == 4) return (DIR == FWD ? pk_add_mib(a, a) : pk_add_pib(a, a)) * h;   // (a -+ i a) h
+    else
+#endif
     return DIR == FWD ? mk<T>((a.x + a.y) * h, (a.y - a.x) * h) : mk<T>((a.x - a.y) * h, (a.x + a.y) * h);
 }
 template <int DIR, typename V> __device__ __forceinline__ V mulw8_3(V a) {
     typedef sc<V> T;
     const T h = (T)0.70710678118654752440084436210485L;
+#ifndef PF_NO_PK_SWIZZLE
+    if constexpr (sizeof(T) == 4) return (DIR == FWD ? pk_add_pib(a, a) : pk_add_mib(a, a)) * -h;  // -(a +- i a) h, signs exact
+    else
+#endif
     return DIR == FWD ? mk<T>((a.y - a.x) * h, -(a.x + a.y) * h) : mk<T>(-(a.x + a.y) * h, (a.x - a.y) * h);
 }
 
 // in-place radix-8, natural-order output (a[d] = sum_q a[q] W8^(q d))
-template <int DIR, typename V> __device__ __forceinline__ void dft8(V (&a)[8]) {
+// R4: a[4] is given BEFORE its quarter turn (radix 16 hands its c[4] over that way)
+template <int DIR, bool R4 = false, typename V> __device__ __forceinline__ void dft8(V (&a)[8]) {
     typedef sc<V> T;
-    cx<T> b0 = a[0] + a[4], c0 = a[0] - a[4];
+    cx<T> b0, c0;
+    if constexpr (R4) { b0 = add_rot<DIR>(a[0], a[4]); c0 = sub_rot<DIR>(a[0], a[4]); }
+    else { b0 = a[0] + a[4]; c0 = a[0] - a[4]; }
     cx<T> b1 = a[1] + a[5], c1 = mulw8_1<DIR>(a[1] - a[5]);
-    cx<T> b2 = a[2] + a[6], c2 = rot<DIR>(a[2] - a[6]);
+    cx<T> b2 = a[2] + a[6], c2 = a[2] - a[6];          // (its quarter turn is folded into dft4_r2)
     cx<T> b3 = a[3] + a[7], c3 = mulw8_3<DIR>(a[3] - a[7]);
     dft4<DIR>(b0, b1, b2, b3);
-    dft4<DIR>(c0, c1, c2, c3);
+    dft4_r2<DIR>(c0, c1, c2, c3);
     a[0] = b0; a[2] = b1; a[4] = b2; a[6] = b3;
     a[1] = c0; a[3] = c1; a[5] = c2; a[7] = c3;
 }
@@ -125,15 +222,15 @@ template <int DIR, typename V> __device__ __forceinline__ void dft16(V (&a)[16])
     for (int q = 0; q < 8; ++q) { b[q] = a[q] + a[q + 8]; c[q] = a[q] - a[q + 8]; }
     // c[q] *= W16^q (forward: exp(-i*pi*q/8))
     const cx<T> w1 = mk<T>(c1, -s1), w3 = mk<T>(s1, -c1);
-    c[1] = twmul<DIR>(c[1], w1);
+    c[1] = twmul_c<DIR>(c[1], w1);
     c[2] = mulw8_1<DIR>(c[2]);
-    c[3] = twmul<DIR>(c[3], w3);
-    c[4] = rot<DIR>(c[4]);
-    c[5] = twmul<DIR>(c[5], mk<T>(-s1, -c1));
+    c[3] = twmul_c<DIR>(c[3], w3);
+    // c[4]'s quarter turn is folded into the first butterflies of dft8<DIR, true>
+    c[5] = twmul_c<DIR>(c[5], mk<T>(-s1, -c1));
     c[6] = mulw8_3<DIR>(c[6]);
-    c[7] = twmul<DIR>(c[7], mk<T>(-c1, -s1));
+    c[7] = twmul_c<DIR>(c[7], mk<T>(-c1, -s1));
     dft8<DIR>(b);
-    dft8<DIR>(c);
+    dft8<DIR, true>(c);
 #pragma unroll
     for (int d = 0; d < 8; ++d) { a[2 * d] = b[d]; a[2 * d + 1] = c[d]; }
 }
@@ -169,7 +266,7 @@ template <int DIR, typename V> __device__ __forceinline__ void dft32(V (&a)[32])
             else if (oct == 1) { cs = -s0; sn = c0; }
             else if (oct == 2) { cs = -c0; sn = -s0; }
             else { cs = s0; sn = -c0; }
-            b[q0][k1] = twmul<DIR>(t[k1], mk<T>(cs, -sn));
+            b[q0][k1] = twmul_c<DIR>(t[k1], mk<T>(cs, -sn));
         }
     }
 #pragma unroll
@@ -241,7 +338,7 @@ template <int P, int Q, int DIR, typename V> __device__ __forceinline__ void dft
 #pragma unroll
         for (int k1 = 0; k1 < P; ++k1) {
             const int m = (b * k1) % R;
-            y[k1][b] = m == 0 ? t[k1] : twmul<DIR>(t[k1], mk<T>((T)CtTab<R>::C[m], (T)-CtTab<R>::S[m]));
+            y[k1][b] = m == 0 ? t[k1] : twmul_c<DIR>(t[k1], mk<T>((T)CtTab<R>::C[m], (T)-CtTab<R>::S[m]));
         }
     }
 #pragma unroll

@@ -280,11 +280,10 @@ __device__ __forceinline__ void sk_last_real(const StockStage& st, const SkArgs<
     typedef cx<T> CX;
     const int n = a.n, nb = st.nb, n4 = n >> 2, items = a.sym_items;
     auto pairf = [&](CX A, CX Bn, int k, CX& Xa, CX& Xb) {
-        const CX B = conj(Bn), wk = sk_wN<T>(a, k);
-        const CX S = (A + B) * (T)0.5, Dm = cmul((A - B) * (T)0.5, wk);
-        const CX D = mk<T>(Dm.y, -Dm.x);
-        Xa = S + D;
-        Xb = conj(S - D);
+        const CX wk = sk_wN<T>(a, k);
+        const CX S = add_conj(A, Bn) * (T)0.5, Dm = cmul(sub_conj(A, Bn) * (T)0.5, wk);   // B = conj(Bn); D = -i Dm rides on the add
+        Xa = add_rot<FWD>(S, Dm);
+        Xb = conj(sub_rot<FWD>(S, Dm));
     };
 #pragma unroll
     for (int i0 = 0; i0 < a.maxcnt * items; i0 += a.nthr) {
@@ -365,11 +364,10 @@ __device__ __forceinline__ void sk_first_real(const StockStage& st, const SkArgs
         };
         // conj Z'[k] -> za, conj Z'[n-k] -> zb
         auto pairb = [&](int k, CX& za, CX& zb) {
-            const CX A = get(k), B = conj(get(n - k)), wk = sk_wN<T>(a, k);
-            const CX S = A + B, Dm = cmulc(A - B, wk);
-            const CX D = mk<T>(-Dm.y, Dm.x);
-            za = conj(S + D);
-            zb = S - D;
+            const CX A = get(k), Bn = get(n - k), wk = sk_wN<T>(a, k);
+            const CX S = add_conj(A, Bn), Dm = cmulc(sub_conj(A, Bn), wk);               // B = conj(Bn); D = i Dm rides on the add
+            za = conj(add_rot<BWD>(S, Dm));
+            zb = sub_rot<BWD>(S, Dm);
         };
         CX v1[R], v2[R];
         if (it) {
@@ -548,14 +546,12 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
             } else if (k == half) {
                 pd[half] = mk<T>((T)2 * A.x, (T)2 * A.y);  // conj(2 conj(A))
             } else {
-                const CX B = conj(Bn);
                 CX wk;
                 if (c.twr_lds) wk = lds[c.twr_off + k];
                 else { wk = c.twrg[k]; asm volatile(""); }
-                const CX S = A + B, Dm = cmulc(A - B, wk);
-                const CX D = mk<T>(-Dm.y, Dm.x);
-                pd[k] = conj(S + D);
-                pd[n - k] = S - D;  // conj(conj(S - D))
+                const CX S = add_conj(A, Bn), Dm = cmulc(sub_conj(A, Bn), wk);   // B = conj(Bn); D = i Dm rides on the add
+                pd[k] = conj(add_rot<BWD>(S, Dm));
+                pd[n - k] = sub_rot<BWD>(S, Dm);  // conj(conj(S - D))
             }
         }
         w ^= 1;
@@ -628,14 +624,13 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
                 Xa = conj(ps[half]);
                 Xb = Xa;
             } else {
-                const CX A = ps[k], B = conj(ps[n - k]);
+                const CX A = ps[k], Bn = ps[n - k];
                 CX wk;
                 if (c.twr_lds) wk = lds[c.twr_off + k];
                 else { wk = c.twrg[k]; asm volatile(""); }
-                const CX S = (A + B) * (T)0.5, Dm = cmul((A - B) * (T)0.5, wk);
-                const CX D = mk<T>(Dm.y, -Dm.x);
-                Xa = S + D;
-                Xb = conj(S - D);
+                const CX S = add_conj(A, Bn) * (T)0.5, Dm = cmul(sub_conj(A, Bn) * (T)0.5, wk);   // B = conj(Bn); D = -i Dm rides on the add
+                Xa = add_rot<FWD>(S, Dm);
+                Xb = conj(sub_rot<FWD>(S, Dm));
             }
             if (out_int) {
                 T* pd = reinterpret_cast<T*>(lds + w * bufsz + g * p.img);
@@ -1027,14 +1022,12 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, co
                     } else if (k == half) {
                         pd[half] = mk<T>((T)2 * A.x, (T)2 * A.y);
                     } else {
-                        const CX B = conj(pb[r]);
                         CX wk;
                         if (c.twr_lds) wk = lds[c.twr_off + k];
                         else { wk = twrg[k]; asm volatile(""); }
-                        const CX S = A + B, Dm = cmulc(A - B, wk);
-                        const CX D = mk<T>(-Dm.y, Dm.x);
-                        pd[k] = conj(S + D);
-                        pd[n - k] = S - D;
+                        const CX S = add_conj(A, pb[r]), Dm = cmulc(sub_conj(A, pb[r]), wk);   // B = conj(pb); D = i Dm rides on the add
+                        pd[k] = conj(add_rot<BWD>(S, Dm));
+                        pd[n - k] = sub_rot<BWD>(S, Dm);
                     }
                 }
             }

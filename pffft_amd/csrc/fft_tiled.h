@@ -349,20 +349,15 @@ struct Tiled {
     // one mirror pair: a holds the bin k, b the bin n-k (spectrum X forward-out / backward-in, packed Z on the other side)
     struct Pair { CX a, b; };
     static __device__ __forceinline__ Pair pair1(CX A, CX Bin, CX wk) {
-        const CX Bc = conj(Bin);
-        CX S, D;
-        if (DIR == FWD) {  // X[k] = S + D, S = (A+B)/2, D = -(i/2) W_N^k (A-B)
-            S = (A + Bc) * (T)0.5;
-            const CX m = cmul((A - Bc) * (T)0.5, wk);
-            D = mk<T>(m.y, -m.x);
-        } else {           // Z'[k] = S + D, S = A+B, D = i conj(W_N^k) (A-B)
-            S = A + Bc;
-            const CX m = cmulc(A - Bc, wk);
-            D = mk<T>(-m.y, m.x);
-        }
+        // forward:  X[k]  = S + D, S = (A+B)/2, D = -(i/2) W_N^k (A-B);   backward: Z'[k] = S + D, S = A+B, D = i conj(W_N^k) (A-B)
+        // with B = conj(Bin); D = rot<DIR>(m): the quarter turn rides on the packed add (cxmath.h add_rot / sub_rot)
+        const CX su = add_conj(A, Bin), di = sub_conj(A, Bin);
+        CX S, m;
+        if (DIR == FWD) { S = su * (T)0.5; m = cmul(di * (T)0.5, wk); }
+        else { S = su; m = cmulc(di, wk); }
         Pair r;
-        r.a = S + D;
-        r.b = conj(S - D);
+        r.a = add_rot<DIR>(S, m);
+        r.b = conj(sub_rot<DIR>(S, m));
         return r;
     }
     // in-register pair pass on the symmetric stage's operands: v[u*RS + d] = bin jm(t,u) + d n/RS.

@@ -8,7 +8,7 @@ import socket
 import numpy as np
 import pytest
 
-from pffft_amd.sharding import combine, shard_range, timed_steps
+from pffft_amd.sharding import combine, combine_stats, shard_range, timed_steps
 
 
 def test_shard_range_partitions_the_batch():
@@ -63,6 +63,27 @@ def test_two_rank_gloo_bracket():
     assert d0 == d1 == 4                          # 1 warm-up + exactly 3 timed steps
 
 
+def test_synthetic_input_is_addressed_by_global_index():
+    """bench.py's inputs are a counter hash of (seed, GLOBAL element index): a strong-scaling shard holds the same vectors
+    whatever the number of ranks, and the torch (device) and numpy (host) generators agree to the bit."""
+    import torch
+    from pffft_amd.sharding import global_uniform_, global_uniform_np
+    vs, total = 96, 1001
+    whole = global_uniform_np(0, total * vs, 5, np.float64).reshape(total, vs)
+    assert -1.0 <= whole.min() and whole.max() < 1.0 and abs(whole.mean()) < 0.01
+    for world in (1, 2, 3, 8):
+        for r in range(world):
+            start, count = shard_range(total, r, world)
+            shard = torch.empty(count, vs, dtype=torch.float64)
+            global_uniform_(shard, start * vs, 5, chunk=4099)
+            assert np.array_equal(shard.numpy(), whole[start:start + count])
+    # float32 carries the same values (multiples of 2^-23), far beyond 2^32 elements too
+    a = global_uniform_np((1 << 34) + 5, 4096, 2, np.float32)
+    b = global_uniform_(torch.empty(4096, dtype=torch.float32), (1 << 34) + 5, 2)
+    assert np.array_equal(a, b.numpy()) and np.array_equal(a.astype(np.float64), global_uniform_np((1 << 34) + 5, 4096, 2, np.float64))
+    assert not np.array_equal(a, global_uniform_np((1 << 34) + 5, 4096, 3, np.float32))     # the seed matters
+
+
 # ------------------------------------------------------------------ bench.py's own launcher
 def _bench(*args, env_extra=None, timeout=300):
     import subprocess
@@ -88,6 +109,9 @@ def test_bench_gpus_2_spawns_two_ranks_over_gloo():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["selftest"] is True
     assert rec["value"] > 0
+    # the line reports how many ranks actually met in the all-reduce, and the fastest / slowest rank
+    assert rec["ranks_seen"] == 2
+    assert 0 < rec["ms_per_step_fastest_rank"] <= rec["ms_per_step_slowest_rank"]
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -1,38 +1,98 @@
-"""Scan of legal sizes for slow outliers (development tool): forward canonical + unordered, 256 MiB per launch, 10 + 10 launches."""
+"""Scan of the legal sizes for slow outliers AND wrong values (development tool):
+
+    python tools/size_scan.py LO HI [f32|f64] [stride]
+
+every `stride`-th legal size N = nmin 2^a 3^b 5^c in [LO, HI] (the set tests/test_fft_factors.c:36-61 enumerates), complex and
+real, the four direction x layout combinations, 256 MiB per launch, 10 untimed + 10 timed launches -> fraction of 8 TB/s on
+2 x vector bytes (short runs: below steady state; the point is outliers).  While it times it CHECKS: the canonical forward
+spectrum of two vectors of the batch against a float64 numpy FFT (1e-5 float / 1e-12 double, the parity bar),
+zreorder(unordered) == ordered bit for bit, and the backward transforms through the round trip.  A failed check prints
+"BAD" and the exit status is 1.  (No oracle/ import here: tools are not test infrastructure.)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pffft_amd as pa
 
-def smooth5(m):
-    for q in (2, 3, 5):
-        while m % q == 0: m //= q
-    return m == 1
 
-lo, hi = int(sys.argv[1]), int(sys.argv[2])
-dt = np.float64 if len(sys.argv) > 3 and sys.argv[3] == "f64" else np.float32
-tdt = torch.float64 if dt == np.float64 else torch.float32
-step = 16
-sizes = [n for n in range(max(16, lo), hi + 1, step) if smooth5(n)]
-if len(sizes) > 160: sizes = sizes[:: len(sizes) // 160 + 1]
-for tr, name in ((pa.COMPLEX, "cplx"), (pa.REAL, "real")):
-    for n in sizes:
-        N = n if tr == pa.COMPLEX else 2 * n
-        try: s = pa.Setup(N, tr, dt)
-        except Exception as e: print(name, N, "setup failed", e); continue
-        batch = max(1, (1 << 28) // (s.vec_scalars * np.dtype(dt).itemsize))
-        x = torch.rand(batch, s.vec_scalars, device="cuda", dtype=tdt) * 2 - 1
-        y = torch.empty_like(x)
-        res = []
-        for o in (True, False):
-            f = lambda: s.transform_batch(x, y, pa.FORWARD, o)
-            for _ in range(10): f()
-            torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(10): f()
-            b.record(); torch.cuda.synchronize()
-            res.append(2 * x.numel() * x.element_size() / (a.elapsed_time(b) / 10 * 1e-3) / 8e12)
-        print(f"{name} N={N:7d} [{pa.kernel_name(s):9s}] ordered {res[0]:.3f} unordered {res[1]:.3f}", flush=True)
-        del x, y; torch.cuda.empty_cache(); s.close()
+def legal_sizes(transform, lo, hi):
+    nmin = 32 if transform == pa.REAL else 16
+    out, a = [], 1
+    while nmin * a <= hi:
+        b = a
+        while nmin * b <= hi:
+            c = b
+            while nmin * c <= hi:
+                if nmin * c >= lo: out.append(nmin * c)
+                c *= 5
+            b *= 3
+        a *= 2
+    return sorted(out)
+
+
+def canonical_f64(x, N, tr):
+    """float64 canonical spectrum in pffft's format (include/pffft/pffft.h:144-155)."""
+    if tr == pa.COMPLEX:
+        X = np.fft.fft(x[0::2].astype(np.float64) + 1j * x[1::2].astype(np.float64))
+        out = np.empty(2 * N); out[0::2] = X.real; out[1::2] = X.imag
+        return out
+    X = np.fft.rfft(x.astype(np.float64))
+    out = np.empty(N); out[0] = X[0].real; out[1] = X[N // 2].real
+    out[2::2] = X[1:N // 2].real; out[3::2] = X[1:N // 2].imag
+    return out
+
+
+def main():
+    lo, hi = int(sys.argv[1]), int(sys.argv[2])
+    dt = np.float64 if len(sys.argv) > 3 and sys.argv[3] == "f64" else np.float32
+    stride = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    tol = 1e-12 if dt == np.float64 else 1e-5
+    bad = 0
+    print(f"# tools/size_scan.py {lo} {hi} {np.dtype(dt).name} stride {stride}: fraction of 8 TB/s, "
+          "fwd ordered / fwd unordered / bwd ordered / bwd unordered; err = max rel error of the checked vectors vs float64 numpy")
+    for tr, name in ((pa.COMPLEX, "cplx"), (pa.REAL, "real")):
+        for N in legal_sizes(tr, lo, hi)[::stride]:
+            s = pa.Setup(N, tr, dt)
+            isz = np.dtype(dt).itemsize
+            batch = max(2, (1 << 28) // (s.vec_scalars * isz))
+            x = torch.rand(batch, s.vec_scalars, device="cuda", dtype=tdt) * 2 - 1
+            y = torch.empty_like(x)
+            res = []
+            for d in (pa.FORWARD, pa.BACKWARD):
+                for o in (True, False):
+                    f = lambda: s.transform_batch(x, y, d, o)
+                    for _ in range(10): f()
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(10): f()
+                    b.record(); torch.cuda.synchronize()
+                    res.append(2 * x.numel() * isz / (a.elapsed_time(b) / 10 * 1e-3) / 8e12)
+            # ---- values: first and last vector of the batch
+            idx = torch.tensor([0, batch - 1], device="cuda")
+            xs = x[idx].contiguous()
+            fo = s.transform_batch(xs, None, pa.FORWARD, True)
+            fu = s.transform_batch(xs, None, pa.FORWARD, False)
+            xh = xs.cpu().numpy()
+            err = 0.0
+            for i in range(2):
+                want = canonical_f64(xh[i], N, tr)
+                err = max(err, float(np.abs(fo[i].cpu().numpy() - want).max() / np.abs(want).max()))
+            ok = err <= tol
+            ok &= bool(torch.equal(s.zreorder_batch(fu, None, pa.FORWARD), fo))      # unordered = permuted ordered, bit for bit
+            for o, spec in ((True, fo), (False, fu)):                                # round trips: backward of both layouts
+                back = s.transform_batch(spec, None, pa.BACKWARD, o)
+                e2 = float((back / N - xs).abs().max())
+                err = max(err, e2 / 4)       # round trip of two transforms on |x| <= 1: reported on the scale of one
+                ok &= e2 <= 8 * tol
+            bad += 0 if ok else 1
+            print(f"{name} N={N:8d} [{pa.kernel_name(s):9s}] {res[0]:.3f} {res[1]:.3f} {res[2]:.3f} {res[3]:.3f}  err {err:.1e} "
+                  f"{'ok' if ok else 'BAD'}", flush=True)
+            del x, y; torch.cuda.empty_cache(); s.close()
+    print(f"# {bad} sizes failed the value checks")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
