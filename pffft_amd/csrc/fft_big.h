@@ -128,6 +128,160 @@ __global__ void real_pair_kernel(cx<T>* data, long long batch, long long n) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Layout / pair sweeps of the vectors beyond LDS, ONE sweep each (round 3).  Reference: pffft_zreorder
+// (src/pffft_priv_impl.h:1158-1193), real finalize / preprocess (:1330-1372, :1423-1462), which the reference also runs as
+// separate sweeps over the vector.  Before, a real transform into / out of the internal layout cost two elementwise sweeps
+// around the complex core (in-place pair pass + zreorder_kernel with 4-byte gathers: 205 + 280 us per GiB against 170 for a
+// copy); here both are one wave-local kernel whose every global access is a dense run:
+//   a wavefront owns a TILE of 64 consecutive positions t of the spectrum quarters (16 blocks of the internal layout,
+//   SURVEY.md appendix A); lane i = position t0 + i loads / stores the four canonical bins that share that position - runs of
+//   64 consecutive bins (512 bytes float) per quarter, ascending or descending - and the tile's 16 blocks pass through a
+//   wave-private LDS image (32-scalar blocks padded to 36) whose other side is linear 16-byte units (1 KiB per instruction).
+//   MODE 0  complex  canonical -> internal            MODE 1  complex  internal -> canonical
+//   MODE 2  real forward:  packed spectrum Z of the complex core -> half-complex spectrum X in the internal layout
+//           X[k] = S + D, X[n-k] = conj(S - D), S = (A+B)/2, D = -(i/2) W_N^k (A-B), A = Z[k], B = conj Z[n-k]
+//   MODE 3  real backward: X in the internal layout -> packed spectrum Z' for the complex core
+//           Z'[k] = S + D, Z'[n-k] = conj(S - D), S = A+B, D = i conj(W_N^k) (A-B), A = X[k], B = conj X[n-k]
+//   MODE 4  real backward, canonical input: half-complex X -> Z' out of place (the copy + in-place pair pass it replaces were two sweeps)
+//   Real quarters (bin(q, t) of the appendix): position t holds bins t, n/2 - t, n/2 + t, n - t, i.e. the two mirror pairs
+//   (t, n - t) and (n/2 - t, n/2 + t) - a lane computes both.
+//   t = 0 holds the self-paired bins 0 = (DC, Nyquist) and n/2 and the pair (n/4, 3n/4).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BLK_WAVES = 4;                                    // wavefronts per workgroup (each owns its tiles)
+template <typename T> struct BlkGeom {
+    static constexpr int CH = 16 / (int)sizeof(T);              // scalars per 16-byte unit
+    static constexpr int IBS = 36;                              // scalars per padded 32-scalar block
+    static constexpr int IMG = 16 * IBS;                        // scalars per tile image (16 blocks)
+    static constexpr int UNITS = 16 * 32 / CH;                  // 16-byte units per tile: 128 (float) / 256 (double)
+    static constexpr size_t LDS_BYTES = (size_t)BLK_WAVES * IMG * sizeof(T);
+};
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(BLK_WAVES * 64)
+big_block_kernel(const T* __restrict__ in, T* __restrict__ out, long long batch, long long n) {
+    typedef cx<T> CX;
+    typedef BlkGeom<T> G;
+    typedef vec4<float> U16;                                    // a 16-byte register quantum
+    __shared__ __attribute__((aligned(16))) T img_all[BLK_WAVES * G::IMG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T* img = img_all + wave * G::IMG;
+    const long long n4 = n >> 2, half = n >> 1;
+    const long long tpv = (n4 + 63) >> 6;                       // tiles per vector
+    const long long ntiles = batch * tpv;
+    const long long gw = (long long)blockIdx.x * BLK_WAVES + wave, nw = (long long)gridDim.x * BLK_WAVES;
+    // scalar position, inside the padded tile image, of (quarter q, part p) of this lane's position
+    const int ipos = G::IBS * (lane >> 2) + (lane & 3);
+    auto fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (long long tile = gw; tile < ntiles; tile += nw) {
+        const long long vec = tile / tpv, t0 = (tile - vec * tpv) << 6, t = t0 + lane;
+        const bool act = t < n4;
+        const CX* cin = reinterpret_cast<const CX*>(in) + vec * n;
+        CX* cout = reinterpret_cast<CX*>(out) + vec * n;
+        const int nblk = (int)((n4 - t0) < 64 ? (n4 - t0) >> 2 : 16);            // whole blocks of this tile
+        const int nunits = nblk * (32 / G::CH);
+        const long long ubase = (vec * 2 * n + 8 * t0) / G::CH;                   // first 16-byte unit of the tile in the internal layout
+        CX q[4];                                                                  // the four quarters' values at position t
+        if constexpr (MODE == 0 || MODE == 2) {
+            // ---- canonical side in: dense runs of 64 bins per quarter
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) q[m] = act ? __builtin_nontemporal_load(cin + m * n4 + t) : mk<T>((T)0, (T)0);
+            } else {
+                const long long ta = act ? t : 0;
+                const long long k1 = ta ? ta : n4;                                // pair (k1, n - k1); t = 0 carries (n/4, 3n/4)
+                const CX A1 = __builtin_nontemporal_load(cin + k1), B1 = __builtin_nontemporal_load(cin + (n - k1));
+                const long long k2 = ta ? half - ta : 0;                          // pair (k2, n - k2); t = 0: the self-paired bins 0 and n/2
+                const CX A2 = __builtin_nontemporal_load(cin + k2), B2 = __builtin_nontemporal_load(cin + (ta ? half + ta : half));
+                // every W_N^k through the same exact-argument evaluation as real_pair_kernel: pffft_transform_ordered ==
+                // pffft_zreorder(pffft_transform) must hold bit for bit (benchmarks/bench_pffft.c:343-349)
+                const CX w1 = unit_root<T>(k1, 2 * n, FWD), w2 = unit_root<T>(k2, 2 * n, FWD);
+                auto pairf = [](CX A, CX Bn, CX wk, CX& Xa, CX& Xb) {
+                    const CX S = add_conj(A, Bn) * (T)0.5, Dm = cmul(sub_conj(A, Bn) * (T)0.5, wk);
+                    Xa = add_rot<FWD>(S, Dm);
+                    Xb = conj(sub_rot<FWD>(S, Dm));
+                };
+                CX Xa1, Xb1, Xa2, Xb2;
+                pairf(A1, B1, w1, Xa1, Xb1);
+                pairf(A2, B2, w2, Xa2, Xb2);
+                if (ta) { q[0] = Xa1; q[3] = Xb1; q[1] = Xa2; q[2] = Xb2; }       // bins t, n - t, n/2 - t, n/2 + t
+                else { q[0] = mk<T>(A2.x + A2.y, A2.x - A2.y); q[1] = Xa1; q[2] = conj(B2); q[3] = Xb1; }   // 0, n/4, n/2, 3n/4
+            }
+            if (act) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { img[ipos + 8 * m] = q[m].x; img[ipos + 8 * m + 4] = q[m].y; }
+            }
+            fence();
+            // ---- internal side out: the tile's blocks as linear 16-byte units
+            U16* o16 = reinterpret_cast<U16*>(out) + ubase;
+#pragma unroll
+            for (int h = 0; h < G::UNITS / 64; ++h) {
+                const int u = lane + 64 * h;
+                if (u < nunits) {
+                    const int sc = u * G::CH, b = sc >> 5, r = sc & 31;
+                    __builtin_nontemporal_store(*reinterpret_cast<const U16*>(img + G::IBS * b + r), o16 + u);
+                }
+            }
+            fence();
+        } else {
+            if constexpr (MODE == 4) {
+                // ---- canonical half-complex spectrum in: the four bins of position t (dense ascending / descending runs)
+                const long long ta = act ? t : 0;
+                q[0] = __builtin_nontemporal_load(cin + ta);
+                q[1] = __builtin_nontemporal_load(cin + (ta ? half - ta : n4));
+                q[2] = __builtin_nontemporal_load(cin + half + ta);
+                q[3] = __builtin_nontemporal_load(cin + (ta ? n - ta : n - n4));
+            } else {
+            // ---- internal side in
+            const U16* i16 = reinterpret_cast<const U16*>(in) + ubase;
+#pragma unroll
+            for (int h = 0; h < G::UNITS / 64; ++h) {
+                const int u = lane + 64 * h;
+                if (u < nunits) {
+                    const int sc = u * G::CH, b = sc >> 5, r = sc & 31;
+                    *reinterpret_cast<U16*>(img + G::IBS * b + r) = __builtin_nontemporal_load(i16 + u);
+                }
+            }
+            fence();
+            if (act) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) q[m] = mk<T>(img[ipos + 8 * m], img[ipos + 8 * m + 4]);
+            }
+            fence();
+            }
+            if (act) {
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) __builtin_nontemporal_store(q[m], cout + m * n4 + t);
+                } else {
+                    auto pairb = [](CX A, CX Bn, CX wk, CX& Za, CX& Zb) {
+                        const CX S = add_conj(A, Bn), Dm = cmulc(sub_conj(A, Bn), wk);
+                        Za = add_rot<BWD>(S, Dm);
+                        Zb = conj(sub_rot<BWD>(S, Dm));
+                    };
+                    const long long k1 = t ? t : n4;
+                    const CX w1 = unit_root<T>(k1, 2 * n, FWD), w2 = unit_root<T>(half - t, 2 * n, FWD);
+                    if (t) {
+                        CX Za1, Zb1, Za2, Zb2;
+                        pairb(q[0], q[3], w1, Za1, Zb1);                          // X[t], X[n - t]
+                        pairb(q[1], q[2], w2, Za2, Zb2);                          // X[n/2 - t], X[n/2 + t]
+                        __builtin_nontemporal_store(Za1, cout + t);
+                        __builtin_nontemporal_store(Zb1, cout + (n - t));
+                        __builtin_nontemporal_store(Za2, cout + (half - t));
+                        __builtin_nontemporal_store(Zb2, cout + (half + t));
+                    } else {
+                        CX Za, Zb;
+                        pairb(q[1], q[3], w1, Za, Zb);                            // X[n/4], X[3n/4]
+                        cout[n4] = Za; cout[n - n4] = Zb;
+                        cout[0] = mk<T>(q[0].x + q[0].y, q[0].x - q[0].y);
+                        cout[half] = mk<T>((T)2 * q[2].x, (T)-2 * q[2].y);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // n = R x N2 with R <= 32 and N2 small enough for the LDS-resident batched kernels (complex N up to 32 x 8192): three
 // streaming passes instead of the strided mixed-radix kernel above,
 //   1. big_col_kernel   : x[n1 N2 + n2] -> length-R transform over n1 IN REGISTERS (one column per thread, every access

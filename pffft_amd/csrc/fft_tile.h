@@ -54,7 +54,10 @@ template <typename T, int LOGL, int PP> struct TileGeom {
     static constexpr int L = 1 << LOGL, TPT = L / 8, WG = TPT * PP, S = TileUnit<T>::S, C = PP * S;
     static constexpr int PITCH = PP + 1;                                  // 16-byte units per point row
     static constexpr int NS = (LOGL + 2) / 3;
-    static constexpr size_t IMG_BYTES = (size_t)L * PITCH * 16;
+    // internal-layout output (OINT): the last stage's rows are skewed by QSKEW units per spectrum quarter so that the
+    // block-gather of the store loop reads conflict-free (+ 3 QSKEW units at the end of the image)
+    static constexpr int QSKEW = S == 2 ? 4 : 1;
+    static constexpr size_t IMG_BYTES = (size_t)L * PITCH * 16 + 256;
     // + W_L^k (L entries) + `levels` x 512 entries of the four-step twiddle table
     __host__ __device__ static constexpr size_t lds_bytes(int levels) { return IMG_BYTES + ((size_t)L + (size_t)levels * 512) * 2 * sizeof(T) + 16; }
     __host__ __device__ static constexpr int rad(int s) { return (LOGL % 3 == 0 || s > 0) ? 8 : (1 << (LOGL % 3)); }
@@ -77,7 +80,13 @@ template <typename CX> __device__ __forceinline__ CX tile_w3(const CX* w3, unsig
 // SEQC = 1: pass A (adjacent columns, four-step twiddle)   SEQC = 0: pass B (rows in, transposing store)
 // PF = 1: the loads of the workgroup's next tile fly while the current one is transformed (for the tiles so large that
 //         one workgroup fills a CU: nothing else would overlap its load latency)
-template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF>
+// OINT = 1 (pass B of a forward transform only): the spectrum leaves in the pffft-internal layout instead of the canonical one
+//   (reference: pffft_transform's output, src/pffft_priv_impl.h:1195-1237 cplx_finalize; SURVEY.md appendix A:
+//   internal[32 b + 8 m + 4 p + l] = part p of X[m n/4 + 4 b + l]).  A pass-B tile holds, for its C adjacent outer indices,
+//   ALL points k of the rows, i.e. the four quarters m of every bin group: per point k' < L/4 and group of 4 adjacent outer
+//   indices the image yields one whole 128-byte (float) / 256-byte (double) block of the layout, per k' a contiguous run of
+//   C/4 blocks - the canonical -> internal reorder costs no extra sweep over HBM.
+template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0>
 __global__ void __launch_bounds__((1 << LOGL) / 8 * PP, PF ? 2 : 3)
 tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned long long ntiles, TileDesc D, unsigned* ctr) {
     typedef cx<T> CX;
@@ -113,13 +122,15 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
         }
     }
 
-    auto tile_bases = [&](unsigned long long tile, const CX*& src, CX*& dst, unsigned& col0) {
+    // (eb: OINT only - canonical index, inside its vector, of the tile's first output element; dst is then the vector's base)
+    auto tile_bases = [&](unsigned long long tile, const CX*& src, CX*& dst, unsigned& col0, unsigned long long& eb) {
         const unsigned b = (unsigned)(tile % D.TB);
         const unsigned long long rest = tile / D.TB;
         const unsigned a = (unsigned)(rest % D.TA);
         const unsigned long long vec = rest / D.TA;
         src = in + vec * D.vstride + a * D.in_a + b * D.in_b;
-        dst = out + vec * D.vstride + a * D.out_a + b * D.out_b;
+        if constexpr (OINT) { eb = a * D.out_a + b * D.out_b; dst = out + vec * D.vstride; }
+        else dst = out + vec * D.vstride + a * D.out_a + b * D.out_b;
         col0 = a * D.col_a + b * D.col_b;
     };
     // pass A: unit p of points t + TPT m straight into the stage-0 operand registers;
@@ -158,20 +169,20 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     }
     LD nxt[NLD];
     if constexpr (PF) {
-        if (tile < ntiles) { const CX* s0; CX* d0; unsigned cc; tile_bases(tile, s0, d0, cc); issue_loads(s0, nxt); }
+        if (tile < ntiles) { const CX* s0; CX* d0; unsigned cc; unsigned long long e0; tile_bases(tile, s0, d0, cc, e0); issue_loads(s0, nxt); }
     }
     for (unsigned it = 0; tile < ntiles; ++it) {
         if (dyn && tid == 0) {
             s_next[it & 1] = pend;                   // tile of iteration it + 2, read by everyone after the first barrier below
             pend = atomicAdd(&ctr[0], 1u);
         }
-        const CX* src; CX* dst; unsigned col0;
-        tile_bases(tile, src, dst, col0);
+        const CX* src; CX* dst; unsigned col0; unsigned long long ebase = 0;
+        tile_bases(tile, src, dst, col0, ebase);
         LD cur[NLD];
         if constexpr (PF) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) cur[i] = nxt[i];
-            if (tile1 < ntiles) { const CX* s1; CX* d1; unsigned cc; tile_bases(tile1, s1, d1, cc); issue_loads(s1, nxt); }
+            if (tile1 < ntiles) { const CX* s1; CX* d1; unsigned cc; unsigned long long e1; tile_bases(tile1, s1, d1, cc, e1); issue_loads(s1, nxt); }
         } else {
             issue_loads(src, cur);
         }
@@ -243,7 +254,12 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                     U x;
 #pragma unroll
                     for (int sq = 0; sq < S; ++sq) TU::set(x, sq, o[sq][d]);
-                    img[(pbase + d * Ns) * PITCH + p] = x;
+                    if constexpr (OINT && s == NS - 1 && NS > 1) {
+                        static_assert(!OINT || (R == 8 && B == 1 && Ns == L / 8), "last stage shape");
+                        img[(pbase + d * Ns) * PITCH + p + (d / 2) * G::QSKEW] = x;   // row j + d L/8 lies in quarter d / 2
+                    } else {
+                        img[(pbase + d * Ns) * PITCH + p] = x;
+                    }
                 }
             }
         };
@@ -253,10 +269,36 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
         if constexpr (NS > 3) stage(std::integral_constant<int, 3>{});
         __syncthreads();
         // ---- the image holds the spectrum [k][sequence]: runs of C adjacent sequences per point
+        if constexpr (OINT) {
+            // one item = ONE 16-byte unit of the layout, consecutive lanes = consecutive units: every store instruction is
+            // dense (two stores per lane, 16 bytes each at a 32-byte stride, measured 0.25 against 0.31 for the canonical store).  The units of a point k' < L/4 form a run of C/4 whole blocks.
+            constexpr int BPT = C / 4, UPB = 2 * (int)sizeof(T);               // blocks per point; 16-byte units per block: 8 (float) / 16 (double)
+            constexpr int UPP = BPT * UPB, UPQ = UPB / 4, UPS = 4 / S;        // units per point / per (group, quarter) slot; image units per group
+            static_assert(((L / 4) * UPP) % WG == 0, "store units per thread");
+#pragma unroll
+            for (int i = 0; i < (L / 4) * UPP / WG; ++i) {
+                const int g = tid + i * WG, ptq = g / UPP, r = g % UPP, bb = r / UPB, m = (r / UPQ) % 4, sub = r % UPQ;
+                const U* sp = img + (ptq + m * (L / 4)) * PITCH + m * G::QSKEW + bb * UPS;
+                // internal layout in complex units: 4 t + 4 m + 2 p (+ l / 2), t = canonical index of the group's first bin in quarter 0
+                U* dp = reinterpret_cast<U*>(dst + 4 * (ebase + (unsigned long long)ptq * D.ops + 4 * bb)) + r % UPB;
+                U o;
+                if constexpr (S == 2) {           // sub = part p: (re or im) of the four sequences of the group
+                    const U u0 = sp[0], u1 = sp[1];
+                    if (sub) { o.x = u0.y; o.y = u0.w; o.z = u1.y; o.w = u1.w; }
+                    else { o.x = u0.x; o.y = u0.z; o.z = u1.x; o.w = u1.z; }
+                } else {                          // sub = 2 p + (l / 2): part p of sequences 2 (l/2), 2 (l/2) + 1
+                    const U u0 = sp[2 * (sub & 1)], u1 = sp[2 * (sub & 1) + 1];
+                    if (sub >> 1) { o.x = u0.y; o.y = u1.y; }
+                    else { o.x = u0.x; o.y = u1.x; }
+                }
+                __builtin_nontemporal_store(o, dp);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int g = tid + i * WG, pt = g / PP, pu = g % PP;
             __builtin_nontemporal_store(img[pt * PITCH + pu], reinterpret_cast<U*>(dst + (unsigned long long)pt * D.ops + S * pu));
+        }
         }
         const unsigned long long tile2 = dyn ? (unsigned long long)s_next[it & 1] : tile1 + gridDim.x;
         __syncthreads();

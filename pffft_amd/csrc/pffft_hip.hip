@@ -745,6 +745,26 @@ static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, 
     return (int)hipErrorInvalidValue;
 }
 
+// one-sweep layout / pair kernels of the beyond-LDS path (fft_big.h big_block_kernel): mode 0 complex canonical -> internal,
+// 1 complex internal -> canonical, 2 real forward Z -> X (internal), 3 real backward X (internal) -> Z', 4 real backward
+// X (canonical) -> Z'.  in != out.
+template <typename T>
+static int launch_block(Setup* s, int mode, const T* in, T* out, size_t batch, hipStream_t st) {
+    const long long n = s->n, tiles = (long long)batch * ((n / 4 + 63) / 64);
+    long long grid = (tiles + BLK_WAVES - 1) / BLK_WAVES;
+    if (grid > (long long)num_cus() * 8) grid = (long long)num_cus() * 8;
+    const dim3 g((unsigned)grid), b(BLK_WAVES * 64);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((big_block_kernel<T, 0>), g, b, 0, st, in, out, (long long)batch, n); break;
+        case 1: hipLaunchKernelGGL((big_block_kernel<T, 1>), g, b, 0, st, in, out, (long long)batch, n); break;
+        case 2: hipLaunchKernelGGL((big_block_kernel<T, 2>), g, b, 0, st, in, out, (long long)batch, n); break;
+        case 3: hipLaunchKernelGGL((big_block_kernel<T, 3>), g, b, 0, st, in, out, (long long)batch, n); break;
+        default: hipLaunchKernelGGL((big_block_kernel<T, 4>), g, b, 0, st, in, out, (long long)batch, n); break;
+    }
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
 // n beyond LDS: canonical complex four-step through two HBM work buffers, with the real pair pass and the
 // internal layout composed around it (fft_big.h)
 template <typename T>
@@ -779,25 +799,38 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     const unsigned egrid = (unsigned)std::min<size_t>((batch * (size_t)s->n / 2 + 255) / 256, (size_t)num_cus() * 16);
     const cx<T>* cur = (const cx<T>*)in;
     int rc;
-    if (!fwd && !ordered) {  // internal -> canonical
-        if ((rc = zreorder_batch<T>(s, in, (T*)bufA, batch, PFFFT_FORWARD, st))) return rc;
+    // variant 87: the separate sweeps (zreorder_kernel + in-place pair pass) instead of the one-sweep block kernels (A/B)
+    const bool blk = g_variant != 87;
+    if (!fwd && !ordered && blk) {   // internal -> canonical (complex) / -> packed spectrum of the inverse (real), one sweep
+        if ((rc = launch_block<T>(s, real ? 3 : 1, in, (T*)bufA, batch, st))) return rc;
         cur = bufA;
-    }
-    if (!fwd && real) {      // half-complex spectrum -> packed spectrum (in place, never on the caller's input)
-        if (cur != bufA) { PF_CHECK(hipMemcpyAsync(bufA, cur, bytes, hipMemcpyDeviceToDevice, st)); cur = bufA; }
-        hipLaunchKernelGGL((real_pair_kernel<T, BWD>), dim3(egrid), dim3(256), 0, st, bufA, (long long)batch, (long long)s->n);
-        PF_CHECK(hipGetLastError());
+    } else if (!fwd && real && blk) {   // canonical half-complex spectrum -> packed spectrum, out of place, one sweep
+        if ((rc = launch_block<T>(s, 4, in, (T*)bufA, batch, st))) return rc;
+        cur = bufA;
+    } else {
+        if (!fwd && !ordered) {  // internal -> canonical
+            if ((rc = zreorder_batch<T>(s, in, (T*)bufA, batch, PFFFT_FORWARD, st))) return rc;
+            cur = bufA;
+        }
+        if (!fwd && real) {      // half-complex spectrum -> packed spectrum (in place, never on the caller's input)
+            if (cur != bufA) { PF_CHECK(hipMemcpyAsync(bufA, cur, bytes, hipMemcpyDeviceToDevice, st)); cur = bufA; }
+            hipLaunchKernelGGL((real_pair_kernel<T, BWD>), dim3(egrid), dim3(256), 0, st, bufA, (long long)batch, (long long)s->n);
+            PF_CHECK(hipGetLastError());
+        }
     }
     cx<T>* dest = (fwd && !ordered) ? bufA : (cx<T>*)out;
-    bool done = false;
+    bool done = false, out_is_internal = false;
     if ((s->n & (s->n - 1)) == 0 && g_variant != 80 && g_variant != 82) {
         // power-of-two sizes: two passes over HBM up to n = 2^20, three beyond (fft_tile.h); variant 82 = the
         // three-to-five-pass composition below (A/B)
         int logn = 0;
         while ((1 << logn) < s->n) ++logn;
-        const int trc = launch_tile_fft(s, cur, bufB, dest, batch, logn, dir, st);
+        // complex forward into the internal layout: the last tile pass stores the layout itself (variant 86 = separate reorder sweep, A/B)
+        const bool fuse_int = fwd && !ordered && !real && g_variant != 86;
+        const int trc = launch_tile_fft(s, cur, bufB, fuse_int ? (cx<T>*)out : dest, batch, logn, dir, st, fuse_int ? 1 : 0);
         if (trc > 0) return trc;
         done = trc == 0;
+        out_is_internal = done && fuse_int;
     }
     if (done) {
     } else if (s->bigR && g_variant != 80) {   // three streaming passes (fft_big.h); variant 80 = the strided kernels (A/B)
@@ -806,11 +839,13 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
         if ((rc = launch_strided<T>(s, 0, cur, bufB, batch, dir, st))) return rc;
         if ((rc = launch_strided<T>(s, 1, bufB, dest, batch, dir, st))) return rc;
     }
+    if (fwd && !ordered && !out_is_internal && blk)   // (real: pair pass +) canonical -> internal in one sweep
+        return launch_block<T>(s, real ? 2 : 0, (const T*)bufA, out, batch, st);
     if (fwd && real) {
         hipLaunchKernelGGL((real_pair_kernel<T, FWD>), dim3(egrid), dim3(256), 0, st, dest, (long long)batch, (long long)s->n);
         PF_CHECK(hipGetLastError());
     }
-    if (fwd && !ordered)     // canonical -> internal
+    if (fwd && !ordered && !out_is_internal)     // canonical -> internal
         if ((rc = zreorder_batch<T>(s, (const T*)bufA, out, batch, PFFFT_BACKWARD, st))) return rc;
     return 0;
 }

@@ -11,7 +11,8 @@ static int g_tile_pp = [] { const char* e = getenv("PFFFT_HIP_TILE_PP"); return 
 static int g_tile_pf = [] { const char* e = getenv("PFFFT_HIP_TILE_PF"); return e ? atoi(e) : -1; }();  // A/B: prefetch off / on
 
 template <typename T, int LOGL, int PP>
-static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s) {
+static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
+                     bool out_int = false) {
     typedef TileGeom<T, LOGL, PP> G;
     const size_t lds = G::lds_bytes(D.M > (1ull << 18) ? 3 : 2);
     void (*k)(const cx<T>*, cx<T>*, unsigned long long, TileDesc, unsigned*);
@@ -20,6 +21,7 @@ static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, con
     const bool fw = dir == PFFFT_FORWARD;
     if (D.seq_contig) k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 1> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 1>)
                              : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0>);
+    else if (out_int && fw) k = pf ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1, 1> : tile_fft_kernel<T, LOGL, PP, FWD, 0, 0, 1>;
     else k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 1>)
                 : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 0> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 0>);
     int rc = allow_big_lds(k, lds);
@@ -41,13 +43,14 @@ static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, con
 }
 
 template <typename T, int PP>
-static int tile_dispatch(int logl, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s) {
+static int tile_dispatch(int logl, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
+                         bool out_int = false) {
     switch (logl) {
-        case 6: return tile_pass<T, 6, PP>(in, out, ntiles, D, dir, st, s);
-        case 7: return tile_pass<T, 7, PP>(in, out, ntiles, D, dir, st, s);
-        case 8: return tile_pass<T, 8, PP>(in, out, ntiles, D, dir, st, s);
-        case 9: return tile_pass<T, 9, PP>(in, out, ntiles, D, dir, st, s);
-        case 10: if constexpr (PP == 4) return tile_pass<T, 10, 4>(in, out, ntiles, D, dir, st, s);
+        case 6: return tile_pass<T, 6, PP>(in, out, ntiles, D, dir, st, s, out_int);
+        case 7: return tile_pass<T, 7, PP>(in, out, ntiles, D, dir, st, s, out_int);
+        case 8: return tile_pass<T, 8, PP>(in, out, ntiles, D, dir, st, s, out_int);
+        case 9: return tile_pass<T, 9, PP>(in, out, ntiles, D, dir, st, s, out_int);
+        case 10: if constexpr (PP == 4) return tile_pass<T, 10, 4>(in, out, ntiles, D, dir, st, s, out_int);
         default: break;
     }
     g_last_error = "pffft_hip: tile pass length out of range";
@@ -76,9 +79,10 @@ static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long lon
 
 // pass B: rows of length L = 2^logl; row (vec, o, i) [o < outer, i < inner] sits at vec vlen + (o inner + i) L and its
 // spectrum goes to X[vec vlen + (k inner + i) outer + o]   (outer index fastest: runs of C adjacent o)
+// out_int (forward only): the spectrum is stored in the pffft-internal layout (tile_fft_kernel OINT)
 template <typename T>
 static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, int logl, unsigned long long outer,
-                     unsigned long long inner, int dir, hipStream_t st) {
+                     unsigned long long inner, int dir, hipStream_t st, bool out_int = false) {
     const int pp = pick_pp(logl), C = pp * TileUnit<T>::S;
     const unsigned long long L = (unsigned long long)1 << logl;
     TileDesc D{};
@@ -88,32 +92,34 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
     D.out_a = C; D.out_b = outer; D.ops = outer * inner;
     D.M = 0; D.seq_contig = 0;
     const unsigned long long ntiles = nvec * D.TA * D.TB;
-    return pp == 8 ? tile_dispatch<T, 8>(logl, in, out, ntiles, D, dir, st, s) : tile_dispatch<T, 4>(logl, in, out, ntiles, D, dir, st, s);
+    return pp == 8 ? tile_dispatch<T, 8>(logl, in, out, ntiles, D, dir, st, s, out_int) : tile_dispatch<T, 4>(logl, in, out, ntiles, D, dir, st, s, out_int);
 }
 
 // canonical complex transform of `batch` vectors of n = 2^logn points: in -> out through ONE work buffer of the same size
 // (in may equal out; work must differ from both).  Returns -1 when the size is outside the tile plans.
+// out_int: forward transform straight into the internal layout (the last pass stores it: no reorder sweep)
 template <typename T>
-static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, int logn, int dir, hipStream_t st) {
+static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, int logn, int dir, hipStream_t st, bool out_int) {
     const int minlog = 12;
     if (logn < minlog || logn > 27) return -1;
     int rc;
     if (logn <= 20) {
         const int l1 = logn / 2, l2 = logn - l1;
         if ((rc = pass_columns<T>(s, in, work, batch, l1, 1ull << l2, dir, st))) return rc;
-        return pass_rows<T>(s, work, out, batch, l2, 1ull << l1, 1, dir, st);
+        return pass_rows<T>(s, work, out, batch, l2, 1ull << l1, 1, dir, st, out_int);
     }
     const int l1 = logn / 3, rem = logn - l1, l2 = rem / 2, l3 = rem - l2;
     // n = L1 n', n' = L2 L3:  A over L1 (columns n'), then per row of length n': A over L2 (in place), B over L3 with the
     // scatter X[(k3 L2 + k2) L1 + k1]
     if ((rc = pass_columns<T>(s, in, work, batch, l1, 1ull << rem, dir, st))) return rc;
     if ((rc = pass_columns<T>(s, work, work, batch << l1, l2, 1ull << l3, dir, st))) return rc;
-    return pass_rows<T>(s, work, out, batch, l3, 1ull << l1, 1ull << l2, dir, st);
+    return pass_rows<T>(s, work, out, batch, l3, 1ull << l1, 1ull << l2, dir, st, out_int);
 }
 
-int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, int logn, int dir, hipStream_t st) {
-    if (s->is_double) return tile_fft<double>(s, (const cx<double>*)in, (cx<double>*)work, (cx<double>*)out, batch, logn, dir, st);
-    return tile_fft<float>(s, (const cx<float>*)in, (cx<float>*)work, (cx<float>*)out, batch, logn, dir, st);
+int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, int logn, int dir, hipStream_t st, int out_int) {
+    if (out_int && dir != PFFFT_FORWARD) return -1;
+    if (s->is_double) return tile_fft<double>(s, (const cx<double>*)in, (cx<double>*)work, (cx<double>*)out, batch, logn, dir, st, out_int != 0);
+    return tile_fft<float>(s, (const cx<float>*)in, (cx<float>*)work, (cx<float>*)out, batch, logn, dir, st, out_int != 0);
 }
 
 }  // namespace pf

@@ -1,6 +1,7 @@
 """Scan of the legal sizes for slow outliers AND wrong values (development tool):
 
     python tools/size_scan.py LO HI [f32|f64] [stride]
+    python tools/size_scan.py sizes N1,N2,... [f32|f64]         (explicit list; sizes a transform type rejects are skipped)
 
 every `stride`-th legal size N = nmin 2^a 3^b 5^c in [LO, HI] (the set tests/test_fft_factors.c:36-61 enumerates), complex and
 real, the four direction x layout combinations, 256 MiB per launch, 10 untimed + 10 timed launches -> fraction of 8 TB/s on
@@ -43,16 +44,21 @@ def canonical_f64(x, N, tr):
 
 
 def main():
-    lo, hi = int(sys.argv[1]), int(sys.argv[2])
+    explicit = None
+    if sys.argv[1] == "sizes":
+        explicit = [int(v) for v in sys.argv[2].split(",")]
+        lo, hi = min(explicit), max(explicit)
+    else:
+        lo, hi = int(sys.argv[1]), int(sys.argv[2])
     dt = np.float64 if len(sys.argv) > 3 and sys.argv[3] == "f64" else np.float32
-    stride = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    stride = int(sys.argv[4]) if len(sys.argv) > 4 and not explicit else 1
     tdt = torch.float64 if dt == np.float64 else torch.float32
     tol = 1e-12 if dt == np.float64 else 1e-5
     bad = 0
     print(f"# tools/size_scan.py {lo} {hi} {np.dtype(dt).name} stride {stride}: fraction of 8 TB/s, "
           "fwd ordered / fwd unordered / bwd ordered / bwd unordered; err = max rel error of the checked vectors vs float64 numpy")
     for tr, name in ((pa.COMPLEX, "cplx"), (pa.REAL, "real")):
-        for N in legal_sizes(tr, lo, hi)[::stride]:
+        for N in ([v for v in explicit if v in set(legal_sizes(tr, lo, hi))] if explicit else legal_sizes(tr, lo, hi)[::stride]):
             s = pa.Setup(N, tr, dt)
             isz = np.dtype(dt).itemsize
             batch = max(2, (1 << 28) // (s.vec_scalars * isz))
