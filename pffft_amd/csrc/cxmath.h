@@ -370,6 +370,19 @@ template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a
     else if constexpr (R == 32) dft32<DIR>(a);
 }
 
+// value of the same register in lane ^ 1 / lane ^ 2 (DPP quad_perm [1, 0, 3, 2] / [2, 3, 0, 1]); every lane of the quad must be active
+template <int CTRL> __device__ __forceinline__ float dpp_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_quad(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename T> __device__ __forceinline__ T dpp_xor1(T v) { return dpp_quad<0xB1>(v); }
+template <typename T> __device__ __forceinline__ T dpp_xor2(T v) { return dpp_quad<0x4E>(v); }
+
 // 16-byte (float) / 32-byte (double) global access unit: 4 scalars
 template <typename T> struct vec4t;
 template <> struct vec4t<float> { typedef __attribute__((ext_vector_type(4))) float type; };

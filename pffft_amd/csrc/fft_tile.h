@@ -86,7 +86,11 @@ template <typename CX> __device__ __forceinline__ CX tile_w3(const CX* w3, unsig
 //   ALL points k of the rows, i.e. the four quarters m of every bin group: per point k' < L/4 and group of 4 adjacent outer
 //   indices the image yields one whole 128-byte (float) / 256-byte (double) block of the layout, per k' a contiguous run of
 //   C/4 blocks - the canonical -> internal reorder costs no extra sweep over HBM.
-template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0>
+// IINT = 1 (the first pass A of a backward transform only): the mirror image - the tile's C adjacent columns are read from the
+//   internal layout (pffft_transform backward takes it, :1423-1462 / cplx_preprocess): per point row n1' < L/4 the four
+//   quarters of the columns are a run of C/4 whole blocks, loaded as dense 16-byte units; a lane ^ 1 (float) / lane ^ 2 (double)
+//   DPP exchange turns the (re group, im group) units into the image's (re, im) sequence units.
+template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0, int IINT = 0>
 __global__ void __launch_bounds__((1 << LOGL) / 8 * PP, PF ? 2 : 3)
 tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned long long ntiles, TileDesc D, unsigned* ctr) {
     typedef cx<T> CX;
@@ -128,7 +132,8 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
         const unsigned long long rest = tile / D.TB;
         const unsigned a = (unsigned)(rest % D.TA);
         const unsigned long long vec = rest / D.TA;
-        src = in + vec * D.vstride + a * D.in_a + b * D.in_b;
+        if constexpr (IINT) { eb = a * D.in_a + b * D.in_b; src = in + vec * D.vstride; }
+        else src = in + vec * D.vstride + a * D.in_a + b * D.in_b;
         if constexpr (OINT) { eb = a * D.out_a + b * D.out_b; dst = out + vec * D.vstride; }
         else dst = out + vec * D.vstride + a * D.out_a + b * D.out_b;
         col0 = a * D.col_a + b * D.col_b;
@@ -136,8 +141,16 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     // pass A: unit p of points t + TPT m straight into the stage-0 operand registers;
     // pass B: elements g = tid + i WG of the [sequence][point] tile (coalesced over the points of a row)
     typedef typename std::conditional<SEQC != 0, U, CX>::type LD;
-    auto issue_loads = [&](const CX* src, LD (&r)[NLD]) {
-        if constexpr (SEQC) {
+    constexpr int UPB_ = 2 * (int)sizeof(T), UPP_ = (C / 4) * UPB_;   // 16-byte units per block / per point row of the internal layout
+    auto issue_loads = [&](const CX* src, LD (&r)[NLD], unsigned long long eb) {
+        if constexpr (IINT) {
+            static_assert(!IINT || (SEQC && ((L / 4) * UPP_) == 8 * WG), "internal-layout input: eight units per thread");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int g = tid + i * WG, ptq = g / UPP_, rr = g % UPP_, bb = rr / UPB_;
+                r[i] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + 4 * (eb + (unsigned long long)ptq * D.ips + 4 * bb)) + rr % UPB_);
+            }
+        } else if constexpr (SEQC) {
 #pragma unroll
             for (int m = 0; m < 8; ++m)
                 r[m] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)(t + TPT * m) * D.ips + S * p));
@@ -169,7 +182,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     }
     LD nxt[NLD];
     if constexpr (PF) {
-        if (tile < ntiles) { const CX* s0; CX* d0; unsigned cc; unsigned long long e0; tile_bases(tile, s0, d0, cc, e0); issue_loads(s0, nxt); }
+        if (tile < ntiles) { const CX* s0; CX* d0; unsigned cc; unsigned long long e0 = 0; tile_bases(tile, s0, d0, cc, e0); issue_loads(s0, nxt, e0); }
     }
     for (unsigned it = 0; tile < ntiles; ++it) {
         if (dyn && tid == 0) {
@@ -182,12 +195,37 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
         if constexpr (PF) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) cur[i] = nxt[i];
-            if (tile1 < ntiles) { const CX* s1; CX* d1; unsigned cc; unsigned long long e1; tile_bases(tile1, s1, d1, cc, e1); issue_loads(s1, nxt); }
+            if (tile1 < ntiles) { const CX* s1; CX* d1; unsigned cc; unsigned long long e1 = 0; tile_bases(tile1, s1, d1, cc, e1); issue_loads(s1, nxt, e1); }
         } else {
-            issue_loads(src, cur);
+            issue_loads(src, cur, ebase);
         }
         U v[8];   // v[m] = unit p of point t + TPT m
-        if constexpr (SEQC) {
+        if constexpr (IINT) {
+            // (re group, im group) units of the layout -> (re, im) sequence units of the image
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int g = tid + i * WG, ptq = g / UPP_, rr = g % UPP_, bb = rr / UPB_, m = (rr / (UPB_ / 4)) % 4, sub = rr % (UPB_ / 4);
+                U* dp = img + (ptq + m * (L / 4)) * PITCH + m * G::QSKEW + bb * (4 / S);   // quarter rows skewed: conflict-free
+                const U x = cur[i];
+                if constexpr (S == 2) {           // sub = part: even lane re0..3, odd lane im0..3 -> sequences (0, 1) / (2, 3)
+                    const T s0 = dpp_xor1(sub ? x.x : x.z), s1 = dpp_xor1(sub ? x.y : x.w);
+                    U o;
+                    if (sub) { o.x = s0; o.y = x.z; o.z = s1; o.w = x.w; }
+                    else { o.x = x.x; o.y = s0; o.z = x.y; o.w = s1; }
+                    dp[sub] = o;
+                } else {                          // sub = 2 part + (l / 2): lanes (re01, re23, im01, im23) -> sequences 0, 2, 1, 3
+                    const T sv = dpp_xor2(sub >> 1 ? x.x : x.y);
+                    U o;
+                    if (sub >> 1) { o.x = sv; o.y = x.y; }
+                    else { o.x = x.x; o.y = sv; }
+                    dp[2 * (sub & 1) + (sub >> 1)] = o;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p + (m / 2) * G::QSKEW];   // row t + m L/8 lies in quarter m / 2
+            __syncthreads();
+        } else if constexpr (SEQC) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cur[m];
         } else {

@@ -95,8 +95,9 @@ int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, i
                    hipStream_t st, const FcBatch& fb);
 
 // tile_tu.hip: power-of-two sizes beyond LDS in two / three passes (fft_tile.h); canonical complex, in -> out through `work`
-// (same size, distinct from both; in may equal out).  -1 when the size has no tile plan.  out_int (forward only): the
-// spectrum is stored in the pffft-internal layout by the last pass.
-int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, int logn, int dir, hipStream_t st, int out_int = 0);
+// (same size, distinct from both; in may equal out).  -1 when the size has no tile plan.  layout 1 (forward only): the
+// spectrum is stored in the pffft-internal layout by the last pass; layout 2 (backward only): it is read from that layout
+// by the first pass.
+int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, int logn, int dir, hipStream_t st, int layout = 0);
 
 }  // namespace pf

@@ -801,7 +801,11 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     int rc;
     // variant 87: the separate sweeps (zreorder_kernel + in-place pair pass) instead of the one-sweep block kernels (A/B)
     const bool blk = g_variant != 87;
-    if (!fwd && !ordered && blk) {   // internal -> canonical (complex) / -> packed spectrum of the inverse (real), one sweep
+    const bool pow2n = (s->n & (s->n - 1)) == 0 && g_variant != 80 && g_variant != 82;
+    // complex backward from the internal layout, power-of-two n: the first tile pass reads the layout itself (variant 86 = off)
+    const bool fuse_in = !fwd && !ordered && !real && pow2n && g_variant != 86;
+    if (fuse_in) {
+    } else if (!fwd && !ordered && blk) {   // internal -> canonical (complex) / -> packed spectrum of the inverse (real), one sweep
         if ((rc = launch_block<T>(s, real ? 3 : 1, in, (T*)bufA, batch, st))) return rc;
         cur = bufA;
     } else if (!fwd && real && blk) {   // canonical half-complex spectrum -> packed spectrum, out of place, one sweep
@@ -827,8 +831,9 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
         while ((1 << logn) < s->n) ++logn;
         // complex forward into the internal layout: the last tile pass stores the layout itself (variant 86 = separate reorder sweep, A/B)
         const bool fuse_int = fwd && !ordered && !real && g_variant != 86;
-        const int trc = launch_tile_fft(s, cur, bufB, fuse_int ? (cx<T>*)out : dest, batch, logn, dir, st, fuse_int ? 1 : 0);
+        const int trc = launch_tile_fft(s, cur, bufB, fuse_int ? (cx<T>*)out : dest, batch, logn, dir, st, fuse_int ? 1 : fuse_in ? 2 : 0);
         if (trc > 0) return trc;
+        if (trc < 0 && fuse_in) { g_last_error = "pffft_hip: no tile plan for a power-of-two size beyond LDS"; return (int)hipErrorInvalidValue; }
         done = trc == 0;
         out_is_internal = done && fuse_int;
     }
