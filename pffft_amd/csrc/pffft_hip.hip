@@ -503,24 +503,21 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
     }
     if constexpr (sizeof(T) == 4) {
         if (n == 64 && real && dir == PFFFT_FORWARD && g_variant == 0) { *e = tiled_entry<T, TiledAltF32b::A64>(dir, real); return true; }
-        // three-stage n = 8192 (tools/c3_ab.py): complex 0.65-0.71 (Stockham) -> 0.71-0.76; real N = 16384 forward 0.57-0.60 -> 0.62
-        if (n == 8192 && g_variant == 0 && (!real || dir == PFFFT_FORWARD)) {
-            if (!real && dir == PFFFT_FORWARD) *e = tiled_entry<T, TiledAltF32b::T8192>(dir, real);
-            else *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real);
-            return true;
-        }
-        // three-stage, 32 points per thread (tools/c3_ab.py, gpurun_out/c3_ab3.log; fraction of 8 TB/s, before -> now):
-        //   N = 2048 complex 0.58-0.72 -> 0.71-0.76 (one wavefront per transform), N = 4096 real 0.58-0.62 -> 0.64-0.66,
-        //   N = 4096 complex 0.62-0.68 -> 0.68-0.77, N = 8192 real 0.53-0.57 -> 0.59-0.69
-        // prefetch where it does not spill (forward transforms into the internal layout do)
-        if (g_variant == 0 && n == 2048) {
+        // Routing re-measured in round 3 after the packed-arithmetic change (tools/route_ab.py, 1 GiB per launch, 10 + 20
+        // launches, sum of both layouts of a direction; both layouts of a direction share one configuration):
+        //   n = 8192: real forward (C3) three-stage T8192np 0.657 / 0.706; complex forward runs the Stockham plan (0.70 / 0.76
+        //             against 0.68 / 0.68), complex backward the four-stage TiledPick (0.77 / 0.71 against 0.70 / 0.70)
+        //   n = 4096: complex forward three-stage (0.72 / 0.73 against 0.69 / 0.71); complex backward and real (N = 8192) the
+        //             four-stage TiledPick (0.79 / 0.74 against 0.73 / 0.73; real 0.64 / 0.70 / 0.72 / 0.72 against 0.65 / 0.66 / 0.64 / 0.61)
+        //   n = 2048: three-stage, one wavefront per transform, except complex backward (TiledPick 0.81 / 0.76 against 0.75 / 0.76)
+        if (n == 8192 && g_variant == 0 && real && dir == PFFFT_FORWARD) { *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real); return true; }
+        if (g_variant == 0 && n == 2048 && (real || dir == PFFFT_FORWARD)) {
             const bool pf = !real || (dir == PFFFT_BACKWARD && !ordered);
             *e = pf ? tiled_entry<T, TiledAltF32b::T2048>(dir, real) : tiled_entry<T, TiledAltF32b::T2048np>(dir, real);
             return true;
         }
-        if (g_variant == 0 && n == 4096) {
-            const bool pf = dir == PFFFT_BACKWARD || (!real && ordered);
-            *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real);
+        if (g_variant == 0 && n == 4096 && !real && dir == PFFFT_FORWARD) {
+            *e = ordered ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real);
             return true;
         }
         if (g_variant == 77 || g_variant == 78) {
@@ -930,8 +927,12 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         if (s->sk_ok && g_variant != 54 && !(g_variant >= 70 && g_variant <= 79)) {
             const int n = s->n;
             const bool cplx = s->transform == PFFFT_COMPLEX;
-            if (sizeof(T) == 4) stock = cplx ? (n <= 64) : (n <= 32 || (n == 8192 && dir == PFFFT_BACKWARD));
-            else stock = cplx ? (n <= 64 || n >= 8192) : (n <= 32 || n >= 8192 || (n == 4096 && dir == PFFFT_BACKWARD));
+            const bool fw = dir == PFFFT_FORWARD;
+            // (round 3, tools/route_ab.py: float complex n = 128 0.65 -> 0.71-0.74, n = 8192 forward 0.68 -> 0.70 / 0.76; float real
+            //  N = 128 0.66 / 0.66 / 0.69 / 0.69 -> 0.62 / 0.75 / 0.73 / 0.73; double complex n = 128 / 256 0.68 -> 0.75, n = 4096 forward
+            //  0.70 -> 0.73 / 0.75; double real N = 128 0.39-0.50 -> 0.66-0.76, N = 256 backward 0.70 -> 0.76, N = 512 0.70-0.73 -> 0.73-0.75)
+            if (sizeof(T) == 4) stock = cplx ? (n <= 64 || n == 128 || (n == 8192 && fw)) : (n <= 64 || (n == 8192 && !fw));
+            else stock = cplx ? (n <= 256 || n >= 8192 || (n == 4096 && fw)) : (n <= 64 || (n == 128 && !fw) || n == 256 || n >= 8192 || (n == 4096 && !fw));
         }
         if (!stock) return launch_tiled<T>(s, in, out, batch, dir, ordered, st);
         return launch_stock<T>(s, in, out, batch, dir, ordered, st);
