@@ -176,6 +176,10 @@ int pffft_hip_device_count(void);
  * tests that hold every alternative to the same bar.  The selector is THREAD-LOCAL: it affects only calls made by the
  * thread that set it. */
 void pffft_hip_set_variant(int variant);
+/* 1 when the library was built with -DPFFFT_HIP_VARIANTS (development build: both variants of every Stockham plan are
+ * instantiated for A/B measurements), 0 for the product build (the adopted variant only; a selector that asks for the
+ * other one gets the same arithmetic from the kernel that exists). */
+int pffft_hip_has_variants(void);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,7 @@ def lib():
     L.pffft_hip_last_error.restype = C.c_char_p
     L.pffft_hip_device_count.restype = C.c_int
     L.pffft_hip_set_variant.restype = None; L.pffft_hip_set_variant.argtypes = [C.c_int]
+    L.pffft_hip_has_variants.restype = C.c_int; L.pffft_hip_has_variants.argtypes = []
     _LIB = L
     return L
 
@@ -139,6 +140,11 @@ def last_error() -> str:
 
 def set_variant(v: int) -> None:
     lib().pffft_hip_set_variant(int(v))
+
+
+def has_variants() -> bool:
+    """True for a development build (PFFFT_HIP_VARIANTS=1): both variants of every Stockham plan are instantiated."""
+    return bool(lib().pffft_hip_has_variants())
 
 
 def kernel_name(setup: "Setup") -> str:

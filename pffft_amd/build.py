@@ -62,6 +62,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
              "-Wno-pass-failed",   # "loop not unrolled" remarks of fully unrollable radix loops hid real diagnostics
              "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+    # PFFFT_HIP_VARIANTS=1: development build - BOTH variants (deposit / direct first stage) of every Stockham plan are
+    # instantiated so that the A/B selectors 54 / 55 and tools/tune_stock_df.py can compare them (twice the generated kernels,
+    # 10 instead of 5 minutes).  The product build instantiates the adopted one only (tools/gen_stock_plans.hip).
+    if os.environ.get("PFFFT_HIP_VARIANTS") == "1":
+        flags.append("-DPFFFT_HIP_VARIANTS")
     os.makedirs(OBJDIR, exist_ok=True)
     # one hipcc per translation unit, in parallel (the generated Stockham units hold ~600 kernel instantiations);
     # a unit is recompiled only when one of the files in its depfile changed

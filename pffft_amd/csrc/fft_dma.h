@@ -1,15 +1,9 @@
-// LDS-DMA staged variants of the register-tiled power-of-two kernels (fft_tiled.h) for the transforms that need a
-// whole workgroup per vector (n >= 2048 complex points in float: 16 ... 64 KiB per vector).
+// LDS-DMA staged overlap-save block kernel (pffastconv, src/pffastconv.c:207-261) for the blocks that need a whole
+// workgroup (Nfft/2 = 2048 ... 8192 complex points in float: 16 ... 64 KiB per block), built from the register-tiled
+// transform of fft_tiled.h.  (Round 2 also had plain-transform kernels of this organisation; they measured 0.55-0.73
+// against 0.68-0.80 for the register-staged ones and were removed in round 3 - DESIGN.md appendix.)
 //
-// Same reference functions as fft_tiled.h (cfftf1_ps / rfftf1_ps / rfftb1_ps pass drivers, src/pffft_priv_impl.h:809-901,
-// :1004-1048, with the finalize / preprocess / zreorder steps :1158-1462 folded in): one pass over HBM per vector.
-//
-// What was wrong with the register-staged kernels at these sizes (VERDICT r01 "C3 0.63"): a vector does
-// not fit the registers twice, so the loads of the NEXT vector could not be kept in flight while the current one was
-// transformed (the prefetch registers spilled), and with 64 KiB of LDS image per vector only two workgroups fit a CU —
-// HBM idled whenever both were in a compute phase.
-//
-// Here ONE persistent 512-thread workgroup per CU owns TWO LDS images.  While image A is transformed in place (stage-0
+// ONE persistent 512-thread workgroup per CU owns TWO LDS images.  While image A is transformed in place (stage-0
 // operands are read straight from it, the exchanges of the later stages reuse it), the next group of vectors lands in
 // image B by `global_load_lds_dwordx4` — asynchronous global -> LDS copies that occupy no VGPR and need no ds_write
 // pass.  The probe tools/dma_probe.hip measured this skeleton (64 KiB groups pulled in order from an atomic counter,
@@ -56,229 +50,6 @@ template <class C> struct DmaGeom {
     static_assert(LDS_BYTES <= 160 * 1024, "two images must fit LDS");
     static_assert(C::TWMODE == 3 || C::TWMODE == 0, "register twiddles only (no LDS table next to two images)");
 };
-
-// flags: bit0 = input in internal layout, bit1 = output in internal layout
-// COUNTED = 1: the counted vmcnt of the header; 0: vmcnt(0) (A/B)
-template <class C, int DIR, int REAL, int COUNTED = 1>
-__global__ void __launch_bounds__(C::WG_THREADS, 1)
-fft_dma_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned batch, int flags,
-               const cx<typename C::real_t>* __restrict__ twg, const cx<typename C::real_t>* __restrict__ twrg,
-               unsigned* ctr) {
-    typedef typename C::real_t T;
-    typedef cx<T> CX;
-    typedef Tiled<C, DIR, REAL> K;
-    typedef typename K::S0 S0;
-    typedef typename K::SL SL;
-    typedef ChunkOps<T> CO;
-    typedef DmaGeom<C> G;
-    constexpr int n = C::n, E = C::E, TPT = C::TPT, VEC = C::VEC, CH = C::CH, NCH = C::NCH;
-    constexpr int R0 = K::R0, RL = K::RL;
-    static_assert(VEC == 1 || (S0::PAIR && SL::PAIR), "float configs need an even butterfly count in the first/last stage");
-    static_assert(TPT >= 64, "one or more wavefronts per transform");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
-    const int slot = threadIdx.x / TPT, t = threadIdx.x % TPT;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + 2 * (size_t)G::BUF_BYTES);
-    const bool in_int = flags & 1, out_int = flags & 2;
-    const bool plain_in = REAL ? (DIR == FWD) : !in_int;   // stage-0 operand order straight from the landed vector
-    const bool plain_out = REAL ? (DIR == BWD) : !out_int;
-
-    typename K::Tw w;
-    K::load_tw(w, t, twg, twrg);
-    const CX* twt = twg;
-
-    const bool dyn = ctr != nullptr;
-    unsigned pend = 0;
-    unsigned g = blockIdx.x;
-    if (dyn && threadIdx.x == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
-    __syncthreads();
-    if (dyn) g = s_next[0];
-    const size_t last = (size_t)batch - 1;
-
-    // pieces of group `grp` into image `b`: piece p = wave + WAVES i holds bytes [1024 p, 1024 p + 1024) of the group
-    auto issue = [&](unsigned grp, int b) {
-#pragma unroll
-        for (int i = 0; i < G::PPW; ++i) {
-            const int p = wave + G::WAVES * i;
-            const int sl = p / G::PPV, pv = p % G::PPV;
-            size_t tr = (size_t)grp * C::T_PER_WG + sl;
-            if (tr > last) tr = last;                           // slots beyond the batch re-read the last vector
-            const char* src = reinterpret_cast<const char*>(in) + tr * (size_t)G::VEC_BYTES + pv * 1024 + lane * 16;
-            glds16(src, lds0 + (unsigned)(b * G::BUF_BYTES + sl * G::IMG_BYTES + pv * 1024));
-        }
-    };
-    issue(g, 0);
-    int b = 0;
-    bool prev_full = false;
-    for (unsigned it = 0; (size_t)g * C::T_PER_WG < batch; ++it) {
-        if (dyn && threadIdx.x == 0) {
-            s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
-        }
-        // ---- the group of this iteration has landed (its pieces are older than the previous iteration's stores)
-        if (COUNTED && prev_full) wait_vmcnt<G::NSTORE>(); else wait_vmcnt<0>();
-        wg_sync_raw();
-        const unsigned gn = dyn ? s_next[(it + 1) & 1] : g + gridDim.x;
-        issue(gn, b ^ 1);                                        // lands while this group is transformed
-        const size_t tr = (size_t)g * C::T_PER_WG + slot;
-        const bool active = tr < batch;
-        prev_full = ((size_t)g + 1) * C::T_PER_WG <= batch;      // every wave issues exactly NSTORE stores
-        T* dst = out + (active ? tr : last) * 2 * (size_t)n;
-        CX* img = reinterpret_cast<CX*>(smem_raw + (size_t)b * G::BUF_BYTES) + (size_t)slot * C::IMG;
-        T* imgs = reinterpret_cast<T*>(img);
-        const chunk16* land16 = reinterpret_cast<const chunk16*>(img);  // the landed vector: linear, unpadded
-        CX v[E];
-        int tl = t;
-        asm volatile("" : "+v"(tl));
-
-        // ------------------------------------------------------------------ input
-        if (plain_in) {
-            if constexpr (VEC == 2) {
-#pragma unroll
-                for (int ii = 0; ii < S0::B / 2; ++ii)
-#pragma unroll
-                    for (int q = 0; q < R0; ++q) {
-                        const chunk16 c = land16[K::plain_chunk(t, ii * R0 + q)];
-                        v[(2 * ii) * R0 + q] = mk<T>(c.x, c.y);
-                        v[(2 * ii + 1) * R0 + q] = mk<T>(c.z, c.w);
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NCH; ++i) {
-                    const chunk16 c = land16[K::plain_chunk(t, i)];
-                    v[i] = mk<T>(CO::get(c, 0), CO::get(c, 1));
-                }
-            }
-        } else if (in_int) {
-            // internal layout: the landed linear chunks move into the padded block image (16-byte accesses), then every
-            // thread picks the scalars of its own stage-0 operands
-            chunk16 raw[NCH];
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) raw[i] = land16[t + TPT * i];
-            wg_sync_raw();
-            chunk16* im16 = reinterpret_cast<chunk16*>(imgs);
-            constexpr int CPB = 32 / CH;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = t + TPT * i;
-                im16[(c / CPB) * (C::IBS / CH) + (c % CPB)] = raw[i];
-            }
-            wg_sync_raw();
-#pragma unroll
-            for (int u = 0; u < S0::B; ++u)
-#pragma unroll
-                for (int q = 0; q < R0; ++q) {
-                    const int ip = K::template ipos<R0>(K::template jm<0>(t, u), q);
-                    v[u * R0 + q] = mk<T>(imgs[ip], imgs[ip + 4]);
-                }
-            if constexpr (REAL) K::pair_regs(v, t, w);
-        } else {
-            // canonical half-complex spectrum (real backward): the landed vector IS the natural-order image, unpadded
-#pragma unroll
-            for (int u = 0; u < S0::B; ++u)
-#pragma unroll
-                for (int q = 0; q < R0; ++q) {
-                    const int j = K::template jm<0>(tl, u);
-                    v[u * R0 + q] = lds_ld(img + j + q * (n / R0));
-                }
-            if constexpr (REAL) K::pair_regs(v, t, w);
-        }
-
-        // ------------------------------------------------------------------ transform (exchanges reuse the image in place)
-        K::template butterflies<0>(v, t, w, twt);
-        wg_sync_raw();                                           // every thread holds its stage-0 operands: the image is free
-        if constexpr (C::NS > 1) { K::template xwrite<0>(v, t, img); wg_sync_raw(); K::template xread<0>(v, t, img); wg_sync_raw(); K::template butterflies<1>(v, t, w, twt); }
-        if constexpr (C::NS > 2) { K::template xwrite<1>(v, t, img); wg_sync_raw(); K::template xread<1>(v, t, img); wg_sync_raw(); K::template butterflies<2>(v, t, w, twt); }
-        if constexpr (C::NS > 3) { K::template xwrite<2>(v, t, img); wg_sync_raw(); K::template xread<2>(v, t, img); wg_sync_raw(); K::template butterflies<3>(v, t, w, twt); }
-
-        // ------------------------------------------------------------------ output
-        if (plain_out) {
-            if (active) {
-                chunk16* d16 = reinterpret_cast<chunk16*>(dst);
-                if constexpr (VEC == 2) {
-#pragma unroll
-                    for (int ii = 0; ii < SL::B / 2; ++ii)
-#pragma unroll
-                        for (int d = 0; d < RL; ++d) {
-                            const CX a = v[(2 * ii) * RL + d], bb = v[(2 * ii + 1) * RL + d];
-                            chunk16 x; x.x = a.x; x.y = a.y; x.z = bb.x; x.w = bb.y;
-                            __builtin_nontemporal_store(x, d16 + t + TPT * ii + d * (n / (2 * RL)));
-                        }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < SL::B; ++u)
-#pragma unroll
-                        for (int d = 0; d < RL; ++d) {
-                            chunk16 x;
-                            CO::set(x, 0, v[u * RL + d].x); CO::set(x, 1, v[u * RL + d].y);
-                            __builtin_nontemporal_store(x, d16 + t + TPT * u + d * (n / RL));
-                        }
-                }
-            }
-        } else {
-            if constexpr (REAL) K::pair_regs(v, t, w);
-            if (out_int) {
-                // scatter re / im scalars into the padded internal-layout image, read it back linearly
-#pragma unroll
-                for (int u = 0; u < SL::B; ++u)
-#pragma unroll
-                    for (int d = 0; d < RL; ++d) {
-                        const int ip = K::template ipos<RL>(K::template jm<C::NS - 1>(t, u), d);
-                        imgs[ip] = v[u * RL + d].x;
-                        imgs[ip + 4] = v[u * RL + d].y;
-                    }
-                wg_sync_raw();
-                const chunk16* im16 = reinterpret_cast<const chunk16*>(imgs);
-                chunk16* d16o = reinterpret_cast<chunk16*>(dst);
-                constexpr int CPB = 32 / CH;
-#pragma unroll
-                for (int i = 0; i < NCH; ++i) {
-                    const int c = t + TPT * i;
-                    const chunk16 o = im16[(c / CPB) * (C::IBS / CH) + (c % CPB)];
-                    if (active) __builtin_nontemporal_store(o, d16o + c);
-                }
-            } else {
-                // canonical half-complex spectrum (real forward, ordered): natural-order image, linear chunks out
-#pragma unroll
-                for (int u = 0; u < SL::B; ++u)
-#pragma unroll
-                    for (int d = 0; d < RL; ++d) {
-                        const int j = K::template jm<C::NS - 1>(t, u);
-                        lds_st(img + j + C::PADN * (j >> 6) + K::nat_off(d * (n / RL)), v[u * RL + d]);
-                    }
-                wg_sync_raw();
-                chunk16* d16 = reinterpret_cast<chunk16*>(dst);
-#pragma unroll
-                for (int i = 0; i < NCH; ++i) {
-                    const int c = tl + TPT * i;
-                    chunk16 o;
-                    if constexpr (VEC == 2) {
-                        const CX a = lds_ld(img + phys_nat<C>(2 * c)), bb = lds_ld(img + phys_nat<C>(2 * c + 1));
-                        o.x = a.x; o.y = a.y; o.z = bb.x; o.w = bb.y;
-                    } else {
-                        const CX a = lds_ld(img + phys_nat<C>(c));
-                        CO::set(o, 0, a.x); CO::set(o, 1, a.y);
-                    }
-                    if (active) __builtin_nontemporal_store(o, d16 + c);
-                }
-            }
-        }
-        g = gn;
-        b ^= 1;
-    }
-    wait_vmcnt<0>();                                             // the speculative pieces of the group after the last one
-    if (dyn && threadIdx.x == 0) {
-        __threadfence();
-        unsigned d = atomicAdd(&ctr[1], 1u);
-        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // Overlap-save FIR block kernel on the same skeleton (the register-staged one: fft_fir.h; reference: the block loop of
@@ -474,7 +245,6 @@ fastconv_dma_kernel(const float* __restrict__ x, float* __restrict__ y, const cx
 // 16 points per thread, 512-thread workgroups: n = 8192 one vector per workgroup iteration, 4096 two, 2048 four.
 struct DmaCfgF32 {
     typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 0, 512, 1> D8192;
-    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 0, 0, 512, 1> D8192t0;   // every twiddle in registers
     typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 0, 512, 1> D4096;
     typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 8, 3, 0, 512, 1> D2048;
 };

@@ -1,23 +1,8 @@
-// Generic LDS-resident batched FFT kernel: any n = 2^a 3^b 5^c that fits in LDS, float or double,
-// real or complex, forward or backward, canonical ("ordered") or pffft-internal ("unordered")
-// spectrum layout.  This is the coverage kernel behind every pffft_* / pffftd_* entry; the
-// size-specialised kernels (fft_c1024.h ...) replace it on the headline shapes.
-//
-// What it replaces in the reference (all in src/pffft_priv_impl.h):
-//   cfftf1_ps :1004-1048 + passf2/3/4/5_ps :122-321   -> stage<R>() in-place DIF passes in LDS
-//   rfftf1_ps/rfftb1_ps :809-901 + radf*/radb* :323-807 -> complex FFT of length N/2 + real_post/real_pre
-//   pffft_cplx_finalize/_preprocess :1195-1270, pffft_real_finalize/_preprocess :1330-1462
-//                                                       -> absorbed: one length-n transform, no 4-lane stitch
-//   pffft_zreorder :1158-1193                           -> bin_of(): the layout is applied on the global
-//                                                          load / store address, never as a separate sweep
-//   pffft_transform_internal :1465-1532                 -> the kernel body (load, passes, store)
-//
-// Structure (one workgroup handles G transforms per pass, grid-stride over the batch):
-//   L  global -> LDS, coalesced 4-scalar loads, scatter to natural order (undoing the internal layout)
-//   P  (real backward) half-complex spectrum -> packed complex spectrum, pairs (k, n-k) in place
-//   C  radix-2/3/4/5 decimation-in-frequency passes, in place, output left digit-reversed in LDS
-//   Q  (real forward) packed complex spectrum -> half-complex spectrum, pairs in place
-//   S  LDS -> global, coalesced 4-scalar stores, gather through digit reversal + layout map
+// Shared pieces of the LDS / streaming kernels that survive from the first coverage kernel (an in-place radix 2-5 transform in
+// one LDS image; every size it served now runs a Stockham plan or the streaming passes, and the kernel itself was removed in
+// round 3): the radix plan struct the setup keeps, bin_of() - the internal-layout map of SURVEY.md appendix A -, the in-place
+// DIF stage used by the strided fallback of fft_big.h, and the direct (no LDS image) zreorder / zconvolve kernels that serve
+// vectors beyond LDS and double precision (pffft_zreorder src/pffft_priv_impl.h:1158-1193, pffft_zconvolve_* :1534-1684).
 #pragma once
 #include "cxmath.h"
 
@@ -97,193 +82,6 @@ __device__ __forceinline__ void stage(cx<T>* z, int total, int Ls, int tw_stride
         z[gpad(e0)] = a[0];
 #pragma unroll
         for (int d = 1; d < R; ++d) z[gpad(e0 + d * m)] = twmul<DIR>(a[d], tw[(i * d) * tw_stride]);
-    }
-}
-
-// LDS carve-up (bytes) of the generic kernel: data image, then (when they fit) the W_n^j table, the W_N^k
-// table of the real pair pass and the digit-reversal table — read thousands of times per transform, and a
-// global (L2) load in a barrier-separated pass is what such a kernel waits for.
-struct GenericLds {
-    size_t tw, twr, pos, next, total;
-};
-template <typename T>
-__host__ __device__ inline GenericLds generic_lds(int n, int G, int is_real, int tables) {
-    GenericLds l;
-    size_t o = (((size_t)G * n + ((size_t)G * n >> 5) + 2) * sizeof(cx<T>) + 15) / 16 * 16;
-    l.tw = o;  if (tables) o += (size_t)n * sizeof(cx<T>);
-    l.twr = o; if (tables && is_real) o += ((size_t)n / 2 + 1) * sizeof(cx<T>);
-    l.pos = o; if (tables) o += (((size_t)n * 2 + 15) / 16) * 16;
-    l.next = o; o += 16;
-    l.total = o;
-    return l;
-}
-
-template <typename T, int DIR>
-__global__ void __launch_bounds__(1024)
-fft_generic_kernel(const T* in, T* out, size_t batch, GenericPlan p, int in_internal, int out_internal,
-                   const cx<T>* __restrict__ twg, const cx<T>* __restrict__ twrg, int tables, unsigned* ctr) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cx<T>* z = reinterpret_cast<cx<T>*>(smem_raw);
-    T* zs = reinterpret_cast<T*>(smem_raw);
-    const int n = p.n, G = p.G;
-    const GenericLds L = generic_lds<T>(n, G, p.is_real, tables);
-    const cx<T>* tw = twg;
-    const cx<T>* twr = twrg;
-    const unsigned short* lpos = nullptr;
-    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + L.next);
-    if (tables) {
-        cx<T>* ltw = reinterpret_cast<cx<T>*>(smem_raw + L.tw);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) ltw[i] = twg[i];
-        tw = ltw;
-        if (p.is_real) {
-            cx<T>* ltwr = reinterpret_cast<cx<T>*>(smem_raw + L.twr);
-            for (int i = threadIdx.x; i <= n / 2; i += blockDim.x) ltwr[i] = twrg[i];
-            twr = ltwr;
-        }
-        unsigned short* lp = reinterpret_cast<unsigned short*>(smem_raw + L.pos);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) lp[i] = (unsigned short)pos_of(i, p);
-        lpos = lp;
-    }
-    auto POS = [&](int k) -> int { return lpos ? (int)lpos[k] : pos_of(k, p); };
-    const int nv = n >> 1;  // 4-scalar groups per vector (2n scalars complex, N = 2n scalars real)
-    const float inv_nv = 1.0f / (float)nv, inv_per = 1.0f / (float)(nv + 1);
-    const vec4<T>* in4 = reinterpret_cast<const vec4<T>*>(in);
-    vec4<T>* out4 = reinterpret_cast<vec4<T>*>(out);
-
-    // groups of G consecutive vectors are pulled in order from the counter (ctr == nullptr: one group per
-    // workgroup, static) — see fft_c1024.h for what in-order sweeping buys on HBM
-    const bool dyn = ctr != nullptr;
-    unsigned pend = 0, g0 = blockIdx.x;
-    if (dyn && threadIdx.x == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
-    __syncthreads();
-    if (dyn) g0 = s_next[0];
-    for (unsigned it = 0; (size_t)g0 * G < batch; ++it) {
-        if (dyn && threadIdx.x == 0) {
-            s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
-        }
-        const size_t t0 = (size_t)g0 * G;
-        const int g_here = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);
-        const int totv = g_here * nv;
-        // ---- L: load (4 independent 16-byte loads in flight per thread before the first LDS write) ----
-        for (int base = threadIdx.x; base < totv; base += 4 * blockDim.x) {
-            vec4<T> vals[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int iv = base + u * blockDim.x;
-                if (iv < totv) vals[u] = __builtin_nontemporal_load(in4 + t0 * nv + iv);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int iv = base + u * blockDim.x;
-                if (iv >= totv) continue;
-                const vec4<T> val = vals[u];
-                if (!in_internal) {
-                    z[gpad(2 * iv)] = mk<T>(val.x, val.y);
-                    z[gpad(2 * iv + 1)] = mk<T>(val.z, val.w);
-                } else {
-                    int g = fdiv(iv, nv, inv_nv), v = iv - g * nv, part = v & 1;
-                    const int eb = g * n;
-                    zs[2 * gpad(eb + bin_of(v, 0, n, p.is_real)) + part] = val.x;
-                    zs[2 * gpad(eb + bin_of(v, 1, n, p.is_real)) + part] = val.y;
-                    zs[2 * gpad(eb + bin_of(v, 2, n, p.is_real)) + part] = val.z;
-                    zs[2 * gpad(eb + bin_of(v, 3, n, p.is_real)) + part] = val.w;
-                }
-            }
-        }
-        __syncthreads();
-        const unsigned gn = dyn ? s_next[(it + 1) & 1] : g0 + gridDim.x;
-        // ---- P: real backward pre-processing: Z'[k] = (A+B) + i w (A-B), Z'[n-k] = conj((A+B) - i w (A-B)),
-        //         A = X[k], B = conj X[n-k], w = exp(+2 pi i k / N)  (gives N*x after the unscaled inverse) ----
-        if (p.is_real && DIR == BWD) {
-            const int half = n >> 1, per = half + 1;
-            for (int id = threadIdx.x; id < g_here * per; id += blockDim.x) {
-                int g = fdiv(id, per, inv_per), k = id - g * per;
-                const int eb = g * n;
-                if (k == 0) {
-                    cx<T> a = z[gpad(eb)];
-                    z[gpad(eb)] = mk<T>(a.x + a.y, a.x - a.y);
-                } else if (k == half) {
-                    cx<T> a = z[gpad(eb + half)];
-                    z[gpad(eb + half)] = mk<T>((T)2 * a.x, (T)-2 * a.y);
-                } else {
-                    cx<T> A = z[gpad(eb + k)], B = conj(z[gpad(eb + n - k)]);
-                    cx<T> S = A + B, Dm = cmulc(A - B, twr[k]);  // (A-B) * conj(W_N^k)
-                    cx<T> D = mk<T>(-Dm.y, Dm.x);                // * i
-                    z[gpad(eb + k)] = S + D;
-                    z[gpad(eb + n - k)] = conj(S - D);
-                }
-            }
-            __syncthreads();
-        }
-        // ---- C: in-place DIF passes ----
-        {
-            int Ls = n;
-            const int total = g_here * n;
-            for (int s = 0; s < p.nstages; ++s) {
-                const int R = p.radix[s];
-                const int tws = n / Ls;
-                switch (R) {
-                    case 2: stage<T, 2, DIR>(z, total, Ls, tws, tw); break;
-                    case 3: stage<T, 3, DIR>(z, total, Ls, tws, tw); break;
-                    case 4: stage<T, 4, DIR>(z, total, Ls, tws, tw); break;
-                    default: stage<T, 5, DIR>(z, total, Ls, tws, tw); break;
-                }
-                Ls /= R;
-                __syncthreads();
-            }
-        }
-        // ---- Q: real forward post-processing: X[k] = S + D, X[n-k] = conj(S - D),
-        //         S = (A+B)/2, D = -(i/2) W_N^k (A-B), A = Z[k], B = conj Z[n-k] ----
-        if (p.is_real && DIR == FWD) {
-            const int half = n >> 1, per = half + 1;
-            for (int id = threadIdx.x; id < g_here * per; id += blockDim.x) {
-                int g = fdiv(id, per, inv_per), k = id - g * per;
-                const int eb = g * n;
-                if (k == 0) {
-                    cx<T> a = z[gpad(eb)];
-                    z[gpad(eb)] = mk<T>(a.x + a.y, a.x - a.y);  // (DC, Nyquist): include/pffft/pffft.h:144-152
-                } else if (k == half) {
-                    int pk = gpad(eb + POS(half));
-                    z[pk] = conj(z[pk]);
-                } else {
-                    int pk = gpad(eb + POS(k)), pn = gpad(eb + POS(n - k));
-                    cx<T> A = z[pk], B = conj(z[pn]);
-                    cx<T> S = (A + B) * (T)0.5, Dm = cmul(A - B, twr[k]) * (T)0.5;
-                    cx<T> D = mk<T>(Dm.y, -Dm.x);  // * (-i)
-                    z[pk] = S + D;
-                    z[pn] = conj(S - D);
-                }
-            }
-            __syncthreads();
-        }
-        // ---- S: store ----
-        for (int iv = threadIdx.x; iv < totv; iv += blockDim.x) {
-            int g = fdiv(iv, nv, inv_nv), v = iv - g * nv;
-            const int eb = g * n;
-            vec4<T> val;
-            if (!out_internal) {
-                cx<T> a = z[gpad(eb + POS(2 * v))], b = z[gpad(eb + POS(2 * v + 1))];
-                val.x = a.x; val.y = a.y; val.z = b.x; val.w = b.y;
-            } else {
-                const int part = v & 1;
-                val.x = zs[2 * gpad(eb + POS(bin_of(v, 0, n, p.is_real))) + part];
-                val.y = zs[2 * gpad(eb + POS(bin_of(v, 1, n, p.is_real))) + part];
-                val.z = zs[2 * gpad(eb + POS(bin_of(v, 2, n, p.is_real))) + part];
-                val.w = zs[2 * gpad(eb + POS(bin_of(v, 3, n, p.is_real))) + part];
-            }
-            __builtin_nontemporal_store(val, out4 + t0 * nv + iv);
-        }
-        __syncthreads();
-        g0 = gn;
-    }
-    if (dyn && threadIdx.x == 0) {
-        __threadfence();
-        unsigned d = atomicAdd(&ctr[1], 1u);
-        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
     }
 }
 

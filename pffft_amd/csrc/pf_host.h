@@ -63,7 +63,6 @@ struct Setup {
     int device = -1;        // the device the tables / counters / scratch of this setup live on (bound at first use)
     void* d_tw = nullptr;   // W_n^j, j < n
     void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
-    void* d_tw_sub = nullptr;  // W_1024^j of the wave-local sub-transform (fft_split.h), created on first use
     void* d_twc[2] = {nullptr, nullptr};  // compact per-stage base twiddles of the Stockham plans (forward / backward order)
     unsigned* d_ctr = nullptr;             // ring of {next, done} work counters for the dynamic kernels
     std::atomic<unsigned> ctr_slot{0};
@@ -87,10 +86,7 @@ constexpr uint32_t MAGIC = 0x50464654u;  // "PFFT"
 
 struct FcBatch { int nsig; size_t xstride, ystride; };   // signals of one pffastconv call (1 for the reference entries)
 
-// dma_tu.hip: the LDS-DMA staged kernels (fft_dma.h).  launch_dma returns -1 when the size has no such kernel.
-int launch_dma(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st, int mode);
-// the split kernel of fft_split.h (real forward, n = 8192 float): -1 when the setup is not that size
-int launch_split(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st, int prefetch);
+// dma_tu.hip: the LDS-DMA staged FIR block kernel (fft_dma.h); -1 when the block length has no such kernel
 int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
                    hipStream_t st, const FcBatch& fb);
 

@@ -126,11 +126,13 @@ static bool sub_is_fast(const Setup* q) {
     if (q->kernel == K_TILED || q->kernel == K_C1024_F32) return true;
     if (q->kernel != K_GENERIC) return false;
     const int flags = q->transform == PFFFT_REAL ? 8 : 0;   // forward, canonical layouts (fft_stock.h)
-    if (q->is_double)
-        return (q->skw_ok && stock_ct_lookup(q->skw[0], flags, true, (const double*)nullptr)) ||
-               (q->sk_ok && stock_ct_lookup(q->sk[0], flags, false, (const double*)nullptr));
-    return (q->skw_ok && stock_ct_lookup(q->skw[0], flags, true, (const float*)nullptr)) ||
-           (q->sk_ok && stock_ct_lookup(q->sk[0], flags, false, (const float*)nullptr));
+    // (the product build instantiates ONE of the two variants of a plan - deposit or direct first stage, bit 4 -, see
+    //  tools/gen_stock_plans.hip: a plan exists when either is there)
+    auto has = [&](const StockPlan& p, bool wl) {
+        if (q->is_double) return stock_ct_lookup(p, flags, wl, (const double*)nullptr) || stock_ct_lookup(p, flags | 16, wl, (const double*)nullptr);
+        return stock_ct_lookup(p, flags, wl, (const float*)nullptr) || stock_ct_lookup(p, flags | 16, wl, (const float*)nullptr);
+    };
+    return (q->skw_ok && has(q->skw[0], true)) || (q->sk_ok && has(q->sk[0], false));
 }
 
 static Setup* new_setup(int N, int transform, int is_double) {
@@ -259,7 +261,6 @@ static void destroy_setup(Setup* s) {
         for (void* q : s->d_twc) if (q) (void)hipFree(q);
     }
     if (s->d_ctr) (void)hipFree(s->d_ctr);
-    if (s->d_tw_sub) (void)hipFree(s->d_tw_sub);
     if (s->sub) destroy_setup(s->sub);
     for (void* p : s->d_bigtw) if (p) (void)hipFree(p);
     for (auto& kv : s->big_scratch) for (void* p : kv.second.buf) if (p) (void)hipFree(p);
@@ -371,34 +372,6 @@ int num_cus() {
         if (cus <= 0) cus = 256;
     }
     return cus;
-}
-
-template <typename T>
-static int launch_generic(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
-    const GenericPlan& gp = s->gp;
-    const int in_internal = (dir == PFFFT_BACKWARD) && !ordered;
-    const int out_internal = (dir == PFFFT_FORWARD) && !ordered;
-    // twiddle / digit-reversal tables in LDS when the image leaves room for them (n <= 65535 for the 16-bit map)
-    int tables = gp.n < 65536 && generic_lds<T>(gp.n, gp.G, gp.is_real, 1).total <= LDS_MAX;
-    if (g_variant == 40) tables = 0;
-    const size_t lds = generic_lds<T>(gp.n, gp.G, gp.is_real, tables).total;
-    size_t groups = (batch + gp.G - 1) / gp.G;
-    size_t per_cu = LDS_MAX / lds;
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu < 1) per_cu = 1;
-    size_t grid = (size_t)num_cus() * per_cu;
-    if (grid > groups) grid = groups;
-    // in-order pulling pays once a group is tens of KiB; small groups are cheaper with the static grid-stride walk
-    const bool want_dyn = (size_t)gp.G * gp.n * sizeof(cx<T>) >= 24 * 1024 && g_variant != 41;
-    unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
-    auto kf = fft_generic_kernel<T, FWD>;
-    auto kb = fft_generic_kernel<T, BWD>;
-    int rc = allow_big_lds(dir == PFFFT_FORWARD ? kf : kb, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(dir == PFFFT_FORWARD ? kf : kb, dim3((unsigned)grid), dim3(s->gthreads), lds, st, in, out, batch, gp,
-                       in_internal, out_internal, (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, tables, ctr);
-    PF_CHECK(hipGetLastError());
-    return 0;
 }
 
 static int launch_c1024(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st) {
@@ -600,9 +573,6 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
     return 0;
 }
 
-// PFFFT_HIP_DMA=<0|1|2>: LDS-DMA staged kernels off / counted vmcnt / vmcnt(0) for every size that has one (A/B)
-static int g_dma_mode = [] { const char* e = getenv("PFFFT_HIP_DMA"); return e ? atoi(e) : -1; }();   // -1 = per-size default
-
 template <typename T>
 static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     const bool bwd = dir == PFFFT_BACKWARD;
@@ -640,8 +610,10 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
         const bool want_df = df_ok && (g_variant == 54 ? true : g_variant == 55 ? false : df_env >= 0 ? df_env != 0
                                        : stock_df_adopted(sizeof(T) == 8, (flags & 8) != 0, sp.n, (flags & 2) != 0, bwd));
         auto cf = want_df ? stock_ct_lookup(sp, flags | 16, wl, (const T*)nullptr) : nullptr;
-        const bool df = cf != nullptr;
+        bool df = cf != nullptr;
         if (!cf && g_variant != 53) cf = stock_ct_lookup(sp, flags, wl, (const T*)nullptr);
+        // product build (no -DPFFFT_HIP_VARIANTS): one of the two twins exists per plan, whatever a selector asked for
+        if (!cf && g_variant != 53 && df_ok) { cf = stock_ct_lookup(sp, flags | 16, wl, (const T*)nullptr); df = cf != nullptr; }
         if (cf) {
             const int threads = df ? sk_df_threads(sp, flags & 15, wl) : (wl ? s->skw_threads : s->sk_threads);
             int rc = allow_big_lds(cf, lds);
@@ -894,27 +866,15 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
     if (batch == 0) return 0;
     int rc = ensure_device<T>(s);
     if (rc) return rc;
-    if (g_variant != 91 && g_variant != 1) {   // one thread per transform for the minimum sizes (fft_tiny.h); variant 91 = off
+    if (g_variant != 91) {   // one thread per transform for the minimum sizes (fft_tiny.h); variant 91 = off
         if (s->n == 16) return launch_tiny<T, 16>(s, in, out, batch, dir, ordered, st);
         if constexpr (sizeof(T) == 4) { if (s->n == 32) return launch_tiny<T, 32>(s, in, out, batch, dir, ordered, st); }
     }
     if constexpr (sizeof(T) == 4) {
-        if (s->kernel == K_C1024_F32 && g_variant != 1 && g_variant != 50 && batch < (1ull << 32))
+        if (s->kernel == K_C1024_F32 && g_variant != 50 && batch < (1ull << 32))
             return launch_c1024(s, in, out, batch, dir, ordered, st);
     }
-    if constexpr (sizeof(T) == 4) {
-        // variants 95 / 96 (or PFFFT_HIP_DMA=1 / 2): the LDS-DMA staged kernels, counted vmcnt / vmcnt(0) (fft_dma.h)
-        const int dma = g_variant == 95 ? 1 : g_variant == 96 ? 2 : g_variant == 98 ? 3 : (g_variant == 0 ? g_dma_mode : 0);
-        if (s->kernel == K_TILED && dma > 0 && batch < (1ull << 32) && s->n >= 2048 && s->n <= 8192)
-            return launch_dma(s, in, out, batch, dir, ordered, st, dma);
-    }
-    if constexpr (sizeof(T) == 4) {
-        // variants 89 / 90: the split kernel (fft_split.h), with / without register prefetch (A/B)
-        if ((g_variant == 89 || g_variant == 90) && s->kernel == K_TILED && s->n == 8192 && s->transform == PFFFT_REAL &&
-            dir == PFFFT_FORWARD && batch < (1ull << 32))
-            return launch_split(s, in, out, batch, dir, ordered, st, g_variant == 89);
-    }
-    if (s->kernel == K_TILED && g_variant != 1 && g_variant != 50 && batch < (1ull << 32)) {
+    if (s->kernel == K_TILED && g_variant != 50 && batch < (1ull << 32)) {
         // power-of-two sizes where the Stockham kernel instantiated on its compile-time plan measured faster than
         // the register-tiled one (float, 1 GiB of vectors, tools/stock_ab.py; variant 54 = always tiled):
         //   complex n = 16: 0.46 vs 0.26, 32: 0.70 vs 0.59, 64: 0.70 vs 0.65, 4096 unordered: 0.67 vs 0.62,
@@ -938,10 +898,12 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         return launch_stock<T>(s, in, out, batch, dir, ordered, st);
     }
     if (s->kernel == K_BIG) return launch_big<T>(s, in, out, batch, dir, ordered, st);
-    // variants (A/B only): 50 = Stockham kernel also for the sizes that have a tiled kernel, 51 = never
-    if (s->sk_ok && ((s->kernel == K_GENERIC && g_variant != 1 && g_variant != 51) || g_variant == 50))
+    // variant 50 (A/B only): the Stockham kernel also for the sizes that have a tiled kernel
+    if (s->sk_ok && (s->kernel == K_GENERIC || g_variant == 50))
         return launch_stock<T>(s, in, out, batch, dir, ordered, st);
-    return launch_generic<T>(s, in, out, batch, dir, ordered, st);
+    // (every legal size is routed above: new_setup sends whatever has no Stockham plan to the streaming passes, K_BIG)
+    g_last_error = "pffft_hip: no kernel for this size";
+    return (int)hipErrorInvalidValue;
 }
 
 // frequency shift (src/pf_mixer.cpp) immediately followed by the forward FFT, the usual SDR
@@ -1345,14 +1307,13 @@ PF_EXPORT int pffft_hip_shift_transform_batch(PFFFT_Setup* s, const float* in, f
 PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
     const pf::Setup* s = static_cast<const pf::Setup*>(setup);
     if (!s || s->magic != pf::MAGIC) return "invalid";
-    if (pf::g_variant == 1) return "generic";
     if (pf::g_variant != 91 && (s->n == 16 || (s->n == 32 && !s->is_double))) return "tiny";
     switch (s->kernel) {
         case pf::K_C1024_F32: return "c1024_f32";
         case pf::K_TILED: return "tiled";
         case pf::K_BIG: return "fourstep";
         // "stockham_rt": the plan has no compile-time twin and runs the run-time-plan kernel (0.3 of the roofline and less)
-        default: return (s->sk_ok && pf::g_variant != 51) ? (pf::sub_is_fast(s) ? "stockham" : "stockham_rt") : "generic";
+        default: return s->sk_ok ? (pf::sub_is_fast(s) ? "stockham" : "stockham_rt") : "none";
     }
 }
 PF_EXPORT const char* pffft_hip_last_error(void) { return pf::g_last_error.c_str(); }
@@ -1363,5 +1324,12 @@ PF_EXPORT int pffft_hip_device_count(void) {
     return n;
 }
 PF_EXPORT void pffft_hip_set_variant(int v) { pf::g_variant = v; }
+PF_EXPORT int pffft_hip_has_variants(void) {
+#ifdef PFFFT_HIP_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 #include "pffastconv_impl.h"

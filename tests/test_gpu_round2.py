@@ -278,35 +278,7 @@ def test_one_2p26_vector_per_precision(ref, dt):
     assert pa.Setup  # (2^26 + 16 is rejected like the reference does: tests/test_abi.py)
 
 
-# ------------------------------------------------------------------ LDS-DMA staged kernels (opt-in variants of fft_dma.h)
-@pytest.mark.parametrize("variant", [95, 96])
-@pytest.mark.parametrize("n", [2048, 4096, 8192])
-def test_dma_staged_kernels_against_reference(ref, variant, n):
-    """fft_dma.h: global -> LDS DMA landing, counted vmcnt (95) / vmcnt(0) (96).  Opt-in for the plain transforms
-    (measured slower than the register-staged kernels) but shipped: same parity bar, every direction /
-    layout, complex and real, ragged batches (inactive slots of the last group), in place."""
-    try:
-        for tr in (pa.COMPLEX, pa.REAL):
-            N = n if tr == pa.COMPLEX else 2 * n
-            s = pa.Setup(N, tr)
-            rs = ref.setup(N, tr)
-            for B in (1, 5, 259):
-                x = _uniform((B, s.vec_scalars), 100 + B)
-                idx = sorted({0, B // 2, B - 1})
-                xh = x[idx].cpu().numpy()
-                for d in (pa.FORWARD, pa.BACKWARD):
-                    for o in (True, False):
-                        pa.set_variant(variant)
-                        y = s.transform_batch(x, None, d, o)
-                        z = x.clone(); s.transform_batch(z, z, d, o)
-                        pa.set_variant(0)
-                        assert relerr(y[idx].cpu().numpy(), rs.batch(xh, d, o)) <= 1e-5, (tr, B, d, o)
-                        assert torch.equal(z, y), (tr, B, d, o)
-            s.close(); rs.close()
-    finally:
-        pa.set_variant(0)
-
-
+# ------------------------------------------------------------------ LDS-DMA staged FIR block kernel (fft_dma.h)
 @pytest.mark.parametrize("flush", [1, 0])
 def test_fastconv_dma_block_kernel_on_a_long_signal(ref, flush):
     """fastconv_dma_kernel (default for Nfft 16384 when a call spans many blocks): 4096 taps over 2^23 samples — dword-aligned
@@ -359,33 +331,6 @@ def test_fastconv_partitioned_kernel(ref, taps, L, nsig, flush):
     fc.close()
 
 
-def test_split_kernel_c3_against_reference(ref):
-    """fft_split.h (variant 89): real forward N = 16384 as a cross-wave radix-8 stage + one wave-local 1024-point transform
-    per wavefront + block-gather pair pass.  Opt-in (measured on par with the default kernel); same parity bar, both
-    layouts, ragged batches, in place, and bit-identical between its two layouts through zreorder."""
-    N = 16384
-    s = pa.Setup(N, pa.REAL)
-    rs = ref.setup(N, pa.REAL)
-    try:
-        for B in (1, 3, 259, 1031):
-            x = _uniform((B, N), 300 + B)
-            idx = sorted({0, B // 2, B - 1})
-            xh = x[idx].cpu().numpy()
-            pa.set_variant(89)
-            yu = s.transform_batch(x, None, pa.FORWARD, False)
-            yo = s.transform_batch(x, None, pa.FORWARD, True)
-            z = x.clone(); s.transform_batch(z, z, pa.FORWARD, False)
-            pa.set_variant(0)
-            assert relerr(yu[idx].cpu().numpy(), rs.batch(xh, 0, False)) <= 1e-5, B
-            assert relerr(yo[idx].cpu().numpy(), rs.batch(xh, 0, True)) <= 1e-5, B
-            assert torch.equal(z, yu)
-            assert torch.equal(s.zreorder_batch(yu, None, pa.FORWARD), yo)
-    finally:
-        pa.set_variant(0)
-    s.close(); rs.close()
-
-
-# ------------------------------------------------------------------ Stockham kernels, direct first stage (fft_stock.h sk_df_body)
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("tr,N", [(pa.COMPLEX, 96), (pa.COMPLEX, 288), (pa.COMPLEX, 640), (pa.COMPLEX, 960), (pa.COMPLEX, 2592),
                                   (pa.COMPLEX, 9216), (pa.REAL, 96), (pa.REAL, 576), (pa.REAL, 1280), (pa.REAL, 1920),
