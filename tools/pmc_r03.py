@@ -24,7 +24,10 @@ CASES = [
     ("c5", "TiledCfg<double, 10, 64, 3, 8, 16, 8", (1 << 20) * 32768, "C5 N=1024 cplx f64 fwd, batch 2^20"),
     ("c4_long", "fastconv_", 8 * N26, "C4 FIR 2^26 samples, 4096 taps (8 B per output sample)"),
     ("big16_A", "tile_fft_kernel<float, 8, 8, 0, 1", 2 * (1 << 30), "N=2^16 cplx f32, pass A (column tiles), 1 GiB of vectors"),
-    ("big16_B", "tile_fft_kernel<float, 8, 8, 0, 0", 2 * (1 << 30), "N=2^16 cplx f32, pass B (row tiles)"),
+    ("big16_B", "tile_fft_kernel<float, 8, 8, 0, 0, 1, 0", 2 * (1 << 30), "N=2^16 cplx f32, pass B (row tiles), canonical store"),
+    ("big16_Bi", "tile_fft_kernel<float, 8, 8, 0, 0, 1, 1", 2 * (1 << 30), "N=2^16 cplx f32, pass B storing the internal layout (round 3)"),
+    ("blk_real", "big_block_kernel<float, 2>", 2 * (1 << 30), "real N=2^18 forward: pair pass + internal layout, one sweep (round 3)"),
+    ("stock4000", "SKP_f_4000_c_0", 2 * (1 << 15) * 4000 * 8, "N=4000 cplx f32 forward unordered (Stockham workgroup kernel), batch 2^15"),
     ("big20_A", "tile_fft_kernel<float, 10, 4, 0, 1", 2 * (1 << 30), "N=2^20 cplx f32, pass A"),
     ("big20_B", "tile_fft_kernel<float, 10, 4, 0, 0", 2 * (1 << 30), "N=2^20 cplx f32, pass B"),
 ]

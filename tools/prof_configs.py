@@ -26,4 +26,7 @@ for _ in range(reps + 1):
 torch.cuda.synchronize()
 fc.close(); del x, y; torch.cuda.empty_cache()
 fft(1 << 16, pa.COMPLEX, np.float32, 2048, ordered=True)
+fft(1 << 16, pa.COMPLEX, np.float32, 2048, ordered=False)     # round 3: the last tile pass stores the internal layout itself
 fft(1 << 20, pa.COMPLEX, np.float32, 128, ordered=True)
+fft(1 << 18, pa.REAL, np.float32, 1024, ordered=False)        # round 3: pair pass + internal layout as one block-kernel sweep
+fft(4000, pa.COMPLEX, np.float32, 1 << 15, ordered=False)     # a mixed-radix Stockham plan (workgroup kernel)
