@@ -31,6 +31,25 @@ template <typename T> __device__ __forceinline__ cx<T> unit_root(long long m, lo
     return mk<T>((T)c, (T)(dir == FWD ? -s : s));
 }
 
+// W_N^k = exp(-i pi k / n), N = 2n: the twiddle of the real pair passes below.  float: the angle is reduced in double, the
+// sincos runs in float with a first-order correction for the rounding of the angle (error < 1e-8; the exact-argument double
+// sincospi cost the one-sweep block kernel 0.64 instead of ~0.75 of the roofline); double: exact-argument sincospi.  BOTH real pair
+// kernels use this one function: pffft_transform_ordered == pffft_zreorder(pffft_transform) holds bit for bit.
+template <typename T> __device__ __forceinline__ cx<T> pair_root(long long k, long long n);
+template <> __device__ __forceinline__ cx<float> pair_root<float>(long long k, long long n) {
+    const double turns = (double)k / (double)(2 * n);          // 0 <= turns <= 1/2
+    const float th = (float)turns;
+    const float d = 6.28318530717958647692f * (float)(turns - (double)th);
+    float sn, cs;
+    sincospif(2.0f * th, &sn, &cs);
+    return mk<float>(cs - sn * d, -(sn + cs * d));
+}
+template <> __device__ __forceinline__ cx<double> pair_root<double>(long long k, long long n) {
+    double sn, cs;
+    sincospi((double)k / (double)n, &sn, &cs);
+    return mk<double>(cs, -sn);
+}
+
 __device__ __forceinline__ int pos_of_sp(int k, const StridedPlan& p) {
     int pos = 0, m = p.n;
     for (int s = 0; s < p.nstages; ++s) {
@@ -109,7 +128,7 @@ __global__ void real_pair_kernel(cx<T>* data, long long batch, long long n) {
             cx<T> a = z[k];
             z[k] = DIR == FWD ? conj(a) : mk<T>((T)2 * a.x, (T)-2 * a.y);
         } else {
-            const cx<T> wk = unit_root<T>(k, 2 * n, FWD);  // W_N^k, N = 2n
+            const cx<T> wk = pair_root<T>(k, n);          // W_N^k, N = 2n
             const cx<T> A = z[k], Bc = conj(z[n - k]);
             cx<T> S, D;
             if (DIR == FWD) {
@@ -194,7 +213,7 @@ big_block_kernel(const T* __restrict__ in, T* __restrict__ out, long long batch,
                 const CX A2 = __builtin_nontemporal_load(cin + k2), B2 = __builtin_nontemporal_load(cin + (ta ? half + ta : half));
                 // every W_N^k through the same exact-argument evaluation as real_pair_kernel: pffft_transform_ordered ==
                 // pffft_zreorder(pffft_transform) must hold bit for bit (benchmarks/bench_pffft.c:343-349)
-                const CX w1 = unit_root<T>(k1, 2 * n, FWD), w2 = unit_root<T>(k2, 2 * n, FWD);
+                const CX w1 = pair_root<T>(k1, n), w2 = pair_root<T>(k2, n);
                 auto pairf = [](CX A, CX Bn, CX wk, CX& Xa, CX& Xb) {
                     const CX S = add_conj(A, Bn) * (T)0.5, Dm = cmul(sub_conj(A, Bn) * (T)0.5, wk);
                     Xa = add_rot<FWD>(S, Dm);
@@ -259,7 +278,7 @@ big_block_kernel(const T* __restrict__ in, T* __restrict__ out, long long batch,
                         Zb = conj(sub_rot<BWD>(S, Dm));
                     };
                     const long long k1 = t ? t : n4;
-                    const CX w1 = unit_root<T>(k1, 2 * n, FWD), w2 = unit_root<T>(half - t, 2 * n, FWD);
+                    const CX w1 = pair_root<T>(k1, n), w2 = pair_root<T>(half - t, n);
                     if (t) {
                         CX Za1, Zb1, Za2, Zb2;
                         pairb(q[0], q[3], w1, Za1, Zb1);                          // X[t], X[n - t]

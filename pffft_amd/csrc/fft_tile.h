@@ -58,8 +58,11 @@ template <typename T, int LOGL, int PP> struct TileGeom {
     // block-gather of the store loop reads conflict-free (+ 3 QSKEW units at the end of the image)
     static constexpr int QSKEW = S == 2 ? 4 : 1;
     static constexpr size_t IMG_BYTES = (size_t)L * PITCH * 16 + 256;
-    // + W_L^k (L entries) + `levels` x 512 entries of the four-step twiddle table
-    __host__ __device__ static constexpr size_t lds_bytes(int levels) { return IMG_BYTES + ((size_t)L + (size_t)levels * 512) * 2 * sizeof(T) + 16; }
+    // + W_L^k (L entries) + `levels` x 2^WB entries of the four-step twiddle table.  WB = 9 (two levels reach M = 2^18, three
+    // 2^27); the one tile that fills LDS - L = 1024 with 128-byte runs (PP = 8): 147 KiB of image - takes three levels of 2^7
+    // (M <= 2^21), 3 KiB instead of 12
+    static constexpr int WB = (LOGL == 10 && PP == 8) ? 7 : 9;
+    __host__ __device__ static constexpr size_t lds_bytes(int levels) { return IMG_BYTES + ((size_t)L + ((size_t)levels << WB)) * 2 * sizeof(T) + 16; }
     __host__ __device__ static constexpr int rad(int s) { return (LOGL % 3 == 0 || s > 0) ? 8 : (1 << (LOGL % 3)); }
     __host__ __device__ static constexpr int nsprod(int s) { int p = 1; for (int i = 0; i < s; ++i) p *= rad(i); return p; }
 };
@@ -70,10 +73,11 @@ template <typename T> __device__ __forceinline__ cx<T> tile_unit_root(double tur
     return mk<T>((T)cs, (T)-sn);
 }
 
-// `levels`-level 512-entry table of W_M^m: w3[l][d] = W_M^(d 512^l); W_M^idx = product of its digits' entries
-template <typename CX> __device__ __forceinline__ CX tile_w3(const CX* w3, unsigned idx, bool lv3) {
-    CX f = cmul(w3[idx & 511], w3[512 + ((idx >> 9) & 511)]);
-    if (lv3) f = cmul(f, w3[1024 + (idx >> 18)]);
+// `levels`-level table of W_M^m with 2^WB entries per level: w3[l][d] = W_M^(d 2^(WB l)); W_M^idx = product of its digits' entries
+template <int WB, typename CX> __device__ __forceinline__ CX tile_w3(const CX* w3, unsigned idx, bool lv3) {
+    constexpr unsigned MSK = (1u << WB) - 1;
+    CX f = cmul(w3[idx & MSK], w3[(1u << WB) + ((idx >> WB) & MSK)]);
+    if (lv3) f = cmul(f, w3[(2u << WB) + (idx >> (2 * WB))]);
     return f;
 }
 
@@ -106,12 +110,13 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     const int tid = threadIdx.x, t = tid / PP, p = tid % PP;
 
     for (int i = tid; i < L; i += WG) wl[i] = tile_unit_root<T>((double)i / (double)L);
-    const bool lv3 = D.M > (1ull << 18);
+    constexpr int WB = G::WB;
+    const bool lv3 = D.M > (1ull << (2 * WB));
     if (SEQC) {
         const double invM = 1.0 / (double)D.M;
-        for (int i = tid; i < (lv3 ? 3 : 2) * 512; i += WG) {
-            const int lvl = i >> 9, m = i & 511;
-            w3[i] = tile_unit_root<T>((double)m * (double)(1u << (9 * lvl)) * invM);
+        for (int i = tid; i < ((lv3 ? 3 : 2) << WB); i += WG) {
+            const int lvl = i >> WB, m = i & ((1 << WB) - 1);
+            w3[i] = tile_unit_root<T>((double)m * (double)(1u << (WB * lvl)) * invM);
         }
     }
     __syncthreads();
@@ -121,8 +126,8 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     if constexpr (SEQC) {
 #pragma unroll
         for (int sq = 0; sq < S; ++sq) {
-            c0[sq] = tile_w3(w3, (unsigned)t * (unsigned)(S * p + sq), lv3);
-            c1[sq] = tile_w3(w3, (unsigned)(L / 8) * (unsigned)(S * p + sq), lv3);
+            c0[sq] = tile_w3<WB>(w3, (unsigned)t * (unsigned)(S * p + sq), lv3);
+            c1[sq] = tile_w3<WB>(w3, (unsigned)(L / 8) * (unsigned)(S * p + sq), lv3);
         }
     }
 
@@ -166,7 +171,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     // Tiles are taken IN ORDER from an atomic counter (ctr != nullptr): the workgroups in flight then sweep neighbouring
     // column bands / row blocks together, which HBM rewards; the grab runs two tiles ahead so that the
     // prefetch knows its tile.  ctr == nullptr: static stride.
-    unsigned* s_next = reinterpret_cast<unsigned*>(w3 + (lv3 ? 3 : 2) * 512);
+    unsigned* s_next = reinterpret_cast<unsigned*>(w3 + ((lv3 ? 3 : 2) << WB));
     const bool dyn = ctr != nullptr;
     unsigned long long tile = blockIdx.x, tile1 = (unsigned long long)blockIdx.x + gridDim.x;
     unsigned pend = 0;
@@ -274,7 +279,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 if constexpr (SEQC && s == NS - 1 && NS > 1) {
                     // the last stage is a radix 8 with one butterfly per thread: outputs k = t + d L/8
                     static_assert(R == 8 && B == 1 && Ns == L / 8, "last stage shape");
-                    const CX A = tile_w3(w3, (unsigned)t * col0, lv3), Bc = tile_w3(w3, (unsigned)(L / 8) * col0, lv3);
+                    const CX A = tile_w3<WB>(w3, (unsigned)t * col0, lv3), Bc = tile_w3<WB>(w3, (unsigned)(L / 8) * col0, lv3);
 #pragma unroll
                     for (int sq = 0; sq < S; ++sq) {
                         CX f[8];

@@ -14,7 +14,7 @@ template <typename T, int LOGL, int PP>
 static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
                      bool out_int = false, bool in_int = false) {
     typedef TileGeom<T, LOGL, PP> G;
-    const size_t lds = G::lds_bytes(D.M > (1ull << 18) ? 3 : 2);
+    const size_t lds = G::lds_bytes(D.M > (1ull << (2 * G::WB)) ? 3 : 2);
     void (*k)(const cx<T>*, cx<T>*, unsigned long long, TileDesc, unsigned*);
     // register prefetch of the next tile where one or two workgroups fill a CU (images of 40 KiB and more)
     const bool pf = g_tile_pf >= 0 ? g_tile_pf != 0 : lds > 40 * 1024;
@@ -58,8 +58,12 @@ static int tile_dispatch(int logl, const cx<T>* in, cx<T>* out, unsigned long lo
     return (int)hipErrorInvalidValue;
 }
 
-static int pick_pp(int logl) {
-    if (logl == 10) return 4;                 // a padded image of 1024 x 144 bytes plus the tables does not fit LDS: 64-byte runs
+template <typename T> static int pick_pp(int logl) {
+    // L = 1024: a padded image of 1024 x 144 bytes plus the tables does not fit LDS twice: 64-byte runs (PP = 4), three
+    // workgroups of 512 threads per CU.  Measured in round 3 and dropped: the same tile with 128-byte runs in float (PP = 8:
+    // 147 KiB image + W_L + three levels of 2^7 four-step twiddles = 158 KiB, ONE workgroup of 1024 threads per CU):
+    // N = 2^20 0.197-0.199 against 0.206-0.239 - the denser runs do not pay for the lost overlap between workgroups.
+    if (logl == 10) return 4;
     if (g_tile_pp == 4 || g_tile_pp == 8) return g_tile_pp;
     return 8;                                 // 128-byte runs: 64-byte runs measured 0.18 against 0.30 of the roofline
 }
@@ -70,7 +74,7 @@ static int pick_pp(int logl) {
 template <typename T>
 static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, int logl, unsigned long long cols, int dir, hipStream_t st,
                         bool in_int = false) {
-    const int pp = pick_pp(logl), C = pp * TileUnit<T>::S;
+    const int pp = pick_pp<T>(logl), C = pp * TileUnit<T>::S;
     TileDesc D{};
     D.TA = (unsigned)(cols / C); D.TB = 1;
     D.vstride = ((unsigned long long)1 << logl) * cols;
@@ -86,7 +90,7 @@ static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long lon
 template <typename T>
 static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, int logl, unsigned long long outer,
                      unsigned long long inner, int dir, hipStream_t st, bool out_int = false) {
-    const int pp = pick_pp(logl), C = pp * TileUnit<T>::S;
+    const int pp = pick_pp<T>(logl), C = pp * TileUnit<T>::S;
     const unsigned long long L = (unsigned long long)1 << logl;
     TileDesc D{};
     D.TA = (unsigned)(outer / C); D.TB = (unsigned)inner;
