@@ -372,6 +372,138 @@ fastconv_part_kernel(const float* __restrict__ x, float* __restrict__ y, const c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One wavefront per overlap-save block with the block step the FILTER allows (round 3).  fastconv_part_kernel advances by
+// B = Nfft/2 samples per block whatever the filter: the partitioned form needs that, but a filter of 200 taps wastes 45 % of
+// every inverse transform (1024 of its 1849 valid samples are kept).  Here P = 1 and step = Nfft - taps + 1 (rounded down to
+// a multiple of 4 for the 16-byte stores): src/pffastconv.c:204-261 with the reference's own arithmetic of valid samples,
+// on 2048-sample blocks whatever Nfft the reference would have chosen - what a caller observes is the number of samples
+// produced (fc_schedule) and the values of the exact convolution.  Same transform, same folded coefficients
+//     Z'[k] = A Z[k] + B conj Z[n-k]                      (fastconv_part_kernel above; one partition)
+// the whole block is loaded (the overlap of taps - 1 samples is re-read: L2 / HBM traffic Nfft / step of the ideal, the
+// kernel is VALU-bound), one block ahead.
+template <class C, int OCC = 3>
+__global__ void __launch_bounds__(C::WG_THREADS, OCC)
+fastconv_wave_kernel(const float* __restrict__ x, float* __restrict__ y, const cx<float>* __restrict__ Hp,
+                     int nblk, int step, int inputLen, int lastOut, int kchunk,
+                     const cx<float>* __restrict__ twg, const cx<float>* __restrict__ twrg,
+                     int nsig, size_t xstride, size_t ystride) {
+    typedef float T;
+    typedef cx<T> CX;
+    typedef Tiled<C, FWD, 1> KF;
+    typedef Tiled<C, BWD, 1> KB;
+    constexpr int n = C::n, E = C::E, TPT = C::TPT, NS = C::NS, WAVES = C::T_PER_WG;
+    constexpr int R0 = C::rad(0), RL = C::rad(NS - 1), RS = RL;
+    static_assert(TPT == 64 && R0 == RL && E / R0 == 2 && C::VEC == 2, "one wavefront per block, two butterflies per thread, float");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int slot = threadIdx.x / TPT, t = threadIdx.x % TPT;
+    CX* img = reinterpret_cast<CX*>(smem_raw) + (size_t)slot * C::IMG;
+    CX* AB = reinterpret_cast<CX*>(smem_raw) + (size_t)WAVES * C::IMG;          // [E][2][64]: coefficients A, B per lane
+    typename KF::Tw wf;
+    typename KB::Tw wb;
+    KF::load_tw(wf, t, twg, twrg);
+    KB::load_tw(wb, t, twg, twrg);
+    if (slot == 0) {   // the folded coefficients of fastconv_part_kernel, one partition
+        auto bin_of_slot = [&](int i) { return KF::template jm<NS - 1>(t, i / RL) + (i % RL) * (n / RL); };
+        auto put = [&](int i, CX a, CX b) { AB[(i * 2 + 0) * 64 + t] = a; AB[(i * 2 + 1) * 64 + t] = b; };
+        auto pair_coef = [&](int ia, int ib, CX w) {
+            const CX Hk = Hp[bin_of_slot(ia)], Hm = Hp[bin_of_slot(ib)];
+            const CX iw = mk<T>(-w.y, w.x), iwc = mk<T>(w.y, w.x);
+            const CX al = mk<T>(0.5f * (1.f - iw.x), -0.5f * iw.y), be = mk<T>(0.5f * (1.f + iw.x), 0.5f * iw.y);
+            const CX ga = mk<T>(1.f + iwc.x, iwc.y), de = mk<T>(1.f - iwc.x, -iwc.y);
+            const CX gH = cmul(ga, Hk), dHm = cmul(de, conj(Hm)), dH = cmul(de, Hk), gHm = cmul(ga, conj(Hm));
+            put(ia, cmul(gH, al) + cmul(dHm, be), cmul(gH, be) + cmul(dHm, al));
+            put(ib, conj(cmul(dH, be) + cmul(gHm, al)), conj(cmul(dH, al) + cmul(gHm, be)));
+        };
+        if (t != 0) {
+            for (int d = 0; d < RS; ++d) pair_coef(d, RS + (RS - 1 - d), wf.p[d]);
+        } else {
+            const CX H0 = Hp[0], Hh = Hp[n / 2];
+            put(0, mk<T>(H0.x + H0.y, 0.f), mk<T>(0.f, H0.x - H0.y));
+            put(RS / 2, mk<T>(2.f * Hh.x, -2.f * Hh.y), mk<T>(0.f, 0.f));
+            for (int d = 1; d < RS / 2; ++d) pair_coef(d, RS - d, wf.p[d]);
+            for (int d = 0; d < RS / 2; ++d) pair_coef(RS + d, RS + (RS - 1 - d), wf.p[RS / 2 + d]);
+        }
+    }
+    __syncthreads();
+
+    const long ntask_sig = (nblk + kchunk - 1) / kchunk;
+    const long ntask = ntask_sig * nsig;
+    const long gw = (long)blockIdx.x * WAVES + slot, nw = (long)gridDim.x * WAVES;
+    typedef vec4<float> F4;
+    auto load4 = [&](const float* xs, long e) -> F4 {     // zero beyond the end of the signal: src/pffastconv.c:231-233
+        F4 r;
+        if (e + 3 < inputLen) {
+            const F4u q4 = *reinterpret_cast<const F4u*>(xs + e);
+            r.x = q4.a; r.y = q4.b; r.z = q4.c; r.w = q4.d;
+        } else {
+            r.x = e < inputLen ? xs[e] : 0.f; r.y = e + 1 < inputLen ? xs[e + 1] : 0.f;
+            r.z = e + 2 < inputLen ? xs[e + 2] : 0.f; r.w = e + 3 < inputLen ? xs[e + 3] : 0.f;
+        }
+        return r;
+    };
+    const bool first = t == 0;
+    for (long task = gw; task < ntask; task += nw) {
+        const int sig = (int)(task / ntask_sig);
+        const int k0 = (int)(task - (long)sig * ntask_sig) * kchunk;
+        const int k1 = k0 + kchunk < nblk ? k0 + kchunk : nblk;
+        const float* xs = x + (size_t)sig * xstride;
+        float* ys = y + (size_t)sig * ystride;
+        F4 nx[R0];                                            // chunk q of a block: samples 4 (t + q n / (2 R0)) .. + 3
+#pragma unroll
+        for (int q = 0; q < R0; ++q) nx[q] = load4(xs, (long)k0 * step + 4 * (t + q * (n / (2 * R0))));
+        for (int k = k0; k < k1; ++k) {
+            CX v[E];
+#pragma unroll
+            for (int q = 0; q < R0; ++q) { v[q] = mk<T>(nx[q].x, nx[q].y); v[R0 + q] = mk<T>(nx[q].z, nx[q].w); }
+            if (k + 1 < k1) {
+#pragma unroll
+                for (int q = 0; q < R0; ++q) nx[q] = load4(xs, (long)(k + 1) * step + 4 * (t + q * (n / (2 * R0))));   // the next block flies
+            }
+            KF::template butterflies<0>(v, t, wf, twg);
+            KF::template xwrite<0>(v, t, img); KF::xsync();
+            KF::template xread<0>(v, t, img); KF::xsync(); KF::template butterflies<1>(v, t, wf, twg);
+            if constexpr (NS > 2) { KF::template xwrite<1>(v, t, img); KF::xsync(); KF::template xread<1>(v, t, img); KF::xsync(); KF::template butterflies<2>(v, t, wf, twg); }
+            if constexpr (NS > 3) { KF::template xwrite<2>(v, t, img); KF::xsync(); KF::template xread<2>(v, t, img); KF::xsync(); KF::template butterflies<3>(v, t, wf, twg); }
+            // Z' = A Z + B conj(mirror of Z): the mirror of slot i sits in slot pi(i) of the same thread
+            CX z[E];
+#pragma unroll
+            for (int i = 0; i < E; ++i) z[i] = v[i];
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int u = i / RS, d = i % RS;
+                const int pi1 = u == 0 ? RS + (RS - 1 - d) : (RS - 1 - d);                           // threads 1 .. 63
+                const int pi0 = u == 0 ? (d == 0 || d == RS / 2 ? d : RS - d) : RS + (RS - 1 - d);   // thread 0
+                const CX a = AB[(i * 2 + 0) * 64 + t], bq = AB[(i * 2 + 1) * 64 + t];
+                const CX zz = z[i], zm = KF::sel(first, z[pi0], z[pi1]);
+                v[i] = mk<T>(fma_(a.x, zz.x, fma_(-a.y, zz.y, fma_(bq.x, zm.x, bq.y * zm.y))),
+                             fma_(a.x, zz.y, fma_(a.y, zz.x, fma_(bq.y, zm.x, -(bq.x * zm.y)))));
+            }
+            KB::template butterflies<0>(v, t, wb, twg);
+            KB::template xwrite<0>(v, t, img); KB::xsync();
+            KB::template xread<0>(v, t, img); KB::xsync(); KB::template butterflies<1>(v, t, wb, twg);
+            if constexpr (NS > 2) { KB::template xwrite<1>(v, t, img); KB::xsync(); KB::template xread<1>(v, t, img); KB::xsync(); KB::template butterflies<2>(v, t, wb, twg); }
+            if constexpr (NS > 3) { KB::template xwrite<2>(v, t, img); KB::xsync(); KB::template xread<2>(v, t, img); KB::xsync(); KB::template butterflies<3>(v, t, wb, twg); }
+            const int numOut = (k == nblk - 1) ? lastOut : step;   // the first numOut samples are the block's outputs (:255)
+            float* dst = ys + (size_t)k * step;
+#pragma unroll
+            for (int d = 0; d < RL; ++d) {
+                const int e0 = 4 * (t + d * (n / (2 * RL)));
+                const CX a = v[d], bb = v[RL + d];
+                if (e0 + 3 < numOut) {
+                    F4u q4; q4.a = a.x; q4.b = a.y; q4.c = bb.x; q4.d = bb.y;
+                    *reinterpret_cast<F4u*>(dst + e0) = q4;
+                } else {
+                    if (e0 < numOut) dst[e0] = a.x;
+                    if (e0 + 1 < numOut) dst[e0 + 1] = a.y;
+                    if (e0 + 2 < numOut) dst[e0 + 2] = bb.x;
+                }
+            }
+            KB::xsync();
+        }
+    }
+}
+
 struct FirPartCfg {
     // n = 1024 complex points = 2048-sample blocks, one wavefront per block, 4 wavefronts per workgroup
     typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 0, 256, 1> C1024;

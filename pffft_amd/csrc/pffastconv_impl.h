@@ -315,6 +315,41 @@ static int fc_launch_part(FastConv* s, const float* d_x, float* d_y, long produc
 }
 static int g_fir_part = [] { const char* e = getenv("PFFASTCONV_HIP_PART"); return e ? atoi(e) : -1; }();   // -1 = default
 
+// one wavefront per 2048-sample block, step = 2048 - taps + 1 (fft_fir.h fastconv_wave_kernel): filters up to 1024 taps
+static int fc_launch_wave(FastConv* s, const float* d_x, float* d_y, long produced, int inputLen, hipStream_t st, const FcBatch& fb) {
+    typedef FirPartCfg::C1024 C;
+    auto k = fastconv_wave_kernel<C, 3>;
+    const size_t lds = ((size_t)C::T_PER_WG * C::IMG + (size_t)C::E * 2 * 64) * sizeof(cx<float>);
+    int rc = allow_big_lds(k, lds);
+    if (rc) return rc;
+    int per_cu = 0;
+    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, lds));
+    if (per_cu < 1) per_cu = 1;
+    const int step = (2 * PART_B - s->filterLen + 1) & ~3;        // valid samples per block, 16-byte store units
+    const int nblk = (int)((produced + step - 1) / step);
+    const int lastOut = (int)(produced - (long)(nblk - 1) * step);
+    const long waves = (long)num_cus() * per_cu * C::T_PER_WG;
+    long kchunk = ((long)nblk * fb.nsig + 2 * waves - 1) / (2 * waves);   // ~2 tasks per wavefront (fc_launch_part)
+    if (kchunk < 4) kchunk = 4;
+    static const int k_env = [] { const char* e = getenv("PFFASTCONV_HIP_PART_K"); return e ? atoi(e) : 0; }();   // A/B
+    if (k_env > 0) kchunk = k_env;
+    if (kchunk > nblk) kchunk = nblk;
+    const long ntask = ((nblk + kchunk - 1) / kchunk) * fb.nsig;
+    long grid = (ntask + C::T_PER_WG - 1) / C::T_PER_WG;
+    if (grid > (long)num_cus() * per_cu) grid = (long)num_cus() * per_cu;
+    Setup* ps = s->st_part;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), lds, st, d_x, d_y, (const cx<float>*)s->d_Hp, nblk, step, inputLen,
+                       lastOut, (int)kchunk, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, fb.nsig, fb.xstride, fb.ystride);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+// Filters from this many taps up take the wave kernel when a call has many blocks (PFFASTCONV_HIP_WAVE_MIN, A/B); below: time
+// domain.  Measured (MI355X, tools/fir_quick.py, fraction of the 8 B / sample roofline on 2^26 samples / 256 signals of 2^20;
+// time domain or partitioned kernel -> wave kernel): 8-24 taps 0.47 / 0.50-0.52 -> 0.47-0.49 / 0.56 (a tie: the time-domain
+// kernel stays), 32 taps 0.45 / 0.49 -> 0.52 / 0.57, 64 taps 0.38 / 0.43 -> 0.52 / 0.55, 128 taps 0.25 / 0.30 -> 0.52 / 0.55,
+// 200 taps 0.31 / 0.38 -> 0.54 / 0.54, 600 taps 0.31 / 0.38 -> 0.39 / 0.47, 800 taps -> 0.35 / 0.43, 1024 taps 0.30 / 0.37 (equal).
+static int g_fir_wave_min = [] { const char* e = getenv("PFFASTCONV_HIP_WAVE_MIN"); return e ? atoi(e) : 32; }();
+
 // Block schedule of src/pffastconv.c:156-166 / :204-210.  Returns the number of time blocks and the
 // number of outputs of the last one; *produced = value returned by pffastconv_apply (in real samples).
 static int fc_schedule(const FastConv* s, int inputLen, int flush, int* lastOut, int* produced) {
@@ -361,6 +396,15 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     const int nblk = mode ? 2 * nbt : nbt;
     const int Nfft = s->Nfft;
     const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
+    if (mode == 0 && s->cplxFactor == 1 && g_variant == 0 && g_fir_part != 0 && s->filterLen >= g_fir_wave_min && s->filterLen <= PART_B && produced > 0) {
+        // many blocks of a filter of up to 1024 taps: one wavefront per 2048-sample block, step = 2048 - taps + 1 (round 3;
+        // the partitioned kernel below advances 1024 samples per block whatever the filter)
+        const int wstep = (2 * PART_B - s->filterLen + 1) & ~3;
+        if (((long)produced + wstep - 1) / wstep * fb.nsig >= 8L * num_cus()) {
+            if ((rc = fc_ensure_part(s))) return rc;
+            if (s->part_P == 1) return fc_launch_wave(s, d_x, d_y, produced, inputLen, st, fb);
+        }
+    }
     if (mode == 0 && s->cplxFactor == 1 && g_variant != 30 && s->filterLen > TD_MAX_TAPS / 4 && s->filterLen <= PART_B * PART_MAXP) {
         // many blocks of a long filter: the partitioned one-wavefront-per-block kernel (variant 88 forces it,
         // PFFASTCONV_HIP_PART=0 switches it off)

@@ -91,3 +91,34 @@ def test_a_stride_of_legal_sizes_up_to_2p21(ref, dt, tr):
     assert len(sizes) >= 10
     for N in sizes:
         _check_size(ref, N, tr, dt, batch=2)
+
+
+# ------------------------------------------------------------------ FIR: one wavefront per block, step = 2048 - taps + 1
+@pytest.mark.parametrize("flush", [1, 0])
+@pytest.mark.parametrize("taps,L,nsig", [(32, 1 << 22, 1), (33, 3000001, 2), (64, (1 << 21) + 17, 3), (100, 1 << 22, 1),
+                                         (255, 3000001, 1), (600, (1 << 22) + 5, 2), (1021, 1 << 22, 1), (1023, 3000001, 1),
+                                         (1024, (1 << 22) + 1, 2)])
+def test_fastconv_wave_kernel(ref, taps, L, nsig, flush):
+    """fastconv_wave_kernel (fft_fir.h, round 3): filters of 32 .. 1024 taps on calls with many blocks - 2048-sample blocks, one
+    wavefront each, advancing by the 2048 - taps + 1 (rounded down to 4) samples the filter leaves valid.  Same count as the
+    reference's block schedule (src/pffastconv.c:156-166,204-210), values within the reference test's limit
+    (tests/test_pffastconv.c:685) over the WHOLE signals, samples beyond the produced ones untouched; the device entry on one
+    signal and the batched entry on several."""
+    rng = np.random.default_rng(1000 * taps + nsig)
+    xs = rng.uniform(-1, 1, (nsig, L)).astype(np.float32)
+    h = rng.uniform(-1, 1, taps).astype(np.float32)
+    fc = pa.FastConv(h, 0, 0)
+    xd = torch.from_numpy(xs).cuda()
+    yd = torch.full_like(xd, 7.0)
+    if nsig == 1:
+        y, n = fc.apply(xd[0], bool(flush), out=yd[0])
+        got = y.cpu().numpy()[None, :]
+    else:
+        y, n = fc.apply_batch(xd, bool(flush), out=yd)
+        got = y.cpu().numpy()
+    for i in range(nsig):
+        yw, nw, _ = ref.fastconv(xs[i], h, 0, 0, flush)
+        assert n == nw
+        assert np.abs(got[i] - yw).max() <= (yw.max() - yw.min()) / 1e5, i
+    assert bool((yd[:, n:] == 7.0).all())
+    fc.close()
