@@ -516,6 +516,15 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
     const int nchk = (int)((size_t)n * sizeof(CX) / 16);       // 16-byte chunks per vector
     const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);  // slot stride in chunks (img is even)
     const bool in_int = c.in_int, out_int = c.out_int, bwd = c.bwd, real = c.real;
+    // Wave-local kernels, canonical output (forward ordered, both backward transforms): the last phase writes a natural-order
+    // LDS image and the result leaves as linear 16-byte chunks, like the internal layout does - dense 1 KiB store instructions
+    // instead of 8-byte stores in runs of n / R (complex) or ascending + descending runs (real pair phase) that are short for
+    // the small vectors these kernels serve (round 3: the internal-layout path, with its extra phase, had measured FASTER than
+    // the direct stores - real N = 96 .. 384 forward 0.67-0.68 ordered against 0.73-0.77 unordered).  Measured (1 GiB per
+    // launch): float real N = 128 / 160 / 192 forward ordered 0.66-0.68 -> 0.74-0.75, float complex backward +0.02-0.06, double
+    // forward ordered +0.02-0.07; the double BACKWARD transforms lose 0.03-0.05 (a complex double is a 16-byte store per lane
+    // already) and keep their direct stores.
+    const bool via_img = WL && !out_int && !(real && !bwd && p.sym) && (sizeof(T) == 4 || !bwd);
 
     // ---- real backward: half-complex spectrum X -> conj of the packed spectrum Z' (the stages then run
     //      a forward transform; the final conjugation happens on the store):
@@ -590,6 +599,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
                         sk_run<T, SK_L, SK_L, RC>(st, a); w ^= 1; sk_sync<WL>();
                     } else {
                         if (out_int) { sk_run<T, SK_L, SK_I, RC>(st, a); w ^= 1; sk_sync<WL>(); }
+                        else if (via_img) { sk_run<T, SK_L, SK_L, RC>(st, a); w ^= 1; sk_sync<WL>(); }   // natural image, copy-out below
                         else { a.tid = stid; a.nthr = sn; sk_run<T, SK_L, SK_G, RC>(st, a); a.tid = wtid; a.nthr = wn; }
                     }
                 }
@@ -640,16 +650,21 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
                     const int ib = sk_iposr<T>(n - k, n4, p.m_n4, p.ibs);
                     pd[ib] = Xb.x; pd[ib + 4] = Xb.y;
                 }
+            } else if (via_img) {
+                CX* pd = lds + w * bufsz + g * p.img;
+                pd[k] = Xa;
+                if (k != 0 && k != half) pd[n - k] = Xb;
             } else {
                 CX* pd = gout + (size_t)g * n;
                 __builtin_nontemporal_store(Xa, pd + k);
                 if (k != 0 && k != half) __builtin_nontemporal_store(Xb, pd + (n - k));
             }
         }
-        if (out_int) { w ^= 1; sk_sync<WL>(); }
+        if (out_int || via_img) { w ^= 1; sk_sync<WL>(); }
     }
-    // ---- internal-layout output: the padded block image leaves as linear 16-byte chunks
-    if (out_int) {
+    // ---- internal-layout output (padded block image) / canonical output of the wave-local kernels (natural image): the
+    //      image leaves as linear 16-byte chunks; the backward transforms conjugate here (the stages ran a forward transform)
+    if (out_int || via_img) {
         const chunk16* s16 = reinterpret_cast<const chunk16*>(lds + (w ^ 1) * bufsz);
         chunk16* d16 = reinterpret_cast<chunk16*>(gout);
 #pragma unroll
@@ -657,7 +672,16 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
             const int cc0 = cb + stid;
             if (cc0 >= cnt * nchk) continue;
             const int gl = udiv(cc0, p.m_nchk), cc = cc0 - gl * nchk, g = slot0 + gl;
-            __builtin_nontemporal_store(s16[g * img16 + (cc / CPB) * BCH + (cc % CPB)], d16 + (size_t)g * nchk + cc);
+            chunk16 v = s16[g * img16 + (out_int ? (cc / CPB) * BCH + (cc % CPB) : cc)];
+            if (via_img && bwd) {
+                if constexpr (sizeof(T) == 4) { v.y = -v.y; v.w = -v.w; }
+                else {
+                    vec2<double> dv = __builtin_bit_cast(vec2<double>, v);
+                    dv.y = -dv.y;
+                    v = __builtin_bit_cast(chunk16, dv);
+                }
+            }
+            __builtin_nontemporal_store(v, d16 + (size_t)g * nchk + cc);
         }
     }
 }

@@ -480,17 +480,16 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
         // launches, sum of both layouts of a direction; both layouts of a direction share one configuration):
         //   n = 8192: real forward (C3) three-stage T8192np 0.657 / 0.706; complex forward runs the Stockham plan (0.70 / 0.76
         //             against 0.68 / 0.68), complex backward the four-stage TiledPick (0.77 / 0.71 against 0.70 / 0.70)
-        //   n = 4096: complex forward three-stage (0.72 / 0.73 against 0.69 / 0.71); complex backward and real (N = 8192) the
-        //             four-stage TiledPick (0.79 / 0.74 against 0.73 / 0.73; real 0.64 / 0.70 / 0.72 / 0.72 against 0.65 / 0.66 / 0.64 / 0.61)
-        //   n = 2048: three-stage, one wavefront per transform, except complex backward (TiledPick 0.81 / 0.76 against 0.75 / 0.76)
+        //   n = 4096: forward three-stage (complex 0.72 / 0.73 against 0.69 / 0.71; real N = 8192 0.66 / 0.71 against 0.59 / 0.66),
+        //             backward the four-stage TiledPick (complex 0.79 / 0.74 against 0.73 / 0.73; real 0.70 / 0.71 against 0.71 / 0.66)
+        //   n = 2048: complex forward three-stage, one wavefront per transform (0.76 / 0.76 against 0.75 / 0.74); complex backward
+        //             and real (N = 4096) the four-stage TiledPick (0.81 / 0.76 against 0.75 / 0.76; real 0.64 / 0.70 / 0.72 / 0.72
+        //             against 0.65 / 0.66 / 0.64 / 0.61)
         if (n == 8192 && g_variant == 0 && real && dir == PFFFT_FORWARD) { *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real); return true; }
-        if (g_variant == 0 && n == 2048 && (real || dir == PFFFT_FORWARD)) {
-            const bool pf = !real || (dir == PFFFT_BACKWARD && !ordered);
-            *e = pf ? tiled_entry<T, TiledAltF32b::T2048>(dir, real) : tiled_entry<T, TiledAltF32b::T2048np>(dir, real);
-            return true;
-        }
-        if (g_variant == 0 && n == 4096 && !real && dir == PFFFT_FORWARD) {
-            *e = ordered ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real);
+        if (g_variant == 0 && n == 2048 && !real && dir == PFFFT_FORWARD) { *e = tiled_entry<T, TiledAltF32b::T2048>(dir, real); return true; }
+        if (g_variant == 0 && n == 4096 && dir == PFFFT_FORWARD) {   // (backward, real too: TiledPick 0.70 / 0.71 against 0.71 / 0.66)
+            const bool pf = !real && ordered;
+            *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real);
             return true;
         }
         if (g_variant == 77 || g_variant == 78) {
