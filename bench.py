@@ -339,7 +339,7 @@ REF_SIZES = [64, 96, 128, 160, 192, 256, 384, 480, 512, 640, 768, 800, 1024, 204
 def sizes_table(torch, pa, dev, timer):
     """The reference's benchmark table (benchmarks/bench_pffft.c:445,547-550: every size of its lists, real and complex,
     "PFFFT" = ordered and "PFFFT-U" = unordered, forward and backward - the reference times the pair; both halves are listed
-    here) in float and double: 1 GiB of vectors per launch, 10 untimed + 20 timed launches, fraction of 8 TB/s on
+    here) in float and double: 1 GiB of vectors per launch, 60 untimed launches per size, then 10 untimed + 20 timed launches per combination, fraction of 8 TB/s on
     2 x vector bytes per transform (a 256 MiB launch lasts ~80 us: start-up, tail and the gap to the next launch cost 15-20 %).  One line per kernel family and layout, so that a regression shows up in the driver's
     record without profiles/."""
     out = {"workload": "1 GiB of vectors per launch, 10 + 20 launches; [fwd ordered, fwd unordered, bwd ordered, bwd unordered] "
@@ -357,6 +357,10 @@ def sizes_table(torch, pa, dev, timer):
                 x = pool[: batch * s.vec_scalars].view(batch, s.vec_scalars)
                 y = ypool[: batch * s.vec_scalars].view(batch, s.vec_scalars)
                 row = []
+                # a new setup uploads its tables with synchronous copies: the GPU idles for a moment and the clocks take
+                # ~30 ms of work to come back (first_launches_ms of the configs shows the same ramp) - without this untimed
+                # run the FIRST of the four combinations of every size reads 0.05-0.10 low
+                timer(lambda: s.transform_batch(x, y, pa.FORWARD, ordered=True), 1, warm=60)
                 for d in (pa.FORWARD, pa.BACKWARD):
                     for o in (True, False):
                         t = timer(lambda: s.transform_batch(x, y, d, ordered=o), 20, warm=10)
