@@ -163,8 +163,8 @@ int pffastconv_hip_apply_batch(PFFASTCONV_Setup *, const float *d_input, int inp
                                float *d_output, size_t outputStride, int nsignals, int applyFlush, void *stream);
 
 /* Name of the kernel family a setup dispatches to ("c1024_f32", "tiled", "tiny", "stockham", "stockham_rt" = the same kernel on a
- * run-time plan because the size has no generated compile-time plan, "fourstep" = streaming passes beyond LDS, "generic"):
- * for tests/bench. */
+ * run-time plan because the size has no generated compile-time plan (no legal size today), "fourstep" = tile / streaming
+ * passes beyond LDS): for tests/bench. */
 const char *pffft_hip_kernel_name(const void *setup);
 const char *pffft_hip_last_error(void);
 /* Number of legacy (void) entries that failed in this process so far.  The legacy entries have no error channel

@@ -370,4 +370,53 @@ big_transpose_kernel(const cx<T>* in, cx<T>* out, long long batch, int N2) {
     }
 }
 
+// The same transpose storing the pffft-internal layout (forward complex transforms, round 3; reference: cplx_finalize +
+// the layout pffft_transform leaves, src/pffft_priv_impl.h:1195-1237).  Output bin k = k2 R + k1 lies in
+// quarter m = k2 div (N2/4): a workgroup takes 64 columns k2 of EACH quarter (four runs of 64 bins per row k1) and owns the
+// 16 R whole blocks of the layout that they fill - one contiguous range, stored as linear 16-byte units.  It replaces the
+// canonical transpose + a separate reorder sweep.
+template <typename T, int R>
+__global__ void __launch_bounds__(256)
+big_transpose_int_kernel(const cx<T>* in, T* out, long long batch, int N2) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cx<T>* tile = reinterpret_cast<cx<T>*>(smem_raw);          // [4 quarters][64 columns][R + 1]
+    typedef vec4<float> U16;
+    constexpr int CH = 16 / (int)sizeof(T), UPB = 32 / CH, UPQ = UPB / 4;   // scalars per unit; units per block / per quarter slot
+    const int Q = N2 >> 2;                                      // columns per quarter (a multiple of 4)
+    const int tiles_per_vec = (Q + 63) / 64;
+    const long long b = blockIdx.x / tiles_per_vec;
+    const int c0 = (int)(blockIdx.x - b * tiles_per_vec) * 64;
+    const int w = (Q - c0) < 64 ? (Q - c0) : 64;                // columns of this tile per quarter
+    const cx<T>* src = in + b * (long long)R * N2;
+    const int t = threadIdx.x, m0 = t >> 6, c = t & 63;
+    if (c < w) {
+        cx<T>* row = tile + (m0 * 64 + c) * (R + 1);
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) row[k1] = src[(long long)k1 * N2 + m0 * Q + c0 + c];
+    }
+    __syncthreads();
+    const int units = (w * R / 4) * UPB;
+    U16* dst = reinterpret_cast<U16*>(out) + (b * 2 * (long long)R * N2 + 8LL * c0 * R) / CH;
+    for (int u = t; u < units; u += 256) {
+        const int blk = u / UPB, r = u - blk * UPB, m = r / UPQ, sub = r - m * UPQ;
+        const cx<T>* q = tile + m * 64 * (R + 1);
+        const int j = 4 * blk;                                  // first of the block's four positions (k2' R + k1, relative to c0 R)
+        U16 o;
+        if constexpr (sizeof(T) == 4) {                         // sub = part p
+            float e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int cc = (j + i) / R, k1 = (j + i) - cc * R; const cx<T> v = q[cc * (R + 1) + k1]; e[i] = sub ? v.y : v.x; }
+            o.x = e[0]; o.y = e[1]; o.z = e[2]; o.w = e[3];
+        } else {                                                // sub = 2 p + h: part p of positions 2 h, 2 h + 1
+            const int h = sub & 1, p = sub >> 1;
+            double e[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { const int jj = j + 2 * h + i, cc = jj / R, k1 = jj - cc * R; const cx<T> v = q[cc * (R + 1) + k1]; e[i] = p ? v.y : v.x; }
+            vec2<double> d2; d2.x = e[0]; d2.y = e[1];
+            o = __builtin_bit_cast(U16, d2);
+        }
+        __builtin_nontemporal_store(o, dst + u);
+    }
+}
+
 }  // namespace pf

@@ -684,8 +684,10 @@ template <typename T> static int transform_batch(Setup* s, const T* in, T* out, 
 
 // n = R x N2: columns in registers -> batched LDS-resident rows -> tiled transpose (fft_big.h)
 template <typename T>
-static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, int dir, hipStream_t st) {
+static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, int dir, hipStream_t st, bool out_int = false) {
+    // out_int (forward only): the transpose stores the internal layout itself (big_transpose_int_kernel)
     const int R = s->bigR, N2 = s->sub->n;
+    const unsigned tgrid_int = (unsigned)(batch * (size_t)((N2 / 4 + 63) / 64));
     const long long total = (long long)batch * N2;
     const unsigned grid = (unsigned)((total + 255) / 256);
     const double inv_n = 1.0 / (double)s->n;
@@ -697,10 +699,16 @@ static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, 
         PF_CHECK(hipGetLastError());                                                                               \
         int rc = transform_batch<T>(s->sub, (const T*)work, (T*)work, batch * (size_t)RR, dir, 1, st);             \
         if (rc) return rc;                                                                                         \
-        auto k = big_transpose_kernel<T, RR>;                                                                      \
         const size_t lds = (size_t)256 * (RR + 1) * sizeof(cx<T>);                                                 \
-        if ((rc = allow_big_lds(k, lds))) return rc;                                                               \
-        hipLaunchKernelGGL(k, dim3(tgrid), dim3(256), lds, st, (const cx<T>*)work, out, (long long)batch, N2);     \
+        if (out_int) {                                                                                             \
+            auto ki = big_transpose_int_kernel<T, RR>;                                                             \
+            if ((rc = allow_big_lds(ki, lds))) return rc;                                                          \
+            hipLaunchKernelGGL(ki, dim3(tgrid_int), dim3(256), lds, st, (const cx<T>*)work, (T*)out, (long long)batch, N2); \
+        } else {                                                                                                   \
+            auto k = big_transpose_kernel<T, RR>;                                                                  \
+            if ((rc = allow_big_lds(k, lds))) return rc;                                                           \
+            hipLaunchKernelGGL(k, dim3(tgrid), dim3(256), lds, st, (const cx<T>*)work, out, (long long)batch, N2); \
+        }                                                                                                          \
         PF_CHECK(hipGetLastError());                                                                               \
         return 0;                                                                                                  \
     }
@@ -807,7 +815,10 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     }
     if (done) {
     } else if (s->bigR && g_variant != 80) {   // three streaming passes (fft_big.h); variant 80 = the strided kernels (A/B)
-        if ((rc = big_small_factor<T>(s, cur, bufB, dest, batch, dir, st))) return rc;
+        // complex forward into the internal layout: the transpose pass stores it (variant 86 = separate sweep)
+        const bool tint = fwd && !ordered && !real && g_variant != 86;
+        if ((rc = big_small_factor<T>(s, cur, bufB, tint ? (cx<T>*)out : dest, batch, dir, st, tint))) return rc;
+        out_is_internal = tint;
     } else {
         if ((rc = launch_strided<T>(s, 0, cur, bufB, batch, dir, st))) return rc;
         if ((rc = launch_strided<T>(s, 1, bufB, dest, batch, dir, st))) return rc;

@@ -122,3 +122,31 @@ def test_fastconv_wave_kernel(ref, taps, L, nsig, flush):
         assert np.abs(got[i] - yw).max() <= (yw.max() - yw.min()) / 1e5, i
     assert bool((yd[:, n:] == 7.0).all())
     fc.close()
+
+
+def test_fastconv_batch_more_signals_than_a_grid_dimension_and_stride_checks(ref):
+    """the time-domain path took the signal index as blockIdx.y (<= 65535 signals) and accepted an outputStride
+    smaller than the samples one signal produces.  70 000 short signals in one call, every one against the reference's
+    arithmetic (a direct correlation sum in float64), and the stride checks of include/pffft_hip.h."""
+    taps, L, nsig = 5, 64, 70000
+    rng = np.random.default_rng(5)
+    xs = rng.uniform(-1, 1, (nsig, L)).astype(np.float32)
+    h = rng.uniform(-1, 1, taps).astype(np.float32)
+    fc = pa.FastConv(h, 0, 0)
+    xd = torch.from_numpy(xs).cuda()
+    y, n = fc.apply_batch(xd, True)
+    yw, nw, _ = ref.fastconv(xs[0], h, 0, 0, 1)
+    assert n == nw == L - taps + 1
+    want = np.zeros((nsig, n))
+    for i in range(taps):                                   # y[m] = sum_i h[taps-1-i] x[m+i] (src/pffastconv.c:100-106: the flipped filter)
+        want += h[taps - 1 - i].astype(np.float64) * xs[:, i:i + n]
+    got = y.cpu().numpy()
+    assert np.abs(got[0] - yw).max() <= 1e-5
+    assert np.abs(got - want).max() <= 1e-5
+    # outputStride smaller than the samples a signal produces: refused (-1), nothing launched
+    L2 = pa.lib()
+    out = torch.zeros(nsig * 8, device="cuda")
+    rc = L2.pffastconv_hip_apply_batch(fc.handle, xd.data_ptr(), L, L, out.data_ptr(), 8, nsig, 1, None)
+    assert rc == -1 and b"outputStride" in L2.pffft_hip_last_error()
+    assert float(out.abs().max()) == 0.0
+    fc.close()
