@@ -345,6 +345,61 @@ big_col_kernel(const cx<T>* in, cx<T>* out, long long total, int N2, double inv_
     for (int k = 1; k < R; ++k) dst[(long long)k * N2] = twmul<DIR>(a[k], p[k]);
 }
 
+// The column pass reading the pffft-internal layout (backward complex transforms with R a multiple of 4, round 3; reference:
+// cplx_preprocess on pffft_transform's backward input, src/pffft_priv_impl.h:1239-1270).  Row q of the R x N2 matrix lies in
+// quarter m = q div (R/4), at positions t = (q mod R/4) N2 + n2: a workgroup takes 256 adjacent columns; for every q' < R/4
+// the four rows q' + m R/4 are the 64 whole blocks of positions q' N2 + n2 - one contiguous range, loaded as linear 16-byte
+// units and regrouped through an LDS tile [row][column]; the R-point transforms and the twiddle then run as in
+// big_col_kernel.  It replaces a separate reorder sweep.
+template <typename T, int R, int DIR>
+__global__ void __launch_bounds__(256)
+big_col_int_kernel(const T* in, cx<T>* out, long long batch, int N2, double inv_n) {
+    static_assert(R % 4 == 0, "quarters must be whole rows");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);                   // [R rows][256 + 1 columns] complex, as scalars
+    typedef vec4<float> U16;
+    constexpr int CH = 16 / (int)sizeof(T), UPB = 32 / CH, UPQ = UPB / 4, PITCH = 257;
+    const int tiles_per_vec = (N2 + 255) / 256;
+    const long long b = blockIdx.x / tiles_per_vec;
+    const int n20 = (int)(blockIdx.x - b * tiles_per_vec) * 256;
+    const int w = (N2 - n20) < 256 ? (N2 - n20) : 256;          // columns of this tile (a multiple of 16)
+    const int t = threadIdx.x;
+    const long long vbase = b * 2 * (long long)R * N2;           // scalars
+    const int units = (w / 4) * UPB;
+#pragma unroll 1
+    for (int qq = 0; qq < R / 4; ++qq) {
+        const U16* src = reinterpret_cast<const U16*>(in) + (vbase + 8 * ((long long)qq * N2 + n20)) / CH;
+        for (int u = t; u < units; u += 256) {
+            const U16 v = __builtin_nontemporal_load(src + u);
+            const int blk = u / UPB, r = u - blk * UPB, m = r / UPQ, sub = r - m * UPQ;
+            T* row = tile + (size_t)(qq + m * (R / 4)) * PITCH * 2;
+            if constexpr (sizeof(T) == 4) {                     // sub = part p of positions 4 blk .. 4 blk + 3
+                row[(4 * blk + 0) * 2 + sub] = v.x; row[(4 * blk + 1) * 2 + sub] = v.y;
+                row[(4 * blk + 2) * 2 + sub] = v.z; row[(4 * blk + 3) * 2 + sub] = v.w;
+            } else {                                            // sub = 2 p + h: part p of positions 4 blk + 2 h, + 1
+                const vec2<double> d2 = __builtin_bit_cast(vec2<double>, v);
+                const int h = sub & 1, p = sub >> 1;
+                row[(4 * blk + 2 * h + 0) * 2 + p] = d2.x; row[(4 * blk + 2 * h + 1) * 2 + p] = d2.y;
+            }
+        }
+    }
+    __syncthreads();
+    if (t >= w) return;
+    const int n2 = n20 + t;
+    cx<T>* dst = out + b * (long long)R * N2 + n2;
+    cx<T> a[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) a[q] = mk<T>(tile[((size_t)q * PITCH + t) * 2], tile[((size_t)q * PITCH + t) * 2 + 1]);
+    dftR<R, DIR>(a);
+    cx<T> p[R];
+    p[1] = big_unit<T>((double)n2 * inv_n);
+#pragma unroll
+    for (int k = 2; k < R; ++k) p[k] = cmul(p[k >> 1], p[k - (k >> 1)]);
+    dst[0] = a[0];
+#pragma unroll
+    for (int k = 1; k < R; ++k) dst[(long long)k * N2] = twmul<DIR>(a[k], p[k]);
+}
+
 // tile of 256 consecutive k2 per workgroup: rows k1 = 0..R-1 in (coalesced over k2), R*256 consecutive outputs out
 template <typename T, int R>
 __global__ void __launch_bounds__(256)

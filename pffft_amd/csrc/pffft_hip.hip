@@ -186,7 +186,8 @@ static Setup* new_setup(int N, int transform, int is_double) {
         // ... unless n = R x N2 with a register-sized R and an N2 the LDS-resident batched kernels take (fft_big.h)
         // (the first R whose N2 runs on a fast kernel: N = 20480 as 4 x 5120 put the rows on the run-time-plan Stockham
         //  kernel and measured 0.04 of the roofline, as 32 x 640 it has a compile-time plan)
-        for (int R : {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 25, 27, 32}) {
+        // (multiples of 4 first: their column pass can read the internal layout itself, big_col_int_kernel)
+        for (int R : {4, 8, 12, 16, 32, 2, 3, 5, 6, 9, 10, 15, 25, 27}) {
             if (s->n % R) continue;
             const int N2 = s->n / R;
             if ((size_t)N2 * esz > 80 * 1024 || N2 % (SIMD * SIMD)) continue;   // (Stockham plans reach n = 10000 float)
@@ -684,7 +685,9 @@ template <typename T> static int transform_batch(Setup* s, const T* in, T* out, 
 
 // n = R x N2: columns in registers -> batched LDS-resident rows -> tiled transpose (fft_big.h)
 template <typename T>
-static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, int dir, hipStream_t st, bool out_int = false) {
+static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, int dir, hipStream_t st, bool out_int = false,
+                            bool in_int = false) {
+    // in_int (backward only, R a multiple of 4): the column pass reads the internal layout itself (big_col_int_kernel)
     // out_int (forward only): the transpose stores the internal layout itself (big_transpose_int_kernel)
     const int R = s->bigR, N2 = s->sub->n;
     const unsigned tgrid_int = (unsigned)(batch * (size_t)((N2 / 4 + 63) / 64));
@@ -694,7 +697,17 @@ static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, 
     const unsigned tgrid = (unsigned)(batch * (size_t)((N2 + 255) / 256));
 #define PF_BIG_R(RR)                                                                                               \
     case RR: {                                                                                                     \
-        if (dir == PFFFT_FORWARD) hipLaunchKernelGGL((big_col_kernel<T, RR, FWD>), dim3(grid), dim3(256), 0, st, in, work, total, N2, inv_n); \
+        if constexpr (RR % 4 == 0) {                                                                               \
+            if (in_int) {                                                                                          \
+                auto kc = big_col_int_kernel<T, RR, BWD>;                                                          \
+                const size_t ldsc = (size_t)RR * 257 * sizeof(cx<T>);                                              \
+                int rcc = allow_big_lds(kc, ldsc);                                                                 \
+                if (rcc) return rcc;                                                                               \
+                hipLaunchKernelGGL(kc, dim3(tgrid), dim3(256), ldsc, st, (const T*)in, work, (long long)batch, N2, inv_n); \
+            }                                                                                                      \
+        }                                                                                                          \
+        if (in_int && RR % 4 == 0) {                                                                               \
+        } else if (dir == PFFFT_FORWARD) hipLaunchKernelGGL((big_col_kernel<T, RR, FWD>), dim3(grid), dim3(256), 0, st, in, work, total, N2, inv_n); \
         else hipLaunchKernelGGL((big_col_kernel<T, RR, BWD>), dim3(grid), dim3(256), 0, st, in, work, total, N2, inv_n);  \
         PF_CHECK(hipGetLastError());                                                                               \
         int rc = transform_batch<T>(s->sub, (const T*)work, (T*)work, batch * (size_t)RR, dir, 1, st);             \
@@ -780,7 +793,9 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     const bool pow2n = (s->n & (s->n - 1)) == 0 && g_variant != 80 && g_variant != 82;
     // complex backward from the internal layout, power-of-two n: the first tile pass reads the layout itself (variant 86 = off)
     const bool fuse_in = !fwd && !ordered && !real && pow2n && g_variant != 86;
-    if (fuse_in) {
+    // ... and so does the column pass of the three-pass route when R is a multiple of 4
+    const bool col_in = !fwd && !ordered && !real && !pow2n && s->bigR && s->bigR % 4 == 0 && g_variant != 80 && g_variant != 86;
+    if (fuse_in || col_in) {
     } else if (!fwd && !ordered && blk) {   // internal -> canonical (complex) / -> packed spectrum of the inverse (real), one sweep
         if ((rc = launch_block<T>(s, real ? 3 : 1, in, (T*)bufA, batch, st))) return rc;
         cur = bufA;
@@ -817,7 +832,7 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     } else if (s->bigR && g_variant != 80) {   // three streaming passes (fft_big.h); variant 80 = the strided kernels (A/B)
         // complex forward into the internal layout: the transpose pass stores it (variant 86 = separate sweep)
         const bool tint = fwd && !ordered && !real && g_variant != 86;
-        if ((rc = big_small_factor<T>(s, cur, bufB, tint ? (cx<T>*)out : dest, batch, dir, st, tint))) return rc;
+        if ((rc = big_small_factor<T>(s, cur, bufB, tint ? (cx<T>*)out : dest, batch, dir, st, tint, col_in))) return rc;
         out_is_internal = tint;
     } else {
         if ((rc = launch_strided<T>(s, 0, cur, bufB, batch, dir, st))) return rc;
