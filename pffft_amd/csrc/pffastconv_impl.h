@@ -281,6 +281,7 @@ static int fc_ensure_part(FastConv* s) {
     return 0;
 }
 
+#ifdef PFFFT_HIP_VARIANTS
 template <int P, int OCC = (P > 2 ? 1 : 2)>
 static int fc_launch_part(FastConv* s, const float* d_x, float* d_y, long produced, int inputLen, hipStream_t st, const FcBatch& fb) {
     typedef FirPartCfg::C1024 C;
@@ -313,6 +314,7 @@ static int fc_launch_part(FastConv* s, const float* d_x, float* d_y, long produc
     PF_CHECK(hipGetLastError());
     return 0;
 }
+#endif
 static int g_fir_part = [] { const char* e = getenv("PFFASTCONV_HIP_PART"); return e ? atoi(e) : -1; }();   // -1 = default
 
 // one wavefront per 2048-sample block, step = 2048 - taps + 1 (fft_fir.h fastconv_wave_kernel): filters up to 1024 taps
@@ -405,28 +407,24 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
             if (s->part_P == 1) return fc_launch_wave(s, d_x, d_y, produced, inputLen, st, fb);
         }
     }
-    if (mode == 0 && s->cplxFactor == 1 && g_variant != 30 && s->filterLen > TD_MAX_TAPS / 4 && s->filterLen <= PART_B * PART_MAXP) {
-        // many blocks of a long filter: the partitioned one-wavefront-per-block kernel (variant 88 forces it,
-        // PFFASTCONV_HIP_PART=0 switches it off)
-        // Measured (MI355X, tools/fir_quick.py, fraction of the 8 B / sample roofline on 2^26 samples / 256 signals of 2^20;
-        // best other path -> this kernel): 200 taps 0.26 / 0.31 -> 0.30 / 0.30, 600 taps 0.26 / 0.30 -> 0.33 / 0.31, 1024 taps
-        // 0.27 / 0.31 -> 0.34 / 0.32 (one partition, three wavefronts per SIMD); two partitions (2048 taps: 0.25 / 0.26) lose to
-        // the long-block DMA kernel with its folded coefficients (0.26 / 0.30); three and four partitions keep their ring in
-        // > 256 registers, run one wavefront per SIMD (0.12-0.23): default for filters of up to 1024 taps only.
-        const long blocks = ((long)produced + PART_B - 1) / PART_B * fb.nsig;
-        const int P = (s->filterLen + PART_B - 1) / PART_B;
-        const bool want = g_variant == 88 || (g_variant == 0 && g_fir_part != 0 && (g_fir_part > 0 || (P <= 1 && blocks >= 8L * num_cus())));
-        if (want && produced > 0) {
-            if ((rc = fc_ensure_part(s))) return rc;
-            switch (s->part_P) {
-                case 1: return fc_launch_part<1, 3>(s, d_x, d_y, produced, inputLen, st, fb);
-                case 2: return fc_launch_part<2, 2>(s, d_x, d_y, produced, inputLen, st, fb);
-                case 3: return fc_launch_part<3, 1>(s, d_x, d_y, produced, inputLen, st, fb);
-                case 4: return fc_launch_part<4, 1>(s, d_x, d_y, produced, inputLen, st, fb);
-                default: break;
-            }
+#ifdef PFFFT_HIP_VARIANTS
+    if (mode == 0 && s->cplxFactor == 1 && s->filterLen > TD_MAX_TAPS / 4 && s->filterLen <= PART_B * PART_MAXP &&
+        (g_variant == 88 || g_fir_part > 0) && produced > 0) {
+        // development build: the uniformly partitioned one-wavefront-per-block kernel (fft_fir.h fastconv_part_kernel, round 2;
+        // variant 88 / PFFASTCONV_HIP_PART=1 force it).  Measured (fraction of the 8 B / sample roofline, 2^26 samples / 256
+        // signals of 2^20): one partition 0.30 / 0.37 - superseded by the wave kernel above, which advances by the samples the
+        // filter leaves valid instead of 1024; two partitions (2048 taps) 0.25 / 0.26 lose to the long-block DMA kernel; three
+        // and four keep their ring in > 256 registers and run one wavefront per SIMD (0.12-0.23).
+        if ((rc = fc_ensure_part(s))) return rc;
+        switch (s->part_P) {
+            case 1: return fc_launch_part<1, 3>(s, d_x, d_y, produced, inputLen, st, fb);
+            case 2: return fc_launch_part<2, 2>(s, d_x, d_y, produced, inputLen, st, fb);
+            case 3: return fc_launch_part<3, 1>(s, d_x, d_y, produced, inputLen, st, fb);
+            case 4: return fc_launch_part<4, 1>(s, d_x, d_y, produced, inputLen, st, fb);
+            default: break;
         }
     }
+#endif
     if (mode == 0 && s->cplxFactor == 1 && g_variant != 30) {
         const int nbig = fc_big_nfft(s, produced, fb.nsig);
         if (nbig) {

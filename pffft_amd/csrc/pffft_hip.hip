@@ -30,6 +30,12 @@
 
 namespace pf {
 
+#ifdef PFFFT_HIP_VARIANTS
+constexpr bool PF_HAS_VARIANTS = true;
+#else
+constexpr bool PF_HAS_VARIANTS = false;
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
@@ -464,10 +470,10 @@ static TiledEntry<T> tiled_entry(int dir, int real) {
 }
 template <typename T>
 static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e) {
+#ifdef PFFFT_HIP_VARIANTS
     if constexpr (sizeof(T) == 4) {
-        // the no-prefetch / two-workgroups-per-CU variants only win for canonical-layout real transforms of
-        // 8192 points (0.65 vs 0.57 of the roofline, gpurun_out/tiled7.log); everything else prefetches
-        if ((real && ordered && n == 8192 && dir == PFFFT_BACKWARD && g_variant != 22 && g_variant != 75 && g_variant != 76) || g_variant == 20) {
+        // variant 20: no register prefetch, 128-VGPR budget, two workgroups per CU (measured alternatives of round 1)
+        if (g_variant == 20) {
             switch (n) {
                 case 2048: *e = tiled_entry<T, TiledAltF32::C2048>(dir, real); return true;
                 case 4096: *e = tiled_entry<T, TiledAltF32::C4096>(dir, real); return true;
@@ -475,8 +481,8 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
             }
         }
     }
+#endif
     if constexpr (sizeof(T) == 4) {
-        if (n == 64 && real && dir == PFFFT_FORWARD && g_variant == 0) { *e = tiled_entry<T, TiledAltF32b::A64>(dir, real); return true; }
         // Routing re-measured in round 3 after the packed-arithmetic change (tools/route_ab.py, 1 GiB per launch, 10 + 20
         // launches, sum of both layouts of a direction; both layouts of a direction share one configuration):
         //   n = 8192: real forward (C3) three-stage T8192np 0.657 / 0.706; complex forward runs the Stockham plan (0.70 / 0.76
@@ -493,22 +499,26 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
             *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real);
             return true;
         }
+#ifdef PFFFT_HIP_VARIANTS
         if (g_variant == 77 || g_variant == 78) {
             const bool pf = g_variant == 77;
             if (n == 2048) { *e = pf ? tiled_entry<T, TiledAltF32b::T2048>(dir, real) : tiled_entry<T, TiledAltF32b::T2048np>(dir, real); return true; }
             if (n == 4096) { *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real); return true; }
         }
+#endif
         // n = 16384: 512 threads x 32 points with the register prefetch (tools/c16k_quick.py, fraction of 8 TB/s on 4 GiB,
         // 1024-thread configuration -> this one): complex fwd canonical 0.66 -> 0.69, bwd 0.63 / 0.67 -> 0.68 / 0.70, real
         // N = 32768 bwd 0.52 / 0.59 -> 0.54 / 0.64; real forward spills into the internal layout (0.55 -> 0.45) and stays.
         // Both layouts of a direction share one configuration (ordered == zreorder(unordered) bit for bit).
         if (n == 16384 && g_variant == 0 && (!real || dir == PFFFT_BACKWARD)) { *e = tiled_entry<T, TiledAltF32b::T16384>(dir, real); return true; }
+#ifdef PFFFT_HIP_VARIANTS
         if (n == 16384 && g_variant == 83) { *e = tiled_entry<T, TiledAltF32b::T16384>(dir, real); return true; }
         if (n == 16384 && g_variant == 84) { *e = tiled_entry<T, TiledAltF32b::T16384np>(dir, real); return true; }
         if (n == 16384 && g_variant == 85) { *e = tiled_entry<T, TiledAltF32b::T16384b>(dir, real); return true; }
         if (n == 8192 && g_variant == 79) { *e = tiled_entry<T, TiledAltF32b::T8192np0>(dir, real); return true; }
         if (n == 8192 && g_variant == 75) { *e = tiled_entry<T, TiledAltF32b::T8192>(dir, real); return true; }
         if (n == 8192 && g_variant == 76) { *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real); return true; }
+#endif
     }
     if constexpr (sizeof(T) == 8) {
         // alt: 0 = TiledPick, 1 = A (register base twiddles), 2 = B (prefetch), 3 = C (both); fft_tiled.h TiledAltF64
@@ -526,14 +536,20 @@ static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e
             else if (n == 2048) alt = (real && fwd && !ordered) ? 1 : 3;
             else if (n == 4096) alt = !real ? ((!fwd && ordered) ? 1 : 3) : ((fwd && !ordered) ? 1 : 3);
         }
+#ifdef PFFFT_HIP_VARIANTS
+#define PF_ALT64_B(N) if (alt == 2) { *e = tiled_entry<T, TiledAltF64::B##N>(dir, real); return true; }
+#else
+#define PF_ALT64_B(N)
+#endif
 #define PF_ALT64(N)                                                                   \
         case N:                                                                       \
             if (alt == 1) { *e = tiled_entry<T, TiledAltF64::A##N>(dir, real); return true; } \
-            if (alt == 2) { *e = tiled_entry<T, TiledAltF64::B##N>(dir, real); return true; } \
+            PF_ALT64_B(N)                                                             \
             if (alt == 3) { *e = tiled_entry<T, TiledAltF64::C##N>(dir, real); return true; } \
             break;
         switch (n) { PF_ALT64(128) PF_ALT64(256) PF_ALT64(512) PF_ALT64(1024) PF_ALT64(2048) PF_ALT64(4096) }
 #undef PF_ALT64
+#undef PF_ALT64_B
     }
     switch (n) {
         case 16: *e = tiled_entry<T, typename TiledPick<T>::C16>(dir, real); return true;
@@ -577,7 +593,7 @@ template <typename T>
 static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     const bool bwd = dir == PFFFT_BACKWARD;
     // variant 52: workgroup-phase kernel also where the wave-local one applies (A/B)
-    const bool wl = s->skw_ok && g_variant != 52;
+    const bool wl = s->skw_ok && !(PF_HAS_VARIANTS && g_variant == 52);   // (its plans have run-time twins only: development build)
     const StockPlan& sp = wl ? s->skw[bwd ? 1 : 0] : s->sk[bwd ? 1 : 0];
     const int threads = wl ? s->skw_threads : s->sk_threads;
     const size_t lds = stock_lds<T>(sp).total;
@@ -606,14 +622,15 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
         // adopted per plan from a measured table (stock_df_gen.h, written by tools/tune_stock_df.py on the GPU);
         // variants 54 / 55 force it on / off at run time for that measurement
         static const int df_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_DF"); return e ? atoi(e) : -1; }();
-        const bool df_ok = !(flags & 1) && g_variant != 53;
+        const bool rt_forced = PF_HAS_VARIANTS && g_variant == 53;   // variant 53 = always the run-time plan (development build)
+        const bool df_ok = !(flags & 1) && !rt_forced;
         const bool want_df = df_ok && (g_variant == 54 ? true : g_variant == 55 ? false : df_env >= 0 ? df_env != 0
                                        : stock_df_adopted(sizeof(T) == 8, (flags & 8) != 0, sp.n, (flags & 2) != 0, bwd));
         auto cf = want_df ? stock_ct_lookup(sp, flags | 16, wl, (const T*)nullptr) : nullptr;
         bool df = cf != nullptr;
-        if (!cf && g_variant != 53) cf = stock_ct_lookup(sp, flags, wl, (const T*)nullptr);
+        if (!cf && !rt_forced) cf = stock_ct_lookup(sp, flags, wl, (const T*)nullptr);
         // product build (no -DPFFFT_HIP_VARIANTS): one of the two twins exists per plan, whatever a selector asked for
-        if (!cf && g_variant != 53 && df_ok) { cf = stock_ct_lookup(sp, flags | 16, wl, (const T*)nullptr); df = cf != nullptr; }
+        if (!cf && !rt_forced && df_ok) { cf = stock_ct_lookup(sp, flags | 16, wl, (const T*)nullptr); df = cf != nullptr; }
         if (cf) {
             const int threads = df ? sk_df_threads(sp, flags & 15, wl) : (wl ? s->skw_threads : s->sk_threads);
             int rc = allow_big_lds(cf, lds);
@@ -644,6 +661,9 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
             return 0;
         }
     }
+#ifdef PFFFT_HIP_VARIANTS
+    // the same bodies on the run-time plan (0.3 of the roofline: issue-bound).  Every legal size has a compile-time plan
+    // (tests/test_generated_sources.py), so the product build does not carry these four kernels (2 MB); variant 53 forces them here.
     auto k = wl ? fft_stock_wl_kernel<T> : fft_stock_kernel<T>;
     int rc = allow_big_lds(k, lds);
     if (rc) return rc;
@@ -658,6 +678,11 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
                        (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
     PF_CHECK(hipGetLastError());
     return 0;
+#else
+    (void)threads; (void)lds; (void)twp; (void)want_dyn; (void)chunk_for;
+    g_last_error = "pffft_hip: no compile-time Stockham plan for this size (product build)";
+    return (int)hipErrorInvalidValue;
+#endif
 }
 
 template <typename T> static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, hipStream_t st);

@@ -24,7 +24,7 @@ def test_stockham_plans_are_in_sync_with_the_planner(tmp_path):
     out = tmp_path / "gen"
     out.mkdir()
     subprocess.run([str(exe), str(out)], check=True, capture_output=True, timeout=120)
-    for tag in ("f32c", "f32r", "f64c", "f64r"):
+    for tag in (t + "_" + h for t in ("f32c", "f32r", "f64c", "f64r") for h in "ab"):
         name = f"stock_ct_{tag}_gen.hip"
         assert (out / name).read_bytes() == open(os.path.join(CSRC, name), "rb").read(), \
             f"{name} is stale: run tools/tune_stock.sh"

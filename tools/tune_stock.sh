@@ -9,7 +9,7 @@ cd $ROOT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None --cuda-device-only -S -Rpass-analysis=kernel-resource-usage"
 for pass in 1 2 3 4; do
   : > /tmp/stock_res.txt
-  for t in f32c f32r f64c f64r; do
+  for t in f32c_a f32c_b f32r_a f32r_b f64c_a f64c_b f64r_a f64r_b; do
     ( cd /tmp && /opt/rocm/bin/hipcc $FLAGS -o /tmp/stock_$t.s $ROOT/pffft_amd/csrc/stock_ct_${t}_gen.hip 2> /tmp/stock_res_$t.txt ) &
   done
   wait
