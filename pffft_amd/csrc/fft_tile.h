@@ -18,6 +18,9 @@
 // start by exact-argument sincospi in double: no host tables.
 // n > 2^20: n = L1 (L2 L3): pass A over L1, then passes A / B on the rows of length L2 L3 with the scatter of the last pass
 // carrying both outer indices (TileDesc strides).
+// Sizes with factors 3 and 5 (round 3): tile lengths L = R0 2^b, R0 = 3, 5, 9, 15 - the same kernel with ONE odd Stockham stage
+// (radix R0 in registers, cxmath.h) in front of the power-of-two stages; n = L1 L2 with the odd part of n split over the two
+// passes (tile_tu.hip: tile_plan).  Replaces three streaming passes (fft_big.h) by two for those n.
 #pragma once
 #include <type_traits>
 
@@ -50,10 +53,12 @@ template <> struct TileUnit<double> {
     static __device__ __forceinline__ void set(U& u, int, cx<double> v) { u.x = v.x; u.y = v.y; }
 };
 
-template <typename T, int LOGL, int PP> struct TileGeom {
-    static constexpr int L = 1 << LOGL, TPT = L / 8, WG = TPT * PP, S = TileUnit<T>::S, C = PP * S;
+// R0 > 1 (round 3, sizes with factors 3 and 5 beyond LDS): L = R0 2^LOGL, an odd first stage of radix R0 in front of the
+// power-of-two stages
+template <typename T, int LOGL, int PP, int R0 = 1> struct TileGeom {
+    static constexpr int L = R0 << LOGL, TPT = L / 8, WG = TPT * PP, S = TileUnit<T>::S, C = PP * S;
     static constexpr int PITCH = PP + 1;                                  // 16-byte units per point row
-    static constexpr int NS = (LOGL + 2) / 3;
+    static constexpr int NS = (LOGL + 2) / 3 + (R0 > 1);
     // internal-layout output (OINT): the last stage's rows are skewed by QSKEW units per spectrum quarter so that the
     // block-gather of the store loop reads conflict-free (+ 3 QSKEW units at the end of the image)
     static constexpr int QSKEW = S == 2 ? 4 : 1;
@@ -61,9 +66,12 @@ template <typename T, int LOGL, int PP> struct TileGeom {
     // + W_L^k (L entries) + `levels` x 2^WB entries of the four-step twiddle table.  WB = 9 (two levels reach M = 2^18, three
     // 2^27); the one tile that fills LDS - L = 1024 with 128-byte runs (PP = 8): 147 KiB of image - takes three levels of 2^7
     // (M <= 2^21), 3 KiB instead of 12
-    static constexpr int WB = (LOGL == 10 && PP == 8) ? 7 : 9;
+    static constexpr int WB = (LOGL == 10 && PP == 8 && R0 == 1) ? 7 : 9;
     __host__ __device__ static constexpr size_t lds_bytes(int levels) { return IMG_BYTES + ((size_t)L + ((size_t)levels << WB)) * 2 * sizeof(T) + 16; }
-    __host__ __device__ static constexpr int rad(int s) { return (LOGL % 3 == 0 || s > 0) ? 8 : (1 << (LOGL % 3)); }
+    __host__ __device__ static constexpr int rad(int s) {
+        if (R0 > 1) { if (s == 0) return R0; --s; }
+        return (LOGL % 3 == 0 || s > 0) ? 8 : (1 << (LOGL % 3));
+    }
     __host__ __device__ static constexpr int nsprod(int s) { int p = 1; for (int i = 0; i < s; ++i) p *= rad(i); return p; }
 };
 
@@ -94,15 +102,19 @@ template <int WB, typename CX> __device__ __forceinline__ CX tile_w3(const CX* w
 //   internal layout (pffft_transform backward takes it, :1423-1462 / cplx_preprocess): per point row n1' < L/4 the four
 //   quarters of the columns are a run of C/4 whole blocks, loaded as dense 16-byte units; a lane ^ 1 (float) / lane ^ 2 (double)
 //   DPP exchange turns the (re group, im group) units into the image's (re, im) sequence units.
-template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0, int IINT = 0>
-__global__ void __launch_bounds__((1 << LOGL) / 8 * PP, PF ? 2 : 3)
+template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0, int IINT = 0, int R0 = 1>
+__global__ void __launch_bounds__((R0 << LOGL) / 8 * PP, PF ? 2 : 3)
 tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned long long ntiles, TileDesc D, unsigned* ctr) {
     typedef cx<T> CX;
-    typedef TileGeom<T, LOGL, PP> G;
+    typedef TileGeom<T, LOGL, PP, R0> G;
     typedef TileUnit<T> TU;
     typedef typename TU::U U;
     constexpr int L = G::L, TPT = G::TPT, WG = G::WG, S = G::S, C = G::C, PITCH = G::PITCH, NS = G::NS;
-    constexpr int NLD = SEQC ? 8 : C * L / WG / (S == 2 ? 1 : 1);   // loads per thread and tile
+    // odd first stage on a pass-A tile (not from the internal layout): the loads ARE its operands, point j + q 2^LOGL of butterfly
+    // j = t + TPT u (u < UB0, predicated on j < 2^LOGL)
+    constexpr int NB0 = L / R0, UB0 = (8 + R0 - 1) / R0;
+    constexpr bool ODD_DIRECT = R0 > 1 && SEQC && !IINT;
+    constexpr int NLD = ODD_DIRECT ? UB0 * R0 : SEQC ? 8 : C * L / WG;   // loads per thread and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     U* img = reinterpret_cast<U*>(smem);
     CX* wl = reinterpret_cast<CX*>(smem + G::IMG_BYTES);
@@ -155,6 +167,16 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 const int g = tid + i * WG, ptq = g / UPP_, rr = g % UPP_, bb = rr / UPB_;
                 r[i] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + 4 * (eb + (unsigned long long)ptq * D.ips + 4 * bb)) + rr % UPB_);
             }
+        } else if constexpr (ODD_DIRECT) {
+#pragma unroll
+            for (int u = 0; u < UB0; ++u) {
+                const int j = t + TPT * u;
+                if (j < NB0) {
+#pragma unroll
+                    for (int q = 0; q < R0; ++q)
+                        r[u * R0 + q] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)(j + q * NB0) * D.ips + S * p));
+                }
+            }
         } else if constexpr (SEQC) {
 #pragma unroll
             for (int m = 0; m < 8; ++m)
@@ -162,7 +184,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
         } else {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int g = tid + i * WG, seq = g / L, pt = g % L;
+                const int g = tid + i * WG, seq = WG == L ? i : g / L, pt = WG == L ? tid : g % L;   // (128-byte runs: WG == L)
                 r[i] = __builtin_nontemporal_load(src + (unsigned long long)seq * D.iss + pt);
             }
         }
@@ -227,24 +249,72 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 }
             }
             __syncthreads();
+            if constexpr (R0 == 1) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p + (m / 2) * G::QSKEW];   // row t + m L/8 lies in quarter m / 2
-            __syncthreads();
-        } else if constexpr (SEQC) {
+                for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p + (m / 2) * G::QSKEW];   // row t + m L/8 lies in quarter m / 2
+                __syncthreads();
+            }
+        } else if constexpr (SEQC && R0 == 1) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cur[m];
+        } else if constexpr (SEQC) {
+            // odd first stage: cur[] holds its operands
         } else {
             // C rows, contiguous over their points: transposed into the [point][sequence] image
             CX* imgc = reinterpret_cast<CX*>(img);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int g = tid + i * WG, seq = g / L, pt = g % L;
+                const int g = tid + i * WG, seq = WG == L ? i : g / L, pt = WG == L ? tid : g % L;
                 imgc[pt * (PITCH * S) + seq] = cur[i];
             }
             __syncthreads();
+            if constexpr (R0 == 1) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p];
-            __syncthreads();
+                for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p];
+                __syncthreads();
+            }
+        }
+        // ---- odd first stage (R0 > 1): butterflies j < L / R0 = 2^LOGL on the operands j + q 2^LOGL of the image, 8 / R0 per
+        //      thread; outputs to j R0 + d
+        if constexpr (R0 > 1) {
+            constexpr int NB = NB0, UB = UB0;
+            U opnd[UB][R0];
+            if constexpr (ODD_DIRECT) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int q = 0; q < R0; ++q) opnd[u][q] = cur[u * R0 + q];
+            } else {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int j = t + TPT * u;
+                    if (j < NB) {
+#pragma unroll
+                        for (int q = 0; q < R0; ++q) {
+                            const int pt = j + q * NB;
+                            opnd[u][q] = img[pt * PITCH + p + (IINT ? (pt / (L / 4)) * G::QSKEW : 0)];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = t + TPT * u;
+                if (j < NB) {
+#pragma unroll
+                    for (int sq = 0; sq < S; ++sq) {
+                        CX o[R0];
+#pragma unroll
+                        for (int q = 0; q < R0; ++q) o[q] = TU::get(opnd[u][q], sq);
+                        dftR<R0, DIR>(o);
+#pragma unroll
+                        for (int q = 0; q < R0; ++q) TU::set(opnd[u][q], sq, o[q]);
+                    }
+#pragma unroll
+                    for (int d = 0; d < R0; ++d) img[(j * R0 + d) * PITCH + p] = opnd[u][d];
+                }
+            }
         }
         // ---- Stockham stages; stage s, butterfly u (point j = t + TPT u): operands v[u + q B], outputs to
         //      (j div Ns) Ns R + (j mod Ns) + d Ns
@@ -252,17 +322,21 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
             constexpr int s = decltype(sc)::value;
             constexpr int R = G::rad(s), B = 8 / R, Ns = G::nsprod(s);
             if constexpr (s > 0) {
+                static_assert(Ns * R <= L && L % (Ns * R) == 0, "stage shape");
                 __syncthreads();                     // every thread wrote its outputs of the stage before
 #pragma unroll
                 for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p];
                 __syncthreads();                     // ... and read its operands: the image is free again
             }
+            // Ns divides TPT (Ns R <= L, R <= 8): (t + TPT u) mod Ns = t mod Ns, (t + TPT u) div Ns = t div Ns + u TPT / Ns
+            static_assert(TPT % Ns == 0, "stage shape");
+            const int tk = t % Ns, tq = t / Ns;
 #pragma unroll
             for (int u = 0; u < B; ++u) {
                 const int j = t + TPT * u;
                 CX w[R];
                 if constexpr (s > 0) {
-                    const int k = j & (Ns - 1);
+                    const int k = tk;
 #pragma unroll
                     for (int q = 1; q < R; ++q) w[q] = wl[(q * k) * (L / (Ns * R))];
                 }
@@ -291,7 +365,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                         for (int d = 0; d < 8; ++d) o[sq][d] = twmul<DIR>(o[sq][d], f[d]);
                     }
                 }
-                const int pbase = (j / Ns) * (Ns * R) + (j & (Ns - 1));
+                const int pbase = (tq + u * (TPT / Ns)) * (Ns * R) + tk;
 #pragma unroll
                 for (int d = 0; d < R; ++d) {
                     U x;
@@ -306,10 +380,11 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 }
             }
         };
-        stage(std::integral_constant<int, 0>{});
+        if constexpr (R0 == 1) stage(std::integral_constant<int, 0>{});
         if constexpr (NS > 1) stage(std::integral_constant<int, 1>{});
         if constexpr (NS > 2) stage(std::integral_constant<int, 2>{});
         if constexpr (NS > 3) stage(std::integral_constant<int, 3>{});
+        if constexpr (NS > 4) stage(std::integral_constant<int, 4>{});
         __syncthreads();
         // ---- the image holds the spectrum [k][sequence]: runs of C adjacent sequences per point
         if constexpr (OINT) {

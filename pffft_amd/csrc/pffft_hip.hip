@@ -815,11 +815,14 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     int rc;
     // variant 87: the separate sweeps (zreorder_kernel + in-place pair pass) instead of the one-sweep block kernels (A/B)
     const bool blk = g_variant != 87;
-    const bool pow2n = (s->n & (s->n - 1)) == 0 && g_variant != 80 && g_variant != 82;
-    // complex backward from the internal layout, power-of-two n: the first tile pass reads the layout itself (variant 86 = off)
-    const bool fuse_in = !fwd && !ordered && !real && pow2n && g_variant != 86;
+    // two (three beyond 2^20) tile passes: power-of-two n and the n whose odd part splits over two tile lengths (tile_tu.hip)
+    // (deep: the row length of the streaming route is itself beyond LDS, or there is no streaming plan - five sweeps)
+    const bool deep = !s->bigR || !s->sub || s->sub->kernel == K_BIG;
+    const bool tiled = g_variant != 80 && g_variant != 82 && tile_has_plan(s->n, deep);
+    // complex backward from the internal layout on the tile passes: the first one reads the layout itself (variant 86 = off)
+    const bool fuse_in = !fwd && !ordered && !real && tiled && g_variant != 86;
     // ... and so does the column pass of the three-pass route when R is a multiple of 4
-    const bool col_in = !fwd && !ordered && !real && !pow2n && s->bigR && s->bigR % 4 == 0 && g_variant != 80 && g_variant != 86;
+    const bool col_in = !fwd && !ordered && !real && !tiled && s->bigR && s->bigR % 4 == 0 && g_variant != 80 && g_variant != 86;
     if (fuse_in || col_in) {
     } else if (!fwd && !ordered && blk) {   // internal -> canonical (complex) / -> packed spectrum of the inverse (real), one sweep
         if ((rc = launch_block<T>(s, real ? 3 : 1, in, (T*)bufA, batch, st))) return rc;
@@ -840,16 +843,14 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     }
     cx<T>* dest = (fwd && !ordered) ? bufA : (cx<T>*)out;
     bool done = false, out_is_internal = false;
-    if ((s->n & (s->n - 1)) == 0 && g_variant != 80 && g_variant != 82) {
-        // power-of-two sizes: two passes over HBM up to n = 2^20, three beyond (fft_tile.h); variant 82 = the
-        // three-to-five-pass composition below (A/B)
-        int logn = 0;
-        while ((1 << logn) < s->n) ++logn;
+    if (tiled) {
+        // power-of-two sizes: two passes over HBM up to n = 2^20, three beyond; sizes with an odd part that splits over two tile
+        // lengths: two passes (fft_tile.h); variant 82 = the three-to-five-pass composition below, 83 = that only for the latter (A/B)
         // complex forward into the internal layout: the last tile pass stores the layout itself (variant 86 = separate reorder sweep, A/B)
         const bool fuse_int = fwd && !ordered && !real && g_variant != 86;
-        const int trc = launch_tile_fft(s, cur, bufB, fuse_int ? (cx<T>*)out : dest, batch, logn, dir, st, fuse_int ? 1 : fuse_in ? 2 : 0);
+        const int trc = launch_tile_fft(s, cur, bufB, fuse_int ? (cx<T>*)out : dest, batch, (long long)s->n, dir, st, fuse_int ? 1 : fuse_in ? 2 : 0, deep);
         if (trc > 0) return trc;
-        if (trc < 0 && fuse_in) { g_last_error = "pffft_hip: no tile plan for a power-of-two size beyond LDS"; return (int)hipErrorInvalidValue; }
+        if (trc < 0 && fuse_in) { g_last_error = "pffft_hip: no tile plan for this size beyond LDS"; return (int)hipErrorInvalidValue; }
         done = trc == 0;
         out_is_internal = done && fuse_int;
     }

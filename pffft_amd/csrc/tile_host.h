@@ -1,0 +1,100 @@
+// Host side of one tile pass (fft_tile.h): kernel choice, LDS opt-in, grid, in-order counter.  Shared by tile_tu.hip (power-of-two
+// tile lengths) and tile_mr*_tu.hip (tile lengths R0 2^b with an odd first stage) so that the instantiations compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/pffft_hip.h"
+#include "pf_host.h"
+#include "fft_tile.h"
+
+namespace pf {
+
+// PFSEL: -1 = both prefetch variants are instantiated and chosen at run time (power-of-two lengths, PFFFT_HIP_TILE_PF A/B);
+//         0 / 1 = only that one (odd-stage lengths: the choice is a function of the geometry, half the kernels)
+template <typename T, int LOGL, int PP, int R0 = 1, int PFSEL = -1, int PFSEL_B = PFSEL>
+static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
+                     bool out_int = false, bool in_int = false, int pf_force = -1) {
+    typedef TileGeom<T, LOGL, PP, R0> G;
+    const size_t lds = G::lds_bytes(D.M > (1ull << (2 * G::WB)) ? 3 : 2);
+    void (*k)(const cx<T>*, cx<T>*, unsigned long long, TileDesc, unsigned*);
+    const bool fw = dir == PFFFT_FORWARD;
+    if constexpr (PFSEL < 0) {
+        // register prefetch of the next tile where one or two workgroups fill a CU (images of 40 KiB and more)
+        const bool pf = pf_force >= 0 ? pf_force != 0 : lds > 40 * 1024;
+        if (D.seq_contig && in_int && !fw) k = pf ? tile_fft_kernel<T, LOGL, PP, BWD, 1, 1, 0, 1, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0, 0, 1, R0>;
+        else if (D.seq_contig) k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 1, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 1, 0, 0, R0>)
+                                 : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 0, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0, 0, 0, R0>);
+        else if (out_int && fw) k = pf ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1, 1, 0, R0> : tile_fft_kernel<T, LOGL, PP, FWD, 0, 0, 1, 0, R0>;
+        else k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 1, 0, 0, R0>)
+                    : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 0, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 0, 0, 0, R0>);
+    } else {
+        constexpr int PF = PFSEL, PFB = PFSEL_B;
+        if (D.seq_contig && in_int && !fw) k = tile_fft_kernel<T, LOGL, PP, BWD, 1, PF, 0, 1, R0>;
+        else if (D.seq_contig) k = fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, PF, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, PF, 0, 0, R0>;
+        else if (out_int && fw) k = tile_fft_kernel<T, LOGL, PP, FWD, 0, PFB, 1, 0, R0>;
+        else k = fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, PFB, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 0, PFB, 0, 0, R0>;
+    }
+    int rc = allow_big_lds(k, lds);
+    if (rc) return rc;
+    int per_cu = 0;
+    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), G::WG, lds));
+    if (per_cu < 1) per_cu = 1;
+    unsigned long long grid = (unsigned long long)num_cus() * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    // in-order tiles only where a tile is 64 KiB or more: one counter address serves ~80 M atomics/s, so 16-32 KiB tiles
+    // are throttled by the grab (2^15: 0.30 static, 0.20 in order; 2^18 .. 2^20: 0.27-0.31 / 0.19 static, 0.29-0.32 / 0.24 in
+    // order).  PFFFT_HIP_TILE_DYN=0/1 forces it (A/B).
+    static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_TILE_DYN"); return e ? atoi(e) : -1; }();
+    const bool want_dyn = dyn_env >= 0 ? dyn_env != 0 : (size_t)G::L * G::C * sizeof(cx<T>) >= 64 * 1024;
+    unsigned* ctr = (ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D, ctr);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+// tile lengths with an odd first stage: L = R0 2^logl, 128-byte runs (PP = 8)
+template <typename T, int LOGL, int R0>
+static int tile_pass_mr(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
+                        bool out_int, bool in_int) {
+    // always with the prefetch of the next tile: measured 96-270 us -> 95-130 us per GiB on the short row tiles (L <= 192), 120-217 -> 105 on the
+    // short column tiles in double
+    return tile_pass<T, LOGL, 8, R0, 1, 1>(in, out, ntiles, D, dir, st, s, out_int, in_int);
+}
+
+// the odd-stage tile lengths that are instantiated: L = R0 2^logl, logl in [4, mr_max_logl(R0)]  (image <= 110 KiB)
+constexpr int MR_MIN_LOGL = 4;
+constexpr int mr_max_logl(int r0) { return r0 == 3 ? 8 : r0 == 5 ? 7 : r0 == 9 ? 6 : r0 == 15 ? 5 : 0; }
+
+template <typename T, int R0>
+static int tile_dispatch_mr(int logl, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
+                            Setup* s, bool out_int, bool in_int) {
+    switch (logl) {
+        case 4: return tile_pass_mr<T, 4, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 5: return tile_pass_mr<T, 5, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 6: if constexpr (mr_max_logl(R0) >= 6) return tile_pass_mr<T, 6, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int); break;
+        case 7: if constexpr (mr_max_logl(R0) >= 7) return tile_pass_mr<T, 7, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int); break;
+        case 8: if constexpr (mr_max_logl(R0) >= 8) return tile_pass_mr<T, 8, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int); break;
+        default: break;
+    }
+    g_last_error = "pffft_hip: tile pass length out of range";
+    return (int)hipErrorInvalidValue;
+}
+
+// one entry per odd radix, each in its own translation unit (tile_mr<R0>_tu.hip)
+int tile_mr_pass_3(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
+                   Setup* s, bool out_int, bool in_int);
+int tile_mr_pass_5(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
+                   Setup* s, bool out_int, bool in_int);
+int tile_mr_pass_9(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
+                   Setup* s, bool out_int, bool in_int);
+int tile_mr_pass_15(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
+                    Setup* s, bool out_int, bool in_int);
+
+#define PF_TILE_MR_TU(R0)                                                                                                              \
+    int tile_mr_pass_##R0(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir,    \
+                          hipStream_t st, Setup* s, bool out_int, bool in_int) {                                                        \
+        if (is_double) return tile_dispatch_mr<double, R0>(logl, (const cx<double>*)in, (cx<double>*)out, ntiles, D, dir, st, s, out_int, in_int); \
+        return tile_dispatch_mr<float, R0>(logl, (const cx<float>*)in, (cx<float>*)out, ntiles, D, dir, st, s, out_int, in_int);        \
+    }
+
+}  // namespace pf

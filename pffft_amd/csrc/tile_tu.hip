@@ -1,57 +1,24 @@
-// libpffft_hip.so, translation unit of the two / three-pass tile kernels for power-of-two sizes beyond LDS (fft_tile.h).
-#include <hip/hip_runtime.h>
+// libpffft_hip.so, translation unit of the two / three-pass tile kernels beyond LDS (fft_tile.h): the power-of-two tile
+// lengths, the plans and the pass descriptors.  The tile lengths with an odd first stage are instantiated in tile_mr*_tu.hip.
+#include <cstdio>
+#include <cstdlib>
 
-#include "../../include/pffft_hip.h"
-#include "pf_host.h"
-#include "fft_tile.h"
+#include "tile_host.h"
 
 namespace pf {
 
 static int g_tile_pp = [] { const char* e = getenv("PFFFT_HIP_TILE_PP"); return e ? atoi(e) : 0; }();   // A/B: force 4 or 8
 static int g_tile_pf = [] { const char* e = getenv("PFFFT_HIP_TILE_PF"); return e ? atoi(e) : -1; }();  // A/B: prefetch off / on
 
-template <typename T, int LOGL, int PP>
-static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
-                     bool out_int = false, bool in_int = false) {
-    typedef TileGeom<T, LOGL, PP> G;
-    const size_t lds = G::lds_bytes(D.M > (1ull << (2 * G::WB)) ? 3 : 2);
-    void (*k)(const cx<T>*, cx<T>*, unsigned long long, TileDesc, unsigned*);
-    // register prefetch of the next tile where one or two workgroups fill a CU (images of 40 KiB and more)
-    const bool pf = g_tile_pf >= 0 ? g_tile_pf != 0 : lds > 40 * 1024;
-    const bool fw = dir == PFFFT_FORWARD;
-    if (D.seq_contig && in_int && !fw) k = pf ? tile_fft_kernel<T, LOGL, PP, BWD, 1, 1, 0, 1> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0, 0, 1>;
-    else if (D.seq_contig) k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 1> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 1>)
-                             : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0>);
-    else if (out_int && fw) k = pf ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1, 1> : tile_fft_kernel<T, LOGL, PP, FWD, 0, 0, 1>;
-    else k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 1>)
-                : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 0> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 0>);
-    int rc = allow_big_lds(k, lds);
-    if (rc) return rc;
-    int per_cu = 0;
-    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), G::WG, lds));
-    if (per_cu < 1) per_cu = 1;
-    unsigned long long grid = (unsigned long long)num_cus() * per_cu;
-    if (grid > ntiles) grid = ntiles;
-    // in-order tiles only where a tile is 64 KiB or more: one counter address serves ~80 M atomics/s, so 16-32 KiB tiles
-    // are throttled by the grab (2^15: 0.30 static, 0.20 in order; 2^18 .. 2^20: 0.27-0.31 / 0.19 static, 0.29-0.32 / 0.24 in
-    // order).  PFFFT_HIP_TILE_DYN=0/1 forces it (A/B).
-    static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_TILE_DYN"); return e ? atoi(e) : -1; }();
-    const bool want_dyn = dyn_env >= 0 ? dyn_env != 0 : (size_t)G::L * G::C * sizeof(cx<T>) >= 64 * 1024;
-    unsigned* ctr = (ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D, ctr);
-    PF_CHECK(hipGetLastError());
-    return 0;
-}
-
 template <typename T, int PP>
 static int tile_dispatch(int logl, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
                          bool out_int = false, bool in_int = false) {
     switch (logl) {
-        case 6: return tile_pass<T, 6, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int);
-        case 7: return tile_pass<T, 7, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int);
-        case 8: return tile_pass<T, 8, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int);
-        case 9: return tile_pass<T, 9, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int);
-        case 10: if constexpr (PP == 4) return tile_pass<T, 10, 4>(in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 6: return tile_pass<T, 6, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
+        case 7: return tile_pass<T, 7, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
+        case 8: return tile_pass<T, 8, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
+        case 9: return tile_pass<T, 9, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
+        case 10: if constexpr (PP == 4) return tile_pass<T, 10, 4>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
         default: break;
     }
     g_last_error = "pffft_hip: tile pass length out of range";
@@ -71,27 +38,51 @@ template <typename T> static int pick_pp(int logl) {
 // pass A: `nvec` vectors of len = L x cols complex points; length-L transforms over the columns (stride cols), times
 // W_len^(k col); same layout out (in place allowed)
 // in_int (backward only, the first pass of a transform): the columns are read from the pffft-internal layout (tile_fft_kernel IINT)
+// one tile length L = r0 2^logl (r0 = 1: power of two)
+struct TileLen {
+    int r0, logl;
+    unsigned long long len() const { return (unsigned long long)r0 << logl; }
+};
+
 template <typename T>
-static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, int logl, unsigned long long cols, int dir, hipStream_t st,
+static int tile_any(const TileLen& tl, int pp, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
+                    Setup* s, bool out_int, bool in_int) {
+    switch (tl.r0) {
+        case 1: return pp == 8 ? tile_dispatch<T, 8>(tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int)
+                               : tile_dispatch<T, 4>(tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 3: return tile_mr_pass_3(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 5: return tile_mr_pass_5(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 9: return tile_mr_pass_9(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 15: return tile_mr_pass_15(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
+        default: break;
+    }
+    g_last_error = "pffft_hip: tile pass radix out of range";
+    return (int)hipErrorInvalidValue;
+}
+
+template <typename T> static int pick_pp(const TileLen& tl) { return tl.r0 == 1 ? pick_pp<T>(tl.logl) : 8; }
+
+template <typename T>
+static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, TileLen tl, unsigned long long cols, int dir, hipStream_t st,
                         bool in_int = false) {
-    const int pp = pick_pp<T>(logl), C = pp * TileUnit<T>::S;
+    const int pp = pick_pp<T>(tl), C = pp * TileUnit<T>::S;
     TileDesc D{};
     D.TA = (unsigned)(cols / C); D.TB = 1;
-    D.vstride = ((unsigned long long)1 << logl) * cols;
+    D.vstride = tl.len() * cols;
     D.in_a = C; D.out_a = C; D.ips = cols; D.iss = 1; D.ops = cols;
     D.col_a = (unsigned)C; D.M = D.vstride; D.seq_contig = 1;
     const unsigned long long ntiles = nvec * D.TA;
-    return pp == 8 ? tile_dispatch<T, 8>(logl, in, out, ntiles, D, dir, st, s, false, in_int) : tile_dispatch<T, 4>(logl, in, out, ntiles, D, dir, st, s, false, in_int);
+    return tile_any<T>(tl, pp, in, out, ntiles, D, dir, st, s, false, in_int);
 }
 
 // pass B: rows of length L = 2^logl; row (vec, o, i) [o < outer, i < inner] sits at vec vlen + (o inner + i) L and its
 // spectrum goes to X[vec vlen + (k inner + i) outer + o]   (outer index fastest: runs of C adjacent o)
 // out_int (forward only): the spectrum is stored in the pffft-internal layout (tile_fft_kernel OINT)
 template <typename T>
-static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, int logl, unsigned long long outer,
+static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, TileLen tl, unsigned long long outer,
                      unsigned long long inner, int dir, hipStream_t st, bool out_int = false) {
-    const int pp = pick_pp<T>(logl), C = pp * TileUnit<T>::S;
-    const unsigned long long L = (unsigned long long)1 << logl;
+    const int pp = pick_pp<T>(tl), C = pp * TileUnit<T>::S;
+    const unsigned long long L = tl.len();
     TileDesc D{};
     D.TA = (unsigned)(outer / C); D.TB = (unsigned)inner;
     D.vstride = outer * inner * L;
@@ -99,36 +90,138 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
     D.out_a = C; D.out_b = outer; D.ops = outer * inner;
     D.M = 0; D.seq_contig = 0;
     const unsigned long long ntiles = nvec * D.TA * D.TB;
-    return pp == 8 ? tile_dispatch<T, 8>(logl, in, out, ntiles, D, dir, st, s, out_int) : tile_dispatch<T, 4>(logl, in, out, ntiles, D, dir, st, s, out_int);
+    return tile_any<T>(tl, pp, in, out, ntiles, D, dir, st, s, out_int, false);
 }
 
-// canonical complex transform of `batch` vectors of n = 2^logn points: in -> out through ONE work buffer of the same size
+// Two-pass plan of a size with factors 3 and / or 5: n = L1 L2, L = R0 2^b with R0 in {1, 3, 5, 9, 15} (the odd part of n is a
+// product of two of them: 3, 5, 9, 15, 25, 27, 45, 75, 81, 135, 225) and a tile length that is instantiated: power of two
+// 64 .. 512, odd-stage lengths 16 R0 .. 768 (tile_host.h: mr_max_logl; image <= 110 KiB).  Which length is the column pass and
+// which the row pass is decided by the measured cost of each (us per GiB of vectors, float and double alike within 10 %,
+// tools/_bin/mrlen.py on MI355X): column tiles 105-125, but 165-180 from L = 640 (ten and more wavefronts per workgroup: 168
+// registers); row tiles 97-127, 125-140 from L = 576.  Three streaming passes cost ~285: plans above that are refused.
+// false: no plan - the three streaming passes of fft_big.h.
+static int g_mr_min = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMIN"); return e ? atoi(e) : 48; }();    // A/B: shortest / longest
+static int g_mr_max = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMAX"); return e ? atoi(e) : 768; }();   // tile length of a plan
+static int tile_cost(const TileLen& t, bool columns) {
+    const long long L = t.len();
+    if (t.r0 == 1) return columns ? 103 : 97;
+    if (columns) return L >= 600 ? 172 : L <= 100 ? 125 : 115;
+    return L >= 560 ? 135 : L >= 256 ? 122 : 105;
+}
+static bool tile_plan(long long n, TileLen& a, TileLen& b) {
+    static const int R[5] = {1, 3, 5, 9, 15};
+    if (const char* e = getenv("PFFFT_HIP_TILE_MRPLAN")) {   // A/B: "R1,l1,R2,l2" forces the two tile lengths
+        int r1, l1, r2, l2;
+        if (sscanf(e, "%d,%d,%d,%d", &r1, &l1, &r2, &l2) == 4 && ((long long)r1 << l1) * ((long long)r2 << l2) == n) {
+            a = TileLen{r1, l1}; b = TileLen{r2, l2};
+            return true;
+        }
+    }
+    int best = 286;
+    bool found = false;
+    for (int ia = 0; ia < 5; ++ia)
+        for (int la = (R[ia] == 1 ? 6 : MR_MIN_LOGL); la <= (R[ia] == 1 ? 9 : mr_max_logl(R[ia])); ++la) {
+            const TileLen ta{R[ia], la};
+            const long long L1 = ta.len();
+            if (n % L1 || L1 < g_mr_min || L1 > g_mr_max) continue;
+            const long long L2 = n / L1;
+            if (L2 < g_mr_min || L2 > g_mr_max) continue;
+            for (int ib = 0; ib < 5; ++ib) {
+                if (L2 % R[ib]) continue;
+                const long long p2 = L2 / R[ib];
+                if (p2 & (p2 - 1)) continue;
+                int lb = 0;
+                while ((1ll << lb) < p2) ++lb;
+                if (lb < (R[ib] == 1 ? 6 : MR_MIN_LOGL) || lb > (R[ib] == 1 ? 9 : mr_max_logl(R[ib]))) continue;
+                const TileLen tb{R[ib], lb};
+                const int c = tile_cost(ta, true) + tile_cost(tb, false);
+                if (c < best) { best = c; a = ta; b = tb; found = true; }
+            }
+        }
+    return found;
+}
+
+// Three tile passes n = L1 (L2 L3) (the shape of the power-of-two sizes beyond 2^20) for the sizes without a two-pass plan whose
+// streaming route would take five sweeps (its row length is itself beyond LDS: `deep`); ~330 us per GiB against ~450-550.
+static bool tile_plan3(long long n, TileLen& a, TileLen& b, TileLen& c) {
+    static const int R[5] = {1, 3, 5, 9, 15};
+    int best = 1 << 30;
+    for (int ia = 0; ia < 5; ++ia)
+        for (int la = (R[ia] == 1 ? 6 : MR_MIN_LOGL); la <= (R[ia] == 1 ? 9 : mr_max_logl(R[ia])); ++la) {
+            const TileLen ta{R[ia], la};
+            if (n % ta.len() || (long long)ta.len() > g_mr_max) continue;
+            const long long rem = n / ta.len();
+            for (int ib = 0; ib < 5; ++ib)
+                for (int lb = (R[ib] == 1 ? 6 : MR_MIN_LOGL); lb <= (R[ib] == 1 ? 9 : mr_max_logl(R[ib])); ++lb) {
+                    const TileLen tb{R[ib], lb};
+                    if (rem % tb.len() || (long long)tb.len() > g_mr_max) continue;
+                    const long long L3 = rem / tb.len();
+                    if (L3 > g_mr_max) continue;
+                    for (int ic = 0; ic < 5; ++ic) {
+                        if (L3 % R[ic]) continue;
+                        const long long p2 = L3 / R[ic];
+                        if (p2 & (p2 - 1)) continue;
+                        int lc = 0;
+                        while ((1ll << lc) < p2) ++lc;
+                        if (lc < (R[ic] == 1 ? 6 : MR_MIN_LOGL) || lc > (R[ic] == 1 ? 9 : mr_max_logl(R[ic]))) continue;
+                        const TileLen tc{R[ic], lc};
+                        const int cst = tile_cost(ta, true) + tile_cost(tb, true) + tile_cost(tc, false);
+                        if (cst < best) { best = cst; a = ta; b = tb; c = tc; }
+                    }
+                }
+        }
+    return best != (1 << 30);
+}
+
+bool tile_has_plan(long long n, bool deep) {
+    if (n > 0 && (n & (n - 1)) == 0) return n >= (1 << 12) && n <= (1ll << 27);
+    if (g_variant == 83) return false;                   // variant 83: the streaming passes for these sizes (A/B)
+    TileLen a, b, c;
+    return tile_plan(n, a, b) || (deep && n <= (1ll << 27) && tile_plan3(n, a, b, c));
+}
+
+// canonical complex transform of `batch` vectors of n points: in -> out through ONE work buffer of the same size
 // (in may equal out; work must differ from both).  Returns -1 when the size is outside the tile plans.
 // out_int: forward transform straight into the internal layout (the last pass stores it: no reorder sweep)
 template <typename T>
-static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, int logn, int dir, hipStream_t st, bool out_int, bool in_int) {
+static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, long long n, int dir, hipStream_t st, bool out_int, bool in_int,
+                    bool deep) {
+    int rc;
+    if (n & (n - 1)) {
+        TileLen a, b, c;
+        if (g_variant == 83) return -1;
+        if (tile_plan(n, a, b)) {
+            if ((rc = pass_columns<T>(s, in, work, batch, a, b.len(), dir, st, in_int))) return rc;
+            return pass_rows<T>(s, work, out, batch, b, a.len(), 1, dir, st, out_int);
+        }
+        if (!deep || n > (1ll << 27) || !tile_plan3(n, a, b, c)) return -1;
+        if ((rc = pass_columns<T>(s, in, work, batch, a, b.len() * c.len(), dir, st, in_int))) return rc;
+        if ((rc = pass_columns<T>(s, work, work, batch * a.len(), b, c.len(), dir, st))) return rc;
+        return pass_rows<T>(s, work, out, batch, c, a.len(), b.len(), dir, st, out_int);
+    }
+    int logn = 0;
+    while ((1ll << logn) < n) ++logn;
     const int minlog = 12;
     if (logn < minlog || logn > 27) return -1;
-    int rc;
     if (logn <= 20) {
         const int l1 = logn / 2, l2 = logn - l1;
-        if ((rc = pass_columns<T>(s, in, work, batch, l1, 1ull << l2, dir, st, in_int))) return rc;
-        return pass_rows<T>(s, work, out, batch, l2, 1ull << l1, 1, dir, st, out_int);
+        if ((rc = pass_columns<T>(s, in, work, batch, TileLen{1, l1}, 1ull << l2, dir, st, in_int))) return rc;
+        return pass_rows<T>(s, work, out, batch, TileLen{1, l2}, 1ull << l1, 1, dir, st, out_int);
     }
     const int l1 = logn / 3, rem = logn - l1, l2 = rem / 2, l3 = rem - l2;
     // n = L1 n', n' = L2 L3:  A over L1 (columns n'), then per row of length n': A over L2 (in place), B over L3 with the
     // scatter X[(k3 L2 + k2) L1 + k1]
-    if ((rc = pass_columns<T>(s, in, work, batch, l1, 1ull << rem, dir, st, in_int))) return rc;
-    if ((rc = pass_columns<T>(s, work, work, batch << l1, l2, 1ull << l3, dir, st))) return rc;
-    return pass_rows<T>(s, work, out, batch, l3, 1ull << l1, 1ull << l2, dir, st, out_int);
+    if ((rc = pass_columns<T>(s, in, work, batch, TileLen{1, l1}, 1ull << rem, dir, st, in_int))) return rc;
+    if ((rc = pass_columns<T>(s, work, work, batch << l1, TileLen{1, l2}, 1ull << l3, dir, st))) return rc;
+    return pass_rows<T>(s, work, out, batch, TileLen{1, l3}, 1ull << l1, 1ull << l2, dir, st, out_int);
 }
 
 // layout: 1 = forward, spectrum out in the internal layout; 2 = backward, spectrum in from the internal layout
-int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, int logn, int dir, hipStream_t st, int layout) {
+int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, long long n, int dir, hipStream_t st, int layout, bool deep) {
     const bool out_int = layout == 1, in_int = layout == 2;
     if ((out_int && dir != PFFFT_FORWARD) || (in_int && dir != PFFFT_BACKWARD)) return -1;
-    if (s->is_double) return tile_fft<double>(s, (const cx<double>*)in, (cx<double>*)work, (cx<double>*)out, batch, logn, dir, st, out_int, in_int);
-    return tile_fft<float>(s, (const cx<float>*)in, (cx<float>*)work, (cx<float>*)out, batch, logn, dir, st, out_int, in_int);
+    if (s->is_double) return tile_fft<double>(s, (const cx<double>*)in, (cx<double>*)work, (cx<double>*)out, batch, n, dir, st, out_int, in_int, deep);
+    return tile_fft<float>(s, (const cx<float>*)in, (cx<float>*)work, (cx<float>*)out, batch, n, dir, st, out_int, in_int, deep);
 }
 
 }  // namespace pf

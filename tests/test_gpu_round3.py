@@ -150,3 +150,27 @@ def test_fastconv_batch_more_signals_than_a_grid_dimension_and_stride_checks(ref
     assert rc == -1 and b"outputStride" in L2.pffft_hip_last_error()
     assert float(out.abs().max()) == 0.0
     fc.close()
+
+
+# ------------------------------------------------------------------ sizes with factors 3 / 5 beyond LDS on the tile passes
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("N", [10240, 15360, 36864, 61440, 115200, 368640, 327680, 1024000])
+def test_odd_stage_tile_plans(ref, dt, N):
+    """fft_tile.h with an odd first stage (tile lengths 3 / 5 / 9 / 15 x 2^b): two passes where the odd part of n splits over two
+    tile lengths (10240 = 80 x 128 ... 368640 = 576 x 640), three where the streaming route would need five sweeps
+    (327680 = 2^16 x 5, 1024000 = 2^13 x 125).  Complex N and real 2N, four direction x layout combinations against oracle/_ref;
+    the streaming passes (variant 83) must agree with the tile passes to the same bar - two independent routes, one answer."""
+    dtype = np.float32 if dt == "f32" else np.float64
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    for tr, NN in ((pa.COMPLEX, N), (pa.REAL, 2 * N)):
+        _check_size(ref, NN, tr, dt, batch=2)
+        s = pa.Setup(NN, tr, dtype)
+        x = _uniform((2, s.vec_scalars), 77 + N % 1000, tdt)
+        a = s.transform_batch(x, None, pa.FORWARD, True)
+        pa.set_variant(83)
+        try:
+            b = s.transform_batch(x, None, pa.FORWARD, True)
+        finally:
+            pa.set_variant(0)
+        assert relerr(a.cpu().numpy(), b.cpu().numpy()) <= tol_for(dt, NN)
+        s.close()
