@@ -55,10 +55,13 @@ template <> struct TileUnit<double> {
 
 // R0 > 1 (round 3, sizes with factors 3 and 5 beyond LDS): L = R0 2^LOGL, an odd first stage of radix R0 in front of the
 // power-of-two stages
+// R0 = 25, 27, 45: TWO odd stages (5 x 5, 9 x 3, 9 x 5), the second one with twiddles like every later stage
 template <typename T, int LOGL, int PP, int R0 = 1> struct TileGeom {
     static constexpr int L = R0 << LOGL, TPT = L / 8, WG = TPT * PP, S = TileUnit<T>::S, C = PP * S;
     static constexpr int PITCH = PP + 1;                                  // 16-byte units per point row
-    static constexpr int NS = (LOGL + 2) / 3 + (R0 > 1);
+    static constexpr int RA = R0 == 25 ? 5 : R0 == 27 ? 9 : R0 == 45 ? 9 : R0, RB = R0 / RA;   // the odd stages
+    static constexpr int NODD = (RA > 1) + (RB > 1);
+    static constexpr int NS = (LOGL + 2) / 3 + NODD;
     // internal-layout output (OINT): the last stage's rows are skewed by QSKEW units per spectrum quarter so that the
     // block-gather of the store loop reads conflict-free (+ 3 QSKEW units at the end of the image)
     static constexpr int QSKEW = S == 2 ? 4 : 1;
@@ -69,7 +72,8 @@ template <typename T, int LOGL, int PP, int R0 = 1> struct TileGeom {
     static constexpr int WB = (LOGL == 10 && PP == 8 && R0 == 1) ? 7 : 9;
     __host__ __device__ static constexpr size_t lds_bytes(int levels) { return IMG_BYTES + ((size_t)L + ((size_t)levels << WB)) * 2 * sizeof(T) + 16; }
     __host__ __device__ static constexpr int rad(int s) {
-        if (R0 > 1) { if (s == 0) return R0; --s; }
+        if (s < NODD) return s == 0 ? RA : RB;
+        s -= NODD;
         return (LOGL % 3 == 0 || s > 0) ? 8 : (1 << (LOGL % 3));
     }
     __host__ __device__ static constexpr int nsprod(int s) { int p = 1; for (int i = 0; i < s; ++i) p *= rad(i); return p; }
@@ -112,9 +116,10 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     constexpr int L = G::L, TPT = G::TPT, WG = G::WG, S = G::S, C = G::C, PITCH = G::PITCH, NS = G::NS;
     // odd first stage on a pass-A tile (not from the internal layout): the loads ARE its operands, point j + q 2^LOGL of butterfly
     // j = t + TPT u (u < UB0, predicated on j < 2^LOGL)
-    constexpr int NB0 = L / R0, UB0 = (8 + R0 - 1) / R0;
+    constexpr int RA = G::RA, RB = G::RB, NODD = G::NODD;
+    constexpr int NB0 = L / RA, UB0 = (8 + RA - 1) / RA;
     constexpr bool ODD_DIRECT = R0 > 1 && SEQC && !IINT;
-    constexpr int NLD = ODD_DIRECT ? UB0 * R0 : SEQC ? 8 : C * L / WG;   // loads per thread and tile
+    constexpr int NLD = ODD_DIRECT ? UB0 * RA : SEQC ? 8 : C * L / WG;   // loads per thread and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     U* img = reinterpret_cast<U*>(smem);
     CX* wl = reinterpret_cast<CX*>(smem + G::IMG_BYTES);
@@ -173,8 +178,8 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 const int j = t + TPT * u;
                 if (j < NB0) {
 #pragma unroll
-                    for (int q = 0; q < R0; ++q)
-                        r[u * R0 + q] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)(j + q * NB0) * D.ips + S * p));
+                    for (int q = 0; q < RA; ++q)
+                        r[u * RA + q] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)(j + q * NB0) * D.ips + S * p));
                 }
             }
         } else if constexpr (SEQC) {
@@ -274,23 +279,23 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 __syncthreads();
             }
         }
-        // ---- odd first stage (R0 > 1): butterflies j < L / R0 = 2^LOGL on the operands j + q 2^LOGL of the image, 8 / R0 per
-        //      thread; outputs to j R0 + d
+        // ---- odd first stage (R0 > 1): butterflies j < L / RA on the operands j + q L / RA, 8 / RA per thread (predicated);
+        //      outputs to j RA + d
         if constexpr (R0 > 1) {
             constexpr int NB = NB0, UB = UB0;
-            U opnd[UB][R0];
+            U opnd[UB][RA];
             if constexpr (ODD_DIRECT) {
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
 #pragma unroll
-                    for (int q = 0; q < R0; ++q) opnd[u][q] = cur[u * R0 + q];
+                    for (int q = 0; q < RA; ++q) opnd[u][q] = cur[u * RA + q];
             } else {
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
                     const int j = t + TPT * u;
                     if (j < NB) {
 #pragma unroll
-                        for (int q = 0; q < R0; ++q) {
+                        for (int q = 0; q < RA; ++q) {
                             const int pt = j + q * NB;
                             opnd[u][q] = img[pt * PITCH + p + (IINT ? (pt / (L / 4)) * G::QSKEW : 0)];
                         }
@@ -304,15 +309,57 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 if (j < NB) {
 #pragma unroll
                     for (int sq = 0; sq < S; ++sq) {
-                        CX o[R0];
+                        CX o[RA];
 #pragma unroll
-                        for (int q = 0; q < R0; ++q) o[q] = TU::get(opnd[u][q], sq);
-                        dftR<R0, DIR>(o);
+                        for (int q = 0; q < RA; ++q) o[q] = TU::get(opnd[u][q], sq);
+                        dftR<RA, DIR>(o);
 #pragma unroll
-                        for (int q = 0; q < R0; ++q) TU::set(opnd[u][q], sq, o[q]);
+                        for (int q = 0; q < RA; ++q) TU::set(opnd[u][q], sq, o[q]);
                     }
 #pragma unroll
-                    for (int d = 0; d < R0; ++d) img[(j * R0 + d) * PITCH + p] = opnd[u][d];
+                    for (int d = 0; d < RA; ++d) img[(j * RA + d) * PITCH + p] = opnd[u][d];
+                }
+            }
+        }
+        // ---- second odd stage (R0 = 25, 27, 45): radix RB, Ns = RA: operands j + q L / RB times W_(RA RB)^(q (j mod RA)),
+        //      outputs to (j div RA) RA RB + (j mod RA) + d RA
+        if constexpr (RB > 1) {
+            constexpr int NB = L / RB, UB = (8 + RB - 1) / RB;
+            static_assert(TPT % RA == 0, "stage shape");
+            U opnd[UB][RB];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = t + TPT * u;
+                if (j < NB) {
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) opnd[u][q] = img[(j + q * NB) * PITCH + p];
+                }
+            }
+            __syncthreads();
+            const int tk = t % RA, tq = t / RA;
+            CX w[RB];
+#pragma unroll
+            for (int q = 1; q < RB; ++q) w[q] = wl[(q * tk) * (L / (RA * RB))];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = t + TPT * u;
+                if (j < NB) {
+#pragma unroll
+                    for (int sq = 0; sq < S; ++sq) {
+                        CX o[RB];
+#pragma unroll
+                        for (int q = 0; q < RB; ++q) {
+                            o[q] = TU::get(opnd[u][q], sq);
+                            if (q) o[q] = twmul<DIR>(o[q], w[q]);
+                        }
+                        dftR<RB, DIR>(o);
+#pragma unroll
+                        for (int q = 0; q < RB; ++q) TU::set(opnd[u][q], sq, o[q]);
+                    }
+                    const int pbase = (tq + u * (TPT / RA)) * (RA * RB) + tk;
+#pragma unroll
+                    for (int d = 0; d < RB; ++d) img[(pbase + d * RA) * PITCH + p] = opnd[u][d];
                 }
             }
         }
@@ -380,8 +427,8 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 }
             }
         };
-        if constexpr (R0 == 1) stage(std::integral_constant<int, 0>{});
-        if constexpr (NS > 1) stage(std::integral_constant<int, 1>{});
+        if constexpr (NODD == 0) stage(std::integral_constant<int, 0>{});
+        if constexpr (NS > 1 && NODD <= 1) stage(std::integral_constant<int, 1>{});
         if constexpr (NS > 2) stage(std::integral_constant<int, 2>{});
         if constexpr (NS > 3) stage(std::integral_constant<int, 3>{});
         if constexpr (NS > 4) stage(std::integral_constant<int, 4>{});

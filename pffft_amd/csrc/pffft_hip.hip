@@ -818,7 +818,7 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     // two (three beyond 2^20) tile passes: power-of-two n and the n whose odd part splits over two tile lengths (tile_tu.hip)
     // (deep: the row length of the streaming route is itself beyond LDS, or there is no streaming plan - five sweeps)
     const bool deep = !s->bigR || !s->sub || s->sub->kernel == K_BIG;
-    const bool tiled = g_variant != 80 && g_variant != 82 && tile_has_plan(s->n, deep);
+    const bool tiled = g_variant != 80 && g_variant != 82 && tile_has_plan(s->n, s->is_double, deep);
     // complex backward from the internal layout on the tile passes: the first one reads the layout itself (variant 86 = off)
     const bool fuse_in = !fwd && !ordered && !real && tiled && g_variant != 86;
     // ... and so does the column pass of the three-pass route when R is a multiple of 4

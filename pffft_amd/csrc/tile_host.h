@@ -61,16 +61,19 @@ static int tile_pass_mr(const cx<T>* in, cx<T>* out, unsigned long long ntiles, 
     return tile_pass<T, LOGL, 8, R0, 1, 1>(in, out, ntiles, D, dir, st, s, out_int, in_int);
 }
 
-// the odd-stage tile lengths that are instantiated: L = R0 2^logl, logl in [4, mr_max_logl(R0)]  (image <= 110 KiB)
-constexpr int MR_MIN_LOGL = 4;
-constexpr int mr_max_logl(int r0) { return r0 == 3 ? 8 : r0 == 5 ? 7 : r0 == 9 ? 6 : r0 == 15 ? 5 : 0; }
+// the odd-stage tile lengths that are instantiated: L = R0 2^logl, logl in [mr_min_logl(R0, double), mr_max_logl(R0)]  (48 <= L <= 768:
+// image <= 110 KiB).  A tile is C = 16 (float) / 8 (double) adjacent columns or rows, so both tile lengths of a plan must be
+// multiples of C: logl >= 4 in float, 3 in double.
+constexpr int mr_max_logl(int r0) { return r0 == 3 ? 8 : r0 == 5 ? 7 : r0 == 9 ? 6 : r0 == 15 ? 5 : (r0 == 25 || r0 == 27 || r0 == 45) ? 4 : 0; }
+constexpr int mr_min_logl(int r0, bool is_double) { return (is_double && r0 >= 9) ? 3 : 4; }
 
 template <typename T, int R0>
 static int tile_dispatch_mr(int logl, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
                             Setup* s, bool out_int, bool in_int) {
     switch (logl) {
+        case 3: if constexpr (mr_min_logl(R0, sizeof(T) == 8) == 3) return tile_pass_mr<T, 3, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int); break;
         case 4: return tile_pass_mr<T, 4, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int);
-        case 5: return tile_pass_mr<T, 5, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 5: if constexpr (mr_max_logl(R0) >= 5) return tile_pass_mr<T, 5, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int); break;
         case 6: if constexpr (mr_max_logl(R0) >= 6) return tile_pass_mr<T, 6, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int); break;
         case 7: if constexpr (mr_max_logl(R0) >= 7) return tile_pass_mr<T, 7, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int); break;
         case 8: if constexpr (mr_max_logl(R0) >= 8) return tile_pass_mr<T, 8, R0>(in, out, ntiles, D, dir, st, s, out_int, in_int); break;
@@ -88,6 +91,12 @@ int tile_mr_pass_5(bool is_double, int logl, const void* in, void* out, unsigned
 int tile_mr_pass_9(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
                    Setup* s, bool out_int, bool in_int);
 int tile_mr_pass_15(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
+                    Setup* s, bool out_int, bool in_int);
+int tile_mr_pass_25(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
+                    Setup* s, bool out_int, bool in_int);
+int tile_mr_pass_27(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
+                    Setup* s, bool out_int, bool in_int);
+int tile_mr_pass_45(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
                     Setup* s, bool out_int, bool in_int);
 
 #define PF_TILE_MR_TU(R0)                                                                                                              \

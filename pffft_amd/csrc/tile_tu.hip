@@ -1,7 +1,10 @@
 // libpffft_hip.so, translation unit of the two / three-pass tile kernels beyond LDS (fft_tile.h): the power-of-two tile
 // lengths, the plans and the pass descriptors.  The tile lengths with an odd first stage are instantiated in tile_mr*_tu.hip.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "tile_host.h"
 
@@ -54,6 +57,9 @@ static int tile_any(const TileLen& tl, int pp, const cx<T>* in, cx<T>* out, unsi
         case 5: return tile_mr_pass_5(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
         case 9: return tile_mr_pass_9(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
         case 15: return tile_mr_pass_15(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 25: return tile_mr_pass_25(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 27: return tile_mr_pass_27(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
+        case 45: return tile_mr_pass_45(sizeof(T) == 8, tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
         default: break;
     }
     g_last_error = "pffft_hip: tile pass radix out of range";
@@ -93,23 +99,44 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
     return tile_any<T>(tl, pp, in, out, ntiles, D, dir, st, s, out_int, false);
 }
 
-// Two-pass plan of a size with factors 3 and / or 5: n = L1 L2, L = R0 2^b with R0 in {1, 3, 5, 9, 15} (the odd part of n is a
-// product of two of them: 3, 5, 9, 15, 25, 27, 45, 75, 81, 135, 225) and a tile length that is instantiated: power of two
-// 64 .. 512, odd-stage lengths 16 R0 .. 768 (tile_host.h: mr_max_logl; image <= 110 KiB).  Which length is the column pass and
-// which the row pass is decided by the measured cost of each (us per GiB of vectors, float and double alike within 10 %,
-// tools/_bin/mrlen.py on MI355X): column tiles 105-125, but 165-180 from L = 640 (ten and more wavefronts per workgroup: 168
-// registers); row tiles 97-127, 125-140 from L = 576.  Three streaming passes cost ~285: plans above that are refused.
-// false: no plan - the three streaming passes of fft_big.h.
+// Two-pass plan of a size with factors 3 and / or 5: n = L1 L2, L = R0 2^b with R0 in {1, 3, 5, 9, 15, 25, 27, 45} and a tile
+// length that is instantiated: power of two 64 .. 512, odd-stage lengths 48 .. 768 (tile_host.h: mr_min_logl / mr_max_logl; image
+// <= 110 KiB).  Which length is the column pass and which the row pass is decided by the measured cost of each (us per GiB of
+// vectors, float and double alike within 10 %, tools/_bin/mrlen.py on MI355X): column tiles 105-125, but 165-180 from L = 640
+// (ten and more wavefronts per workgroup: 168 registers); row tiles 97-127, 125-140 from L = 576.  Three streaming passes cost
+// ~285 (five ~480 where the row length of that route is itself beyond LDS): plans above that are refused.  Tile lengths with two
+// odd stages (25, 27, 45): columns 118-128 (L = 720: 176-192), rows 102-138 (L = 720: 165-169).  false: no plan - the three streaming passes of fft_big.h.
 static int g_mr_min = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMIN"); return e ? atoi(e) : 48; }();    // A/B: shortest / longest
 static int g_mr_max = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMAX"); return e ? atoi(e) : 768; }();   // tile length of a plan
 static int tile_cost(const TileLen& t, bool columns) {
     const long long L = t.len();
     if (t.r0 == 1) return columns ? 103 : 97;
+    if (t.r0 >= 25) {                                    // two odd stages: one more exchange
+        if (columns) return L >= 600 ? 185 : 125;
+        return L >= 600 ? 167 : L >= 256 ? 133 : 108;
+    }
     if (columns) return L >= 600 ? 172 : L <= 100 ? 125 : 115;
     return L >= 560 ? 135 : L >= 256 ? 122 : 105;
 }
-static bool tile_plan(long long n, TileLen& a, TileLen& b) {
-    static const int R[5] = {1, 3, 5, 9, 15};
+// the tile lengths of one precision, ascending
+static const std::vector<TileLen>& tile_lengths(bool is_double) {
+    static std::once_flag once;
+    static std::vector<TileLen> f32, f64;
+    std::call_once(once, [] {
+        for (int dbl = 0; dbl < 2; ++dbl) {
+            std::vector<TileLen>& v = dbl ? f64 : f32;
+            for (int l = 6; l <= 9; ++l) v.push_back(TileLen{1, l});
+            for (int r0 : {3, 5, 9, 15, 25, 27, 45})
+                for (int l = mr_min_logl(r0, dbl != 0); l <= mr_max_logl(r0); ++l)
+                    if ((r0 << l) >= 48) v.push_back(TileLen{r0, l});
+            std::sort(v.begin(), v.end(), [](const TileLen& x, const TileLen& y) { return x.len() < y.len(); });
+        }
+    });
+    return is_double ? f64 : f32;
+}
+static bool tile_len_ok(const TileLen& t) { return (long long)t.len() >= g_mr_min && (long long)t.len() <= g_mr_max; }
+
+static bool tile_plan(long long n, bool is_double, bool deep, TileLen& a, TileLen& b) {
     if (const char* e = getenv("PFFFT_HIP_TILE_MRPLAN")) {   // A/B: "R1,l1,R2,l2" forces the two tile lengths
         int r1, l1, r2, l2;
         if (sscanf(e, "%d,%d,%d,%d", &r1, &l1, &r2, &l2) == 4 && ((long long)r1 << l1) * ((long long)r2 << l2) == n) {
@@ -117,67 +144,47 @@ static bool tile_plan(long long n, TileLen& a, TileLen& b) {
             return true;
         }
     }
-    int best = 286;
+    const std::vector<TileLen>& V = tile_lengths(is_double);
+    int best = deep ? 460 : 286;                         // (deep: the streaming route takes five sweeps, ~480)
     bool found = false;
-    for (int ia = 0; ia < 5; ++ia)
-        for (int la = (R[ia] == 1 ? 6 : MR_MIN_LOGL); la <= (R[ia] == 1 ? 9 : mr_max_logl(R[ia])); ++la) {
-            const TileLen ta{R[ia], la};
-            const long long L1 = ta.len();
-            if (n % L1 || L1 < g_mr_min || L1 > g_mr_max) continue;
-            const long long L2 = n / L1;
-            if (L2 < g_mr_min || L2 > g_mr_max) continue;
-            for (int ib = 0; ib < 5; ++ib) {
-                if (L2 % R[ib]) continue;
-                const long long p2 = L2 / R[ib];
-                if (p2 & (p2 - 1)) continue;
-                int lb = 0;
-                while ((1ll << lb) < p2) ++lb;
-                if (lb < (R[ib] == 1 ? 6 : MR_MIN_LOGL) || lb > (R[ib] == 1 ? 9 : mr_max_logl(R[ib]))) continue;
-                const TileLen tb{R[ib], lb};
-                const int c = tile_cost(ta, true) + tile_cost(tb, false);
-                if (c < best) { best = c; a = ta; b = tb; found = true; }
-            }
+    for (const TileLen& ta : V) {
+        if (!tile_len_ok(ta) || n % (long long)ta.len()) continue;
+        const long long L2 = n / (long long)ta.len();
+        for (const TileLen& tb : V) {
+            if ((long long)tb.len() != L2 || !tile_len_ok(tb)) continue;
+            const int c = tile_cost(ta, true) + tile_cost(tb, false);
+            if (c < best) { best = c; a = ta; b = tb; found = true; }
         }
+    }
     return found;
 }
 
 // Three tile passes n = L1 (L2 L3) (the shape of the power-of-two sizes beyond 2^20) for the sizes without a two-pass plan whose
 // streaming route would take five sweeps (its row length is itself beyond LDS: `deep`); ~330 us per GiB against ~450-550.
-static bool tile_plan3(long long n, TileLen& a, TileLen& b, TileLen& c) {
-    static const int R[5] = {1, 3, 5, 9, 15};
+static bool tile_plan3(long long n, bool is_double, TileLen& a, TileLen& b, TileLen& c) {
+    const std::vector<TileLen>& V = tile_lengths(is_double);
     int best = 1 << 30;
-    for (int ia = 0; ia < 5; ++ia)
-        for (int la = (R[ia] == 1 ? 6 : MR_MIN_LOGL); la <= (R[ia] == 1 ? 9 : mr_max_logl(R[ia])); ++la) {
-            const TileLen ta{R[ia], la};
-            if (n % ta.len() || (long long)ta.len() > g_mr_max) continue;
-            const long long rem = n / ta.len();
-            for (int ib = 0; ib < 5; ++ib)
-                for (int lb = (R[ib] == 1 ? 6 : MR_MIN_LOGL); lb <= (R[ib] == 1 ? 9 : mr_max_logl(R[ib])); ++lb) {
-                    const TileLen tb{R[ib], lb};
-                    if (rem % tb.len() || (long long)tb.len() > g_mr_max) continue;
-                    const long long L3 = rem / tb.len();
-                    if (L3 > g_mr_max) continue;
-                    for (int ic = 0; ic < 5; ++ic) {
-                        if (L3 % R[ic]) continue;
-                        const long long p2 = L3 / R[ic];
-                        if (p2 & (p2 - 1)) continue;
-                        int lc = 0;
-                        while ((1ll << lc) < p2) ++lc;
-                        if (lc < (R[ic] == 1 ? 6 : MR_MIN_LOGL) || lc > (R[ic] == 1 ? 9 : mr_max_logl(R[ic]))) continue;
-                        const TileLen tc{R[ic], lc};
-                        const int cst = tile_cost(ta, true) + tile_cost(tb, true) + tile_cost(tc, false);
-                        if (cst < best) { best = cst; a = ta; b = tb; c = tc; }
-                    }
-                }
+    for (const TileLen& ta : V) {
+        if (!tile_len_ok(ta) || n % (long long)ta.len()) continue;
+        const long long rem = n / (long long)ta.len();
+        for (const TileLen& tb : V) {
+            if (!tile_len_ok(tb) || rem % (long long)tb.len()) continue;
+            const long long L3 = rem / (long long)tb.len();
+            for (const TileLen& tc : V) {
+                if ((long long)tc.len() != L3 || !tile_len_ok(tc)) continue;
+                const int cst = tile_cost(ta, true) + tile_cost(tb, true) + tile_cost(tc, false);
+                if (cst < best) { best = cst; a = ta; b = tb; c = tc; }
+            }
         }
+    }
     return best != (1 << 30);
 }
 
-bool tile_has_plan(long long n, bool deep) {
+bool tile_has_plan(long long n, bool is_double, bool deep) {
     if (n > 0 && (n & (n - 1)) == 0) return n >= (1 << 12) && n <= (1ll << 27);
     if (g_variant == 83) return false;                   // variant 83: the streaming passes for these sizes (A/B)
     TileLen a, b, c;
-    return tile_plan(n, a, b) || (deep && n <= (1ll << 27) && tile_plan3(n, a, b, c));
+    return tile_plan(n, is_double, deep, a, b) || (deep && n <= (1ll << 27) && tile_plan3(n, is_double, a, b, c));
 }
 
 // canonical complex transform of `batch` vectors of n points: in -> out through ONE work buffer of the same size
@@ -190,11 +197,11 @@ static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t b
     if (n & (n - 1)) {
         TileLen a, b, c;
         if (g_variant == 83) return -1;
-        if (tile_plan(n, a, b)) {
+        if (tile_plan(n, sizeof(T) == 8, deep, a, b)) {
             if ((rc = pass_columns<T>(s, in, work, batch, a, b.len(), dir, st, in_int))) return rc;
             return pass_rows<T>(s, work, out, batch, b, a.len(), 1, dir, st, out_int);
         }
-        if (!deep || n > (1ll << 27) || !tile_plan3(n, a, b, c)) return -1;
+        if (!deep || n > (1ll << 27) || !tile_plan3(n, sizeof(T) == 8, a, b, c)) return -1;
         if ((rc = pass_columns<T>(s, in, work, batch, a, b.len() * c.len(), dir, st, in_int))) return rc;
         if ((rc = pass_columns<T>(s, work, work, batch * a.len(), b, c.len(), dir, st))) return rc;
         return pass_rows<T>(s, work, out, batch, c, a.len(), b.len(), dir, st, out_int);
