@@ -27,7 +27,7 @@ At N = 1 the default line also carries `configs`: every other BASELINE config at
 its own `roofline` and `cpu_baseline` (no warm-up beyond --warmup; the first launches of each are reported as
 `first_launches_ms` next to the timed region), and `sizes`: the reference's benchmark table
 (benchmarks/bench_pffft.c:445,547-550,1140-1150: every size of its lists, real and complex, float and double, ordered and
-unordered, forward and backward).  All GPU work runs back to back, the CPU baselines afterwards (an idle gap between
+unordered, forward and backward; plus six legal sizes with factors 3 and 5 beyond LDS, which that list does not hold).  All GPU work runs back to back, the CPU baselines afterwards (an idle gap between
 configs lets the clocks drop and the next config starts cold).  At N > 1 the line carries the C5 sharded config, weak and
 strong, `ranks_seen` from the RCCL all-reduce and the fastest / slowest rank's ms_per_step.
 Inputs are a counter hash of (seed, GLOBAL element index) (pffft_amd/sharding.py): a shard holds the same data whatever
@@ -336,6 +336,12 @@ REF_SIZES = [64, 96, 128, 160, 192, 256, 384, 480, 512, 640, 768, 800, 1024, 204
              262144, 1048576]
 
 
+# Sizes with factors 3 and 5 beyond LDS (legal sizes of tests/test_fft_factors.c the reference's benchmark list does not hold):
+# two tile passes (15360 = 96 x 160, 61440 = 240 x 256, 102400 = 400 x 256, 368640 = 576 x 640), three where the streaming route
+# needs five sweeps (1024000), and one size without a tile plan (12000 = 2^5 x 375: three streaming passes) - DESIGN.md §3.5
+BEYOND_LDS_35 = [12000, 15360, 61440, 102400, 368640, 1024000]
+
+
 def sizes_table(torch, pa, dev, timer):
     """The reference's benchmark table (benchmarks/bench_pffft.c:445,547-550: every size of its lists, real and complex,
     "PFFFT" = ordered and "PFFFT-U" = unordered, forward and backward - the reference times the pair; both halves are listed
@@ -344,14 +350,14 @@ def sizes_table(torch, pa, dev, timer):
     record without profiles/."""
     out = {"workload": "1 GiB of vectors per launch, 10 + 20 launches; [fwd ordered, fwd unordered, bwd ordered, bwd unordered] "
                        "as fractions of 8 TB/s on 2 x vector bytes",
-           "sizes": REF_SIZES}
+           "sizes": REF_SIZES, "sizes_with_factors_3_5_beyond_lds": BEYOND_LDS_35}
     for tag, dt, tdt in (("f32", np.float32, torch.float32), ("f64", np.float64, torch.float64)):
         isz = np.dtype(dt).itemsize
         pool = make_input(torch, dev, 1, (1 << 30) // isz, tdt, seed=7).reshape(-1)
         ypool = torch.empty_like(pool)
         for tr, name in ((pa.COMPLEX, "complex"), (pa.REAL, "real")):
             tab = {}
-            for N in REF_SIZES:
+            for N in REF_SIZES + BEYOND_LDS_35:
                 s = pa.Setup(N, tr, dt)
                 batch = max(1, pool.numel() // s.vec_scalars)
                 x = pool[: batch * s.vec_scalars].view(batch, s.vec_scalars)

@@ -31,10 +31,16 @@ tile_copy(const V4* __restrict__ in, V4* __restrict__ out, unsigned long long nt
         const unsigned a = (unsigned)(tile % tiles_per_vec);
         const unsigned long long vec = tile / tiles_per_vec;
         V4 v[8];
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 2) {
             const V4* src = in + vec * vec16 + (unsigned long long)a * RUN16;
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = __builtin_nontemporal_load(src + (unsigned long long)(t + TPT * m) * pitch16 + p);
+        } else if (MODE == 3) {
+            // tile-contiguous intermediate: per band of 2 RUN16 columns a chunk of (2 RUN16) rows x (2 RUN16) columns x 8 bytes
+            constexpr int UPB = (2 * RUN16) * (2 * RUN16) / 2;
+            const V4* src = in + vec * vec16 + (unsigned long long)a * UPB;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { const int g = tid + WG * m; v[m] = __builtin_nontemporal_load(src + (unsigned long long)(g / UPB) * (L * RUN16) + g % UPB); }
         } else {
             // rows: tile = 2*RUN16 rows (8-byte elements) x L points, contiguous rows of L*8 bytes = L/2 units
             const V4* src = in + vec * vec16 + (unsigned long long)a * (2 * RUN16) * (L / 2);
@@ -47,9 +53,15 @@ tile_copy(const V4* __restrict__ in, V4* __restrict__ out, unsigned long long nt
 #pragma unroll
         for (int m = 0; m < 8; ++m) { const int g = tid + WG * m, pt = g / RUN16, pu = g % RUN16; v[m] = img[pt * RUN16 + (pu ^ (pt & (RUN16 - 1)))]; }
         __syncthreads();
+        if (MODE == 2) {   // dense: the tile as one contiguous block
+            V4* dst = out + vec * vec16 + (unsigned long long)a * (L * RUN16);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) __builtin_nontemporal_store(v[m], dst + tid + WG * m);
+        } else {
         V4* dst = out + vec * vec16 + (unsigned long long)a * RUN16;
 #pragma unroll
         for (int m = 0; m < 8; ++m) { const int g = tid + WG * m, pt = g / RUN16, pu = g % RUN16; __builtin_nontemporal_store(v[m], dst + (unsigned long long)pt * pitch16 + pu); }
+        }
         }
         tile = tile_next;
     }
@@ -60,7 +72,7 @@ void run(const char* name, const V4* in, V4* out, size_t bytes, int wgs_per_cu) 
     static unsigned* ctr = nullptr; if (!ctr) CK(hipMalloc((void**)&ctr, 64));
     // vectors of L x L2 complex floats with L2 = L (square), pitch = L2 * 8 bytes
     const unsigned long long L2 = L, pitch16 = L2 * 8 / 16, vec16 = (unsigned long long)L * pitch16;
-    const unsigned tiles_per_vec = MODE == 0 ? (unsigned)(pitch16 / RUN16) : (unsigned)(L / (2 * RUN16));
+    const unsigned tiles_per_vec = (MODE == 0 || MODE == 2) ? (unsigned)(pitch16 / RUN16) : (unsigned)(L / (2 * RUN16));
     const unsigned long long nvec = bytes / (vec16 * 16), ntiles = nvec * tiles_per_vec;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto k = tile_copy<RUN16, L, MODE, DYNK>;
@@ -77,22 +89,20 @@ int main() {
     const size_t bytes = (size_t)1 << 30;
     V4 *in, *out; CK(hipMalloc((void**)&in, bytes)); CK(hipMalloc((void**)&out, bytes));
     CK(hipMemset(in, 1, bytes));
-    for (int w : {2, 3, 4, 6}) {
-        run<8, 256, 0>("A: 128-B runs, L=256 (pitch 2 KiB)", in, out, bytes, w);
-        run<8, 256, 1>("B: rows in, 128-B runs out, L=256", in, out, bytes, w);
+    for (int rep = 0; rep < 2; ++rep)
+    for (int w : {2, 3}) {
+        run<8, 256, 0, 4>("A : 128-B runs in and out, L=256, K=4", in, out, bytes, w);
+        run<8, 256, 2, 4>("A': 128-B runs in, dense tile out, K=4", in, out, bytes, w);
+        run<8, 256, 1, 4>("B : rows in, 128-B runs out, K=4", in, out, bytes, w);
+        run<8, 256, 3, 4>("B': 2-KiB chunks in, 128-B runs out, K=4", in, out, bytes, w);
+        run<8, 256, 0>("A : static", in, out, bytes, w);
+        run<8, 256, 2>("A': static", in, out, bytes, w);
+        run<8, 256, 1>("B : static", in, out, bytes, w);
+        run<8, 256, 3>("B': static", in, out, bytes, w);
     }
-    run<8, 256, 0, 1>("A: 128-B runs, L=256, in-order K=1", in, out, bytes, 3);
-    run<8, 256, 0, 2>("A: 128-B runs, L=256, in-order K=2", in, out, bytes, 3);
-    run<8, 256, 0, 4>("A: 128-B runs, L=256, in-order K=4", in, out, bytes, 3);
-    run<8, 256, 0, 8>("A: 128-B runs, L=256, in-order K=8", in, out, bytes, 3);
-    run<8, 256, 1, 4>("B: rows in, runs out, L=256, in-order K=4", in, out, bytes, 3);
-    run<8, 256, 1, 8>("B: rows in, runs out, L=256, in-order K=8", in, out, bytes, 3);
-    run<16, 256, 0, 4>("A: 256-B runs, L=256, in-order K=4", in, out, bytes, 2);
-    run<16, 256, 0>("A: 256-B runs, L=256", in, out, bytes, 2);
-    run<16, 256, 0>("A: 256-B runs, L=256", in, out, bytes, 3);
-    run<4, 256, 0>("A: 64-B runs, L=256", in, out, bytes, 4);
-    run<8, 512, 0>("A: 128-B runs, L=512 (pitch 4 KiB)", in, out, bytes, 2);
-    run<8, 128, 0>("A: 128-B runs, L=128 (pitch 1 KiB)", in, out, bytes, 4);
-    run<8, 128, 0>("A: 128-B runs, L=128 (pitch 1 KiB)", in, out, bytes, 8);
+    run<4, 1024, 0, 4>("A : 64-B runs, L=1024, K=4", in, out, bytes, 1);
+    run<4, 1024, 2, 4>("A': 64-B runs in, dense out, L=1024", in, out, bytes, 1);
+    run<4, 1024, 1, 4>("B : rows in, 64-B runs out, L=1024", in, out, bytes, 1);
+    run<4, 1024, 3, 4>("B': 512-B chunks in, 64-B runs out, L=1024", in, out, bytes, 1);
     return 0;
 }
