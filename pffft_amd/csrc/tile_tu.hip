@@ -102,7 +102,7 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
 // Two-pass plan of a size with factors 3 and / or 5: n = L1 L2, L = R0 2^b with R0 in {1, 3, 5, 9, 15, 25, 27, 45} and a tile
 // length that is instantiated: power of two 64 .. 512, odd-stage lengths 48 .. 768 (tile_host.h: mr_min_logl / mr_max_logl; image
 // <= 110 KiB).  Which length is the column pass and which the row pass is decided by the measured cost of each (us per GiB of
-// vectors, float and double alike within 10 %, tools/_bin/mrlen.py on MI355X): column tiles 105-125, but 165-180 from L = 640
+// vectors, float and double alike within 10 %, tools/tile_len_times.py on MI355X): column tiles 105-125, but 165-180 from L = 640
 // (ten and more wavefronts per workgroup: 168 registers); row tiles 97-127, 125-140 from L = 576.  Three streaming passes cost
 // ~285 (five ~480 where the row length of that route is itself beyond LDS): plans above that are refused.  Tile lengths with two
 // odd stages (25, 27, 45): columns 118-128 (L = 720: 176-192), rows 102-138 (L = 720: 165-169).  false: no plan - the three streaming passes of fft_big.h.
