@@ -173,4 +173,10 @@ def test_odd_stage_tile_plans(ref, dt, N):
         finally:
             pa.set_variant(0)
         assert relerr(a.cpu().numpy(), b.cpu().numpy()) <= tol_for(dt, NN)
+        # in place == out of place, bit for bit, both layouts (the passes go through the work buffer either way)
+        for o in (True, False):
+            want = s.transform_batch(x, None, pa.FORWARD, o)
+            xi = x.clone()
+            got = s.transform_batch(xi, xi, pa.FORWARD, o)
+            assert torch.equal(got, want), (NN, o)
         s.close()
