@@ -337,8 +337,9 @@ REF_SIZES = [64, 96, 128, 160, 192, 256, 384, 480, 512, 640, 768, 800, 1024, 204
 
 
 # Sizes with factors 3 and 5 beyond LDS (legal sizes of tests/test_fft_factors.c the reference's benchmark list does not hold):
-# two tile passes (15360 = 96 x 160, 61440 = 240 x 256, 102400 = 400 x 256, 368640 = 576 x 640), three where the streaming route
-# needs five sweeps (1024000), and one size without a tile plan (12000 = 2^5 x 375: three streaming passes) - DESIGN.md §3.5
+# two tile passes (15360 = 64 x 240, 61440 = 256 x 240, 102400 = 400 x 256, 368640 = 480 x 768: pffft_hip_tile_plan), three where the
+# streaming route needs five sweeps (1024000 = 80 x 160 x 80), and one size without a tile plan (12000 = 2^5 x 375: three streaming
+# passes) - DESIGN.md §3.5
 BEYOND_LDS_35 = [12000, 15360, 61440, 102400, 368640, 1024000]
 
 

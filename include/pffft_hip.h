@@ -166,6 +166,12 @@ int pffastconv_hip_apply_batch(PFFASTCONV_Setup *, const float *d_input, int inp
  * run-time plan because the size has no generated compile-time plan (no legal size today), "fourstep" = tile / streaming
  * passes beyond LDS): for tests/bench. */
 const char *pffft_hip_kernel_name(const void *setup);
+/* The tile plan of a complex core transform of n points beyond LDS (n = N for complex setups, N / 2 for real ones): returns the
+ * number of tile passes over HBM — 2 or 3 — and their tile lengths in `lengths` (column pass(es) first, the row pass last), or 0
+ * when the size runs on the streaming passes (or is LDS-resident: the planner is not consulted then).  `deep` != 0: the size's
+ * streaming route would take five sweeps (its row length is itself beyond LDS), which admits costlier tile plans.  Pure host
+ * arithmetic, no device needed: for tests and for callers that want to know what a size costs. */
+int pffft_hip_tile_plan(long long n, int is_double, int deep, int lengths[3]);
 const char *pffft_hip_last_error(void);
 /* Number of legacy (void) entries that failed in this process so far.  The legacy entries have no error channel
  * (include/pffft/pffft.h:159); a failed call — no device, HIP error — prints one line on stderr, fills its output

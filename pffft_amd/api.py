@@ -97,6 +97,8 @@ def lib():
     L.pffft_hip_device_count.restype = C.c_int
     L.pffft_hip_set_variant.restype = None; L.pffft_hip_set_variant.argtypes = [C.c_int]
     L.pffft_hip_has_variants.restype = C.c_int; L.pffft_hip_has_variants.argtypes = []
+    L.pffft_hip_tile_plan.restype = C.c_int
+    L.pffft_hip_tile_plan.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_int)]
     _LIB = L
     return L
 
@@ -145,6 +147,14 @@ def set_variant(v: int) -> None:
 def has_variants() -> bool:
     """True for a development build (PFFFT_HIP_VARIANTS=1): both variants of every Stockham plan are instantiated."""
     return bool(lib().pffft_hip_has_variants())
+
+
+def tile_plan(n, is_double=False, deep=False):
+    """Tile lengths of the passes over HBM of a complex core transform of n points beyond LDS ([] = streaming passes / not planned
+    by the tile planner): include/pffft_hip.h pffft_hip_tile_plan.  Host arithmetic only."""
+    buf = (C.c_int * 3)()
+    k = lib().pffft_hip_tile_plan(int(n), int(bool(is_double)), int(bool(deep)), buf)
+    return [int(buf[i]) for i in range(k)]
 
 
 def kernel_name(setup: "Setup") -> str:

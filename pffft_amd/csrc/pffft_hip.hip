@@ -1367,6 +1367,10 @@ PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
         default: return s->sk_ok ? (pf::sub_is_fast(s) ? "stockham" : "stockham_rt") : "none";
     }
 }
+PF_EXPORT int pffft_hip_tile_plan(long long n, int is_double, int deep, int lengths[3]) {
+    if (!lengths) return 0;
+    return pf::tile_plan_lengths(n, is_double != 0, deep != 0, lengths);
+}
 PF_EXPORT const char* pffft_hip_last_error(void) { return pf::g_last_error.c_str(); }
 PF_EXPORT unsigned pffft_hip_error_count(void) { return pf::g_error_count.load(); }
 PF_EXPORT int pffft_hip_device_count(void) {

@@ -187,6 +187,28 @@ bool tile_has_plan(long long n, bool is_double, bool deep) {
     return tile_plan(n, is_double, deep, a, b) || (deep && n <= (1ll << 27) && tile_plan3(n, is_double, a, b, c));
 }
 
+int tile_plan_lengths(long long n, bool is_double, bool deep, int lengths[3]) {
+    lengths[0] = lengths[1] = lengths[2] = 0;
+    if (n <= 0) return 0;
+    TileLen a, b, c;
+    if ((n & (n - 1)) == 0) {
+        int logn = 0;
+        while ((1ll << logn) < n) ++logn;
+        if (logn < 12 || logn > 27) return 0;
+        if (logn <= 20) { lengths[0] = 1 << (logn / 2); lengths[1] = 1 << (logn - logn / 2); return 2; }
+        const int l1 = logn / 3, rem = logn - l1;
+        lengths[0] = 1 << l1; lengths[1] = 1 << (rem / 2); lengths[2] = 1 << (rem - rem / 2);
+        return 3;
+    }
+    if (g_variant == 83) return 0;
+    if (tile_plan(n, is_double, deep, a, b)) { lengths[0] = (int)a.len(); lengths[1] = (int)b.len(); return 2; }
+    if (deep && n <= (1ll << 27) && tile_plan3(n, is_double, a, b, c)) {
+        lengths[0] = (int)a.len(); lengths[1] = (int)b.len(); lengths[2] = (int)c.len();
+        return 3;
+    }
+    return 0;
+}
+
 // canonical complex transform of `batch` vectors of n points: in -> out through ONE work buffer of the same size
 // (in may equal out; work must differ from both).  Returns -1 when the size is outside the tile plans.
 // out_int: forward transform straight into the internal layout (the last pass stores it: no reorder sweep)

@@ -195,3 +195,54 @@ def test_legal_size_enumeration_matches_the_library():
             s = L.pffft_new_setup(N, tr)
             assert s, N
             L.pffft_destroy_setup(s)
+
+
+def test_tile_planner_over_every_legal_size():
+    """The planner of the tile passes beyond LDS (tile_tu.hip, reached through pffft_hip_tile_plan: host arithmetic, no GPU): for
+    EVERY legal core size n = 16 2^a 3^b 5^c up to 2^24, both precisions, with and without `deep`, a plan is 2 or 3 tile lengths
+    whose product is n, each one an instantiated length (power of two 64 .. 1024, or R0 2^b with R0 in {3, 5, 9, 15, 25, 27, 45},
+    48 .. 768) and a multiple of the tile width (16 float / 8 double complex numbers) - a plan that names a length without a
+    kernel would only fail at launch time, beyond the sizes the GPU walk of tests/test_gpu_round3.py covers."""
+    import pffft_amd as pa
+    from conftest import legal_sizes
+
+    def instantiated(L, is_double):
+        r0 = L
+        b = 0
+        while r0 % 2 == 0:
+            r0 //= 2; b += 1
+        if r0 == 1:
+            return 6 <= b <= 10
+        if r0 not in (3, 5, 9, 15, 25, 27, 45) or not 48 <= L <= 768:
+            return False
+        return b >= (3 if (is_double and r0 >= 9) else 4)
+
+    covered = {False: 0, True: 0}
+    sizes = [n for n in legal_sizes(pa.COMPLEX, 16, 1 << 24)]
+    assert len(sizes) > 500
+    for is_double in (False, True):
+        for n in sizes:
+            for deep in (False, True):
+                plan = pa.tile_plan(n, is_double, deep)
+                if not plan:
+                    continue
+                assert len(plan) in (2, 3), (n, plan)
+                prod = 1
+                for L in plan:
+                    prod *= L
+                    assert instantiated(L, is_double), (n, is_double, deep, plan)
+                    assert L % (8 if is_double else 16) == 0, (n, plan)
+                assert prod == n, (n, plan)
+                if n & (n - 1):
+                    assert all(L <= 768 for L in plan) and (len(plan) == 2 or deep), (n, deep, plan)
+                if deep and n & (n - 1):
+                    covered[is_double] += 1
+            # without `deep` a plan is never costlier than with it: whatever is planned shallow is planned deep as well
+            if pa.tile_plan(n, is_double, False):
+                assert pa.tile_plan(n, is_double, True), n
+    # the sizes DESIGN.md §3.5 names
+    assert pa.tile_plan(61440) == [256, 240] and pa.tile_plan(115200) == [480, 240] and pa.tile_plan(9216, True) == [64, 144]
+    assert pa.tile_plan(12000) == [] and pa.tile_plan(1024000) == [] and len(pa.tile_plan(1024000, False, True)) == 3
+    assert pa.tile_plan(288000) == [] and pa.tile_plan(288000, False, True) == [400, 720]      # two costly passes beat five sweeps
+    assert pa.tile_plan(1 << 16) == [256, 256] and pa.tile_plan(1 << 22) == [128, 128, 256] and pa.tile_plan(2048) == []
+    assert covered[False] > 100 and covered[True] > 150, covered
