@@ -1,11 +1,12 @@
 """Scan of the legal sizes for slow outliers AND wrong values (development tool):
 
-    python tools/size_scan.py LO HI [f32|f64] [stride]
-    python tools/size_scan.py sizes N1,N2,... [f32|f64]         (explicit list; sizes a transform type rejects are skipped)
+    python tools/size_scan.py LO HI [f32|f64] [stride] [steady]
+    python tools/size_scan.py sizes N1,N2,... [f32|f64] [steady]         (explicit list; sizes a transform type rejects are skipped)
 
 every `stride`-th legal size N = nmin 2^a 3^b 5^c in [LO, HI] (the set tests/test_fft_factors.c:36-61 enumerates), complex and
 real, the four direction x layout combinations, 256 MiB per launch, 10 untimed + 10 timed launches -> fraction of 8 TB/s on
-2 x vector bytes (short runs: below steady state; the point is outliers).  While it times it CHECKS: the canonical forward
+2 x vector bytes (short runs: below steady state; the point is outliers).  With a trailing `steady`: 1 GiB per launch, 40 untimed
+launches per size, then 10 untimed + 20 timed per combination - the convention of bench.py's sizes table.  While it times it CHECKS: the canonical forward
 spectrum of two vectors of the batch against a float64 numpy FFT (1e-5 float / 1e-12 double, the parity bar),
 zreorder(unordered) == ordered bit for bit, and the backward transforms through the round trip.  A failed check prints
 "BAD" and the exit status is 1.  (No oracle/ import here: tools are not test infrastructure.)"""
@@ -45,6 +46,8 @@ def canonical_f64(x, N, tr):
 
 def main():
     explicit = None
+    steady = sys.argv[-1] == "steady"
+    if steady: sys.argv.pop()
     if sys.argv[1] == "sizes":
         explicit = [int(v) for v in sys.argv[2].split(",")]
         lo, hi = min(explicit), max(explicit)
@@ -55,16 +58,19 @@ def main():
     tdt = torch.float64 if dt == np.float64 else torch.float32
     tol = 1e-12 if dt == np.float64 else 1e-5
     bad = 0
-    print(f"# tools/size_scan.py {lo} {hi} {np.dtype(dt).name} stride {stride}: fraction of 8 TB/s, "
+    print(f"# tools/size_scan.py {lo} {hi} {np.dtype(dt).name} stride {stride}{' steady (1 GiB per launch, 40 + 10 untimed, 20 timed)' if steady else ''}: fraction of 8 TB/s, "
           "fwd ordered / fwd unordered / bwd ordered / bwd unordered; err = max rel error of the checked vectors vs float64 numpy")
     for tr, name in ((pa.COMPLEX, "cplx"), (pa.REAL, "real")):
         for N in ([v for v in explicit if v in set(legal_sizes(tr, lo, hi))] if explicit else legal_sizes(tr, lo, hi)[::stride]):
             s = pa.Setup(N, tr, dt)
             isz = np.dtype(dt).itemsize
-            batch = max(2, (1 << 28) // (s.vec_scalars * isz))
+            batch = max(2, (1 << (30 if steady else 28)) // (s.vec_scalars * isz))
             x = torch.rand(batch, s.vec_scalars, device="cuda", dtype=tdt) * 2 - 1
             y = torch.empty_like(x)
             res = []
+            nt = 20 if steady else 10
+            if steady:
+                for _ in range(40): s.transform_batch(x, y, pa.FORWARD, True)
             for d in (pa.FORWARD, pa.BACKWARD):
                 for o in (True, False):
                     f = lambda: s.transform_batch(x, y, d, o)
@@ -72,9 +78,9 @@ def main():
                     torch.cuda.synchronize()
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
-                    for _ in range(10): f()
+                    for _ in range(nt): f()
                     b.record(); torch.cuda.synchronize()
-                    res.append(2 * x.numel() * isz / (a.elapsed_time(b) / 10 * 1e-3) / 8e12)
+                    res.append(2 * x.numel() * isz / (a.elapsed_time(b) / nt * 1e-3) / 8e12)
             # ---- values: first and last vector of the batch
             idx = torch.tensor([0, batch - 1], device="cuda")
             xs = x[idx].contiguous()
