@@ -37,6 +37,9 @@ struct TileDesc {
     unsigned col_a, col_b;                            // four-step twiddle column of sequence c: a col_a + b col_b + c
     unsigned long long M;                             // modulus of the four-step twiddle, output (k, c) *= W_M^(k col); 0 = none
     int seq_contig;                                   // 1: pass A tile (iss == 1), 0: pass B tile (ips == 1)
+    // ragged last tile along a (float only: a tile is 16 sequences, a tile length may be 8 mod 16): 16-byte units of sequences
+    // that exist in tile a = TA - 1 (every other tile: all of them).  0 = not ragged.
+    unsigned last_units;
 };
 
 template <typename T> struct TileUnit;                // one 16-byte LDS / global unit
@@ -106,7 +109,9 @@ template <int WB, typename CX> __device__ __forceinline__ CX tile_w3(const CX* w
 //   internal layout (pffft_transform backward takes it, :1423-1462 / cplx_preprocess): per point row n1' < L/4 the four
 //   quarters of the columns are a run of C/4 whole blocks, loaded as dense 16-byte units; a lane ^ 1 (float) / lane ^ 2 (double)
 //   DPP exchange turns the (re group, im group) units into the image's (re, im) sequence units.
-template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0, int IINT = 0, int R0 = 1>
+// RAG = 1 (float only): the last tile along a may be ragged (TileDesc::last_units); RAG = 0 compiles the predicates away (they cost
+// the L = 512 kernels 4 % when left to run time)
+template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0, int IINT = 0, int R0 = 1, int RAG = 0>
 __global__ void __launch_bounds__((R0 << LOGL) / 8 * PP, PF ? 2 : 3)
 tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned long long ntiles, TileDesc D, unsigned* ctr) {
     typedef cx<T> CX;
@@ -149,10 +154,13 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     }
 
     // (eb: OINT only - canonical index, inside its vector, of the tile's first output element; dst is then the vector's base)
-    auto tile_bases = [&](unsigned long long tile, const CX*& src, CX*& dst, unsigned& col0, unsigned long long& eb) {
+    // (pv: the 16-byte sequence units of the tile that exist - PP but for a ragged last tile)
+    auto tile_bases = [&](unsigned long long tile, const CX*& src, CX*& dst, unsigned& col0, unsigned long long& eb, int& pv) {
         const unsigned b = (unsigned)(tile % D.TB);
         const unsigned long long rest = tile / D.TB;
         const unsigned a = (unsigned)(rest % D.TA);
+        if constexpr (RAG) pv = (D.last_units && a == D.TA - 1) ? (int)D.last_units : PP;
+        else pv = PP;
         const unsigned long long vec = rest / D.TA;
         if constexpr (IINT) { eb = a * D.in_a + b * D.in_b; src = in + vec * D.vstride; }
         else src = in + vec * D.vstride + a * D.in_a + b * D.in_b;
@@ -164,33 +172,36 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     // pass B: elements g = tid + i WG of the [sequence][point] tile (coalesced over the points of a row)
     typedef typename std::conditional<SEQC != 0, U, CX>::type LD;
     constexpr int UPB_ = 2 * (int)sizeof(T), UPP_ = (C / 4) * UPB_;   // 16-byte units per block / per point row of the internal layout
-    auto issue_loads = [&](const CX* src, LD (&r)[NLD], unsigned long long eb) {
+    auto issue_loads = [&](const CX* src, LD (&r)[NLD], unsigned long long eb, int pv) {
         if constexpr (IINT) {
             static_assert(!IINT || (SEQC && ((L / 4) * UPP_) == 8 * WG), "internal-layout input: eight units per thread");
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int g = tid + i * WG, ptq = g / UPP_, rr = g % UPP_, bb = rr / UPB_;
-                r[i] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + 4 * (eb + (unsigned long long)ptq * D.ips + 4 * bb)) + rr % UPB_);
+                if (bb * 4 < pv * S)
+                    r[i] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + 4 * (eb + (unsigned long long)ptq * D.ips + 4 * bb)) + rr % UPB_);
             }
         } else if constexpr (ODD_DIRECT) {
 #pragma unroll
             for (int u = 0; u < UB0; ++u) {
                 const int j = t + TPT * u;
-                if (j < NB0) {
+                if (j < NB0 && p < pv) {
 #pragma unroll
                     for (int q = 0; q < RA; ++q)
                         r[u * RA + q] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)(j + q * NB0) * D.ips + S * p));
                 }
             }
         } else if constexpr (SEQC) {
+            if (p < pv) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
-                r[m] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)(t + TPT * m) * D.ips + S * p));
+                for (int m = 0; m < 8; ++m)
+                    r[m] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)(t + TPT * m) * D.ips + S * p));
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int g = tid + i * WG, seq = WG == L ? i : g / L, pt = WG == L ? tid : g % L;   // (128-byte runs: WG == L)
-                r[i] = __builtin_nontemporal_load(src + (unsigned long long)seq * D.iss + pt);
+                if (seq < pv * S) r[i] = __builtin_nontemporal_load(src + (unsigned long long)seq * D.iss + pt);
             }
         }
     };
@@ -214,7 +225,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     }
     LD nxt[NLD];
     if constexpr (PF) {
-        if (tile < ntiles) { const CX* s0; CX* d0; unsigned cc; unsigned long long e0 = 0; tile_bases(tile, s0, d0, cc, e0); issue_loads(s0, nxt, e0); }
+        if (tile < ntiles) { const CX* s0; CX* d0; unsigned cc; unsigned long long e0 = 0; int pv0; tile_bases(tile, s0, d0, cc, e0, pv0); issue_loads(s0, nxt, e0, pv0); }
     }
     for (unsigned it = 0; tile < ntiles; ++it) {
         if (dyn && tid == 0) {
@@ -222,14 +233,15 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
             pend = atomicAdd(&ctr[0], 1u);
         }
         const CX* src; CX* dst; unsigned col0; unsigned long long ebase = 0;
-        tile_bases(tile, src, dst, col0, ebase);
+        int pv;
+        tile_bases(tile, src, dst, col0, ebase, pv);
         LD cur[NLD];
         if constexpr (PF) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) cur[i] = nxt[i];
-            if (tile1 < ntiles) { const CX* s1; CX* d1; unsigned cc; unsigned long long e1 = 0; tile_bases(tile1, s1, d1, cc, e1); issue_loads(s1, nxt, e1); }
+            if (tile1 < ntiles) { const CX* s1; CX* d1; unsigned cc; unsigned long long e1 = 0; int pv1; tile_bases(tile1, s1, d1, cc, e1, pv1); issue_loads(s1, nxt, e1, pv1); }
         } else {
-            issue_loads(src, cur, ebase);
+            issue_loads(src, cur, ebase, pv);
         }
         U v[8];   // v[m] = unit p of point t + TPT m
         if constexpr (IINT) {
@@ -443,6 +455,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
 #pragma unroll
             for (int i = 0; i < (L / 4) * UPP / WG; ++i) {
                 const int g = tid + i * WG, ptq = g / UPP, r = g % UPP, bb = r / UPB, m = (r / UPQ) % 4, sub = r % UPQ;
+                if (bb * 4 >= pv * S) continue;                                      // (ragged last tile: these blocks do not exist)
                 const U* sp = img + (ptq + m * (L / 4)) * PITCH + m * G::QSKEW + bb * UPS;
                 // internal layout in complex units: 4 t + 4 m + 2 p (+ l / 2), t = canonical index of the group's first bin in quarter 0
                 U* dp = reinterpret_cast<U*>(dst + 4 * (ebase + (unsigned long long)ptq * D.ops + 4 * bb)) + r % UPB;
@@ -462,7 +475,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int g = tid + i * WG, pt = g / PP, pu = g % PP;
-            __builtin_nontemporal_store(img[pt * PITCH + pu], reinterpret_cast<U*>(dst + (unsigned long long)pt * D.ops + S * pu));
+            if (pu < pv) __builtin_nontemporal_store(img[pt * PITCH + pu], reinterpret_cast<U*>(dst + (unsigned long long)pt * D.ops + S * pu));
         }
         }
         const unsigned long long tile2 = dyn ? (unsigned long long)s_next[it & 1] : tile1 + gridDim.x;

@@ -11,9 +11,9 @@ namespace pf {
 
 // PFSEL: -1 = both prefetch variants are instantiated and chosen at run time (power-of-two lengths, PFFFT_HIP_TILE_PF A/B);
 //         0 / 1 = only that one (odd-stage lengths: the choice is a function of the geometry, half the kernels)
-template <typename T, int LOGL, int PP, int R0 = 1, int PFSEL = -1, int PFSEL_B = PFSEL>
-static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
-                     bool out_int = false, bool in_int = false, int pf_force = -1) {
+template <typename T, int LOGL, int PP, int R0, int PFSEL, int PFSEL_B, int RAG>
+static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
+                          bool out_int, bool in_int, int pf_force) {
     typedef TileGeom<T, LOGL, PP, R0> G;
     const size_t lds = G::lds_bytes(D.M > (1ull << (2 * G::WB)) ? 3 : 2);
     void (*k)(const cx<T>*, cx<T>*, unsigned long long, TileDesc, unsigned*);
@@ -21,18 +21,18 @@ static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, con
     if constexpr (PFSEL < 0) {
         // register prefetch of the next tile where one or two workgroups fill a CU (images of 40 KiB and more)
         const bool pf = pf_force >= 0 ? pf_force != 0 : lds > 40 * 1024;
-        if (D.seq_contig && in_int && !fw) k = pf ? tile_fft_kernel<T, LOGL, PP, BWD, 1, 1, 0, 1, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0, 0, 1, R0>;
-        else if (D.seq_contig) k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 1, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 1, 0, 0, R0>)
-                                 : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 0, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0, 0, 0, R0>);
-        else if (out_int && fw) k = pf ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1, 1, 0, R0> : tile_fft_kernel<T, LOGL, PP, FWD, 0, 0, 1, 0, R0>;
-        else k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 1, 0, 0, R0>)
-                    : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 0, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 0, 0, 0, R0>);
+        if (D.seq_contig && in_int && !fw) k = pf ? tile_fft_kernel<T, LOGL, PP, BWD, 1, 1, 0, 1, R0, RAG> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0, 0, 1, R0, RAG>;
+        else if (D.seq_contig) k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 1, 0, 0, R0, RAG> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 1, 0, 0, R0, RAG>)
+                                 : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, 0, 0, 0, R0, RAG> : tile_fft_kernel<T, LOGL, PP, BWD, 1, 0, 0, 0, R0, RAG>);
+        else if (out_int && fw) k = pf ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1, 1, 0, R0, RAG> : tile_fft_kernel<T, LOGL, PP, FWD, 0, 0, 1, 0, R0, RAG>;
+        else k = pf ? (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1, 0, 0, R0, RAG> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 1, 0, 0, R0, RAG>)
+                    : (fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 0, 0, 0, R0, RAG> : tile_fft_kernel<T, LOGL, PP, BWD, 0, 0, 0, 0, R0, RAG>);
     } else {
         constexpr int PF = PFSEL, PFB = PFSEL_B;
-        if (D.seq_contig && in_int && !fw) k = tile_fft_kernel<T, LOGL, PP, BWD, 1, PF, 0, 1, R0>;
-        else if (D.seq_contig) k = fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, PF, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 1, PF, 0, 0, R0>;
-        else if (out_int && fw) k = tile_fft_kernel<T, LOGL, PP, FWD, 0, PFB, 1, 0, R0>;
-        else k = fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, PFB, 0, 0, R0> : tile_fft_kernel<T, LOGL, PP, BWD, 0, PFB, 0, 0, R0>;
+        if (D.seq_contig && in_int && !fw) k = tile_fft_kernel<T, LOGL, PP, BWD, 1, PF, 0, 1, R0, RAG>;
+        else if (D.seq_contig) k = fw ? tile_fft_kernel<T, LOGL, PP, FWD, 1, PF, 0, 0, R0, RAG> : tile_fft_kernel<T, LOGL, PP, BWD, 1, PF, 0, 0, R0, RAG>;
+        else if (out_int && fw) k = tile_fft_kernel<T, LOGL, PP, FWD, 0, PFB, 1, 0, R0, RAG>;
+        else k = fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, PFB, 0, 0, R0, RAG> : tile_fft_kernel<T, LOGL, PP, BWD, 0, PFB, 0, 0, R0, RAG>;
     }
     int rc = allow_big_lds(k, lds);
     if (rc) return rc;
@@ -52,6 +52,16 @@ static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, con
     return 0;
 }
 
+template <typename T, int LOGL, int PP, int R0 = 1, int PFSEL = -1, int PFSEL_B = PFSEL>
+static int tile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
+                     bool out_int = false, bool in_int = false, int pf_force = -1) {
+    // a ragged last tile exists in float only (a double tile is 8 sequences, every tile length a multiple of 8)
+    if constexpr (sizeof(T) == 4) {
+        if (D.last_units) return tile_pass_impl<T, LOGL, PP, R0, PFSEL, PFSEL_B, 1>(in, out, ntiles, D, dir, st, s, out_int, in_int, pf_force);
+    }
+    return tile_pass_impl<T, LOGL, PP, R0, PFSEL, PFSEL_B, 0>(in, out, ntiles, D, dir, st, s, out_int, in_int, pf_force);
+}
+
 // tile lengths with an odd first stage: L = R0 2^logl, 128-byte runs (PP = 8)
 template <typename T, int LOGL, int R0>
 static int tile_pass_mr(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
@@ -61,11 +71,11 @@ static int tile_pass_mr(const cx<T>* in, cx<T>* out, unsigned long long ntiles, 
     return tile_pass<T, LOGL, 8, R0, 1, 1>(in, out, ntiles, D, dir, st, s, out_int, in_int);
 }
 
-// the odd-stage tile lengths that are instantiated: L = R0 2^logl, logl in [mr_min_logl(R0, double), mr_max_logl(R0)]  (48 <= L <= 768:
-// image <= 110 KiB).  A tile is C = 16 (float) / 8 (double) adjacent columns or rows, so both tile lengths of a plan must be
-// multiples of C: logl >= 4 in float, 3 in double.
+// the odd-stage tile lengths that are instantiated: L = R0 2^logl, logl in [mr_min_logl(R0), mr_max_logl(R0)]  (48 <= L <= 768:
+// image <= 110 KiB).  A tile is C = 16 (float) / 8 (double) adjacent columns or rows; every tile length is a multiple of 8, and in
+// float a length that is 8 mod 16 leaves the other pass a ragged last tile of 8 sequences (TileDesc::last_units).
 constexpr int mr_max_logl(int r0) { return r0 == 3 ? 8 : r0 == 5 ? 7 : r0 == 9 ? 6 : r0 == 15 ? 5 : (r0 == 25 || r0 == 27 || r0 == 45) ? 4 : 0; }
-constexpr int mr_min_logl(int r0, bool is_double) { return (is_double && r0 >= 9) ? 3 : 4; }
+constexpr int mr_min_logl(int r0, bool) { return r0 >= 9 ? 3 : 4; }
 
 template <typename T, int R0>
 static int tile_dispatch_mr(int logl, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,

@@ -73,7 +73,8 @@ static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long lon
                         bool in_int = false) {
     const int pp = pick_pp<T>(tl), C = pp * TileUnit<T>::S;
     TileDesc D{};
-    D.TA = (unsigned)(cols / C); D.TB = 1;
+    D.TA = (unsigned)((cols + C - 1) / C); D.TB = 1;
+    D.last_units = (unsigned)((cols % C) / TileUnit<T>::S);      // ragged last tile (float, cols = 8 mod 16): 0 = none
     D.vstride = tl.len() * cols;
     D.in_a = C; D.out_a = C; D.ips = cols; D.iss = 1; D.ops = cols;
     D.col_a = (unsigned)C; D.M = D.vstride; D.seq_contig = 1;
@@ -90,7 +91,8 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
     const int pp = pick_pp<T>(tl), C = pp * TileUnit<T>::S;
     const unsigned long long L = tl.len();
     TileDesc D{};
-    D.TA = (unsigned)(outer / C); D.TB = (unsigned)inner;
+    D.TA = (unsigned)((outer + C - 1) / C); D.TB = (unsigned)inner;
+    D.last_units = (unsigned)((outer % C) / TileUnit<T>::S);
     D.vstride = outer * inner * L;
     D.in_a = (unsigned long long)C * inner * L; D.in_b = L; D.ips = 1; D.iss = inner * L;
     D.out_a = C; D.out_b = outer; D.ops = outer * inner;
@@ -117,6 +119,11 @@ static int tile_cost(const TileLen& t, bool columns) {
     }
     if (columns) return L >= 600 ? 172 : L <= 100 ? 125 : 115;
     return L >= 560 ? 135 : L >= 256 ? 122 : 105;
+}
+// cost factor in percent of a pass whose sequence count `seqs` is not a multiple of the tile width
+static int ragged_pct(unsigned long long seqs, bool is_double) {
+    const unsigned long long C = is_double ? 8 : 16;
+    return (int)(100 * ((seqs + C - 1) / C * C) / seqs);
 }
 // the tile lengths of one precision, ascending
 static const std::vector<TileLen>& tile_lengths(bool is_double) {
@@ -152,7 +159,8 @@ static bool tile_plan(long long n, bool is_double, bool deep, TileLen& a, TileLe
         const long long L2 = n / (long long)ta.len();
         for (const TileLen& tb : V) {
             if ((long long)tb.len() != L2 || !tile_len_ok(tb)) continue;
-            const int c = tile_cost(ta, true) + tile_cost(tb, false);
+            // (float: a length that is 8 mod 16 leaves the OTHER pass a half-empty last tile of 8 sequences)
+            const int c = tile_cost(ta, true) * ragged_pct(tb.len(), is_double) / 100 + tile_cost(tb, false) * ragged_pct(ta.len(), is_double) / 100;
             if (c < best) { best = c; a = ta; b = tb; found = true; }
         }
     }
@@ -172,7 +180,8 @@ static bool tile_plan3(long long n, bool is_double, TileLen& a, TileLen& b, Tile
             const long long L3 = rem / (long long)tb.len();
             for (const TileLen& tc : V) {
                 if ((long long)tc.len() != L3 || !tile_len_ok(tc)) continue;
-                const int cst = tile_cost(ta, true) + tile_cost(tb, true) + tile_cost(tc, false);
+                const int cst = tile_cost(ta, true) * ragged_pct(tb.len() * tc.len(), is_double) / 100 + tile_cost(tb, true) * ragged_pct(tc.len(), is_double) / 100 +
+                                tile_cost(tc, false) * ragged_pct(ta.len(), is_double) / 100;
                 if (cst < best) { best = cst; a = ta; b = tb; c = tc; }
             }
         }
