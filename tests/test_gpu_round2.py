@@ -79,7 +79,9 @@ def test_c5_strong_scaling_one_gpu_in_place(ref):
 
 # ------------------------------------------------------------------ threads sharing one setup (legacy entries)
 @pytest.mark.parametrize("N,tr,dtype", [(1024, pa.COMPLEX, np.float32), (4096, pa.REAL, np.float32),
-                                        (1024, pa.COMPLEX, np.float64)])
+                                        (1024, pa.COMPLEX, np.float64),
+                                        # beyond LDS: two tile passes through the setup's per-stream work buffers (big_mu)
+                                        (61440, pa.COMPLEX, np.float32), (28800, pa.REAL, np.float32)])
 def test_eight_host_threads_share_one_setup(ref, N, tr, dtype):
     """include/pffft/pffft.h:102-105: a PFFFT_Setup is read-only and may be used by several threads at once, each
     with its own buffers.  8 threads x 100 pffft_transform / _ordered calls (host pointers) on ONE setup, every result
