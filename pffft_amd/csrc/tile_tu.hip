@@ -16,12 +16,18 @@ static int g_tile_pf = [] { const char* e = getenv("PFFFT_HIP_TILE_PF"); return 
 template <typename T, int PP>
 static int tile_dispatch(int logl, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
                          bool out_int = false, bool in_int = false) {
+    // (64-byte runs, PP = 4, for the lengths that have 128-byte runs: development build only - PFFFT_HIP_TILE_PP=4 A/B)
+#ifdef PFFFT_HIP_VARIANTS
+    constexpr bool SHORT = true;
+#else
+    constexpr bool SHORT = PP == 8;
+#endif
     switch (logl) {
-        case 6: return tile_pass<T, 6, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
-        case 7: return tile_pass<T, 7, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
-        case 8: return tile_pass<T, 8, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
-        case 9: return tile_pass<T, 9, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
-        case 10: if constexpr (PP == 4) return tile_pass<T, 10, 4>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf);
+        case 6: if constexpr (SHORT) return tile_pass<T, 6, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf); break;
+        case 7: if constexpr (SHORT) return tile_pass<T, 7, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf); break;
+        case 8: if constexpr (SHORT) return tile_pass<T, 8, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf); break;
+        case 9: if constexpr (SHORT) return tile_pass<T, 9, PP>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf); break;
+        case 10: if constexpr (PP == 4) return tile_pass<T, 10, 4>(in, out, ntiles, D, dir, st, s, out_int, in_int, g_tile_pf); break;
         default: break;
     }
     g_last_error = "pffft_hip: tile pass length out of range";
@@ -34,7 +40,11 @@ template <typename T> static int pick_pp(int logl) {
     // 147 KiB image + W_L + three levels of 2^7 four-step twiddles = 158 KiB, ONE workgroup of 1024 threads per CU):
     // N = 2^20 0.197-0.199 against 0.206-0.239 - the denser runs do not pay for the lost overlap between workgroups.
     if (logl == 10) return 4;
+#ifdef PFFFT_HIP_VARIANTS
     if (g_tile_pp == 4 || g_tile_pp == 8) return g_tile_pp;
+#else
+    (void)g_tile_pp;
+#endif
     return 8;                                 // 128-byte runs: 64-byte runs measured 0.18 against 0.30 of the roofline
 }
 
