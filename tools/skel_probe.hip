@@ -80,6 +80,30 @@ void run(const char* name, const V4* in, V4* out, size_t bytes, int wpc) {
     printf("%-58s VB %6d T %4d WG/CU %d: %.3f of 8 TB/s\n", name, VB, T, wpc, 2.0 * nvec * VB * 10 / (ms * 1e-3) / 8e12);
 }
 
+// one wavefront per vector, static stride, `wpc` wavefronts per CU (the N = 1024 kernels: 8 / 16 KiB per wavefront): how many
+// wavefronts does the skeleton need?
+template <int VB>
+__global__ void __launch_bounds__(64) skel_wave(const V4* __restrict__ in, V4* __restrict__ out, unsigned nvec) {
+    constexpr int NCH = VB / 16 / 64;
+    for (unsigned g = blockIdx.x; g < nvec; g += gridDim.x) {
+        V4 cur[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) cur[i] = __builtin_nontemporal_load(in + (size_t)g * (VB / 16) + threadIdx.x + 64 * i);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) __builtin_nontemporal_store(cur[i], out + (size_t)g * (VB / 16) + threadIdx.x + 64 * i);
+    }
+}
+template <int VB> void run_wave(const V4* in, V4* out, size_t bytes, int wpc) {
+    const unsigned nvec = (unsigned)(bytes / VB);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < 3; ++r) skel_wave<VB><<<256 * wpc, 64>>>(in, out, nvec);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 10; ++r) skel_wave<VB><<<256 * wpc, 64>>>(in, out, nvec);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("one wavefront per %5d-byte vector, static stride, %2d wavefronts per CU: %.3f of 8 TB/s\n", VB, wpc, 2.0 * nvec * VB * 10 / (ms * 1e-3) / 8e12);
+}
+
 int main() {
     const size_t bytes = (size_t)4 << 30;
     V4 *in, *out; CK(hipMalloc((void**)&in, bytes)); CK(hipMalloc((void**)&out, bytes));
@@ -95,5 +119,7 @@ int main() {
     for (int w : {2, 4, 8}) run<32768, 256, 0>("32 KiB vectors", in, out, bytes, w);
     for (int w : {1, 2, 4}) run<131072, 512, 0>("128 KiB vectors, 512 threads", in, out, bytes, w);
     for (int w : {2, 4, 8, 16}) run<8192, 64, 0>("8 KiB vectors, one wavefront", in, out, bytes, w);
+    for (int w : {4, 6, 8, 9, 12, 16, 24, 32}) run_wave<16384>(in, out, bytes, w);
+    for (int w : {8, 12, 16, 24, 32}) run_wave<8192>(in, out, bytes, w);
     return 0;
 }
