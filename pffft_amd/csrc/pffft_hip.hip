@@ -605,7 +605,20 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
     // kernels sit at ~0.6 of the roofline on latency / issue, not on the HBM access order, and the hand-over of
     // the next chunk costs more than the ordering buys (measured: 0.63 static vs 0.54 chunked-dynamic on N = 96..800,
     // 0.64 vs 0.56 on N = 2400, 0.68 vs 0.59 on N = 4000).  Variant 42 = chunked in-order pulling (A/B).
-    const bool want_dyn = g_variant == 42;
+    // Round 3, steady state at 1 GiB per launch (tools/scan_variant.py 42 ... steady): the workgroup-phase kernels of the LARGE
+    // complex plans - one workgroup per CU, vectors of 34 KiB and more - do gain from the order: float n = 4320 .. 5760
+    // +0.01 .. +0.04, n = 8192 forward 0.68 -> 0.77 / 0.80, n = 8640 0.65 -> 0.77, n = 9216 +0.01 .. +0.03 (n = 6000 .. 8000 lose
+    // 0.01 .. 0.05 and stay static); double n = 2160 .. 4800 +0.02 .. +0.09, n = 4096 forward 0.69 -> 0.81 / 0.79.  Real
+    // transforms are neutral up to 64 KiB (their small plans lose 0.4: one atomic per 20 KiB) and stay static there.  Variant 43 =
+    // static everywhere.
+    const size_t vbytes = (size_t)sp.n * sizeof(cx<T>);
+    bool auto_dyn = false;
+    if (s->transform == PFFFT_COMPLEX && !wl)
+        auto_dyn = sizeof(T) == 8 ? vbytes >= 32 * 1024 : ((vbytes >= 34 * 1024 && vbytes <= 46 * 1024) || vbytes >= 65536);
+    else if (!wl)
+        auto_dyn = vbytes >= 65536;      // real, n = 8192 float / 4096 double and up: 0 .. +0.04
+    static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_DYN"); return e ? atoi(e) : -1; }();   // A/B: force off / on
+    const bool want_dyn = dyn_env >= 0 ? dyn_env != 0 : (g_variant == 42 || (auto_dyn && g_variant != 43));
     // groups are pulled from the counter in chunks of K (>= 64 KiB per atomic: all workgroups hit one address),
     // but never so large that a workgroup sees fewer than ~8 chunks
     const size_t gbytes = (size_t)sp.G * sp.n * sizeof(cx<T>);
@@ -942,8 +955,12 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
             // (round 3, tools/route_ab.py: float complex n = 128 0.65 -> 0.71-0.74, n = 8192 forward 0.68 -> 0.70 / 0.76; float real
             //  N = 128 0.66 / 0.66 / 0.69 / 0.69 -> 0.62 / 0.75 / 0.73 / 0.73; double complex n = 128 / 256 0.68 -> 0.75, n = 4096 forward
             //  0.70 -> 0.73 / 0.75; double real N = 128 0.39-0.50 -> 0.66-0.76, N = 256 backward 0.70 -> 0.76, N = 512 0.70-0.73 -> 0.73-0.75)
-            if (sizeof(T) == 4) stock = cplx ? (n <= 64 || n == 128 || (n == 8192 && fw)) : (n <= 64 || (n == 8192 && !fw));
-            else stock = cplx ? (n <= 256 || n >= 8192 || (n == 4096 && fw)) : (n <= 64 || (n == 128 && !fw) || n == 256 || n >= 8192 || (n == 4096 && !fw));
+            // (round 3, with the large plans pulled in order (launch_stock): float complex n = 8192 backward 0.78 / 0.72 -> 0.77 / 0.78;
+            //  double complex n = 2048 0.70-0.72 -> 0.75-0.77, n = 4096 backward 0.71 -> 0.77; double real N = 4096 0.69-0.72 ->
+            //  0.71-0.75, N = 8192 forward 0.68 / 0.69 -> 0.73 / 0.70)
+            if (sizeof(T) == 4) stock = cplx ? (n <= 64 || n == 128 || n == 8192) : (n <= 64 || (n == 8192 && !fw));
+            else stock = cplx ? (n <= 256 || n >= 2048) : (n <= 64 || (n == 128 && !fw) || n == 256 || n >= 2048);
+            (void)fw;
         }
         if (!stock) return launch_tiled<T>(s, in, out, batch, dir, ordered, st);
         return launch_stock<T>(s, in, out, batch, dir, ordered, st);
