@@ -28,8 +28,8 @@ CASES = [
     ("big16_Bi", "tile_fft_kernel<float, 8, 8, 0, 0, 1, 1", 2 * (1 << 30), "N=2^16 cplx f32, pass B storing the internal layout (round 3)"),
     ("blk_real", "big_block_kernel<float, 2>", 2 * (1 << 30), "real N=2^18 forward: pair pass + internal layout, one sweep (round 3)"),
     ("stock4000", "SKP_f_4000_c_0", 2 * (1 << 15) * 4000 * 8, "N=4000 cplx f32 forward unordered (Stockham workgroup kernel), batch 2^15"),
-    ("mr480_A", "tile_fft_kernel<float, 5, 8, 0, 1, 1, 0, 0, 15>", 2 * 1165 * 115200 * 8, "N=115200 = 480 x 240 cplx f32, pass A (L = 480) with an odd first stage (radix 15), 1 GiB of vectors (round 3)"),
-    ("mr240_B", "tile_fft_kernel<float, 4, 8, 0, 0, 1, 0, 0, 15>", 2 * 1165 * 115200 * 8, "N=115200, pass B (L = 240) with an odd first stage"),
+    ("mr480_A", "tile_fft_kernel<float, 5, 8, 0, 1, 1, 0, 0, 15,", 2 * 1165 * 115200 * 8, "N=115200 = 480 x 240 cplx f32, pass A (L = 480) with an odd first stage (radix 15), 1 GiB of vectors (round 3)"),
+    ("mr240_B", "tile_fft_kernel<float, 4, 8, 0, 0, 1, 0, 0, 15,", 2 * 1165 * 115200 * 8, "N=115200, pass B (L = 240) with an odd first stage"),
     ("big20_A", "tile_fft_kernel<float, 10, 4, 0, 1", 2 * (1 << 30), "N=2^20 cplx f32, pass A"),
     ("big20_B", "tile_fft_kernel<float, 10, 4, 0, 0", 2 * (1 << 30), "N=2^20 cplx f32, pass B"),
 ]
