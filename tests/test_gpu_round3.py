@@ -154,12 +154,12 @@ def test_fastconv_batch_more_signals_than_a_grid_dimension_and_stride_checks(ref
 
 # ------------------------------------------------------------------ sizes with factors 3 / 5 beyond LDS on the tile passes
 @pytest.mark.parametrize("dt", ["f32", "f64"])
-@pytest.mark.parametrize("N", [10240, 14400, 15360, 17280, 36864, 61440, 115200, 368640, 327680, 1024000])
+@pytest.mark.parametrize("N", [10240, 14400, 15360, 17280, 36864, 61440, 115200, 368640, 327680, 373248, 1024000])
 def test_odd_stage_tile_plans(ref, dt, N):
     """fft_tile.h with an odd first stage (tile lengths 3 / 5 / 9 / 15 x 2^b): two passes where the odd part of n splits over two
     tile lengths (10240 = 64 x 160 ... 368640 = 480 x 768; 327680 = 512 x 640), three where there is no such split and the streaming
     route would need five sweeps (1024000 = 2^13 x 125 = 80 x 160 x 80); 14400 = 120 x 120 and 17280 = 120 x 144 in float have a ragged
-    last tile of 8 sequences (a tile is 16).  Complex N and real 2N, four direction x layout combinations against oracle/_ref;
+    last tile of 8 sequences (a tile is 16), 373248 = 72 x 72 x 72 three ragged passes.  Complex N and real 2N, four direction x layout combinations against oracle/_ref;
     the streaming passes (variant 83) must agree with the tile passes to the same bar - two independent routes, one answer."""
     dtype = np.float32 if dt == "f32" else np.float64
     tdt = torch.float32 if dt == "f32" else torch.float64
