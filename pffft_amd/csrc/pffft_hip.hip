@@ -607,14 +607,14 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
     // 0.64 vs 0.56 on N = 2400, 0.68 vs 0.59 on N = 4000).  Variant 42 = chunked in-order pulling (A/B).
     // Round 3, steady state at 1 GiB per launch (tools/scan_variant.py 42 ... steady): the workgroup-phase kernels of the LARGE
     // complex plans - one workgroup per CU, vectors of 34 KiB and more - do gain from the order: float n = 4320 .. 5760
-    // +0.01 .. +0.04, n = 8192 forward 0.68 -> 0.77 / 0.80, n = 8640 0.65 -> 0.77, n = 9216 +0.01 .. +0.03 (n = 6000 .. 8000 lose
-    // 0.01 .. 0.05 and stay static); double n = 2160 .. 4800 +0.02 .. +0.09, n = 4096 forward 0.69 -> 0.81 / 0.79.  Real
+    // +0.01 .. +0.04, n = 8192 forward 0.68 -> 0.77 / 0.80, n = 8640 0.65 -> 0.77, n = 9216 +0.01 .. +0.03 (n = 6000 .. 8000: -0.01 ..
+    // -0.05 with two groups per atomic, 0 .. +0.03 with one); double n = 2160 .. 4800 +0.02 .. +0.09, n = 4096 forward 0.69 -> 0.81 / 0.79.  Real
     // transforms are neutral up to 64 KiB (their small plans lose 0.4: one atomic per 20 KiB) and stay static there.  Variant 43 =
     // static everywhere.
     const size_t vbytes = (size_t)sp.n * sizeof(cx<T>);
     bool auto_dyn = false;
     if (s->transform == PFFFT_COMPLEX && !wl)
-        auto_dyn = sizeof(T) == 8 ? vbytes >= 32 * 1024 : ((vbytes >= 34 * 1024 && vbytes <= 46 * 1024) || vbytes >= 65536);
+        auto_dyn = vbytes >= (sizeof(T) == 8 ? 32 : 34) * 1024;
     else if (!wl)
         auto_dyn = vbytes >= 65536;      // real, n = 8192 float / 4096 double and up: 0 .. +0.04
     static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_DYN"); return e ? atoi(e) : -1; }();   // A/B: force off / on
@@ -622,8 +622,12 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
     // groups are pulled from the counter in chunks of K (>= 64 KiB per atomic: all workgroups hit one address),
     // but never so large that a workgroup sees fewer than ~8 chunks
     const size_t gbytes = (size_t)sp.G * sp.n * sizeof(cx<T>);
+    // (44 000 B: ONE group per atomic from 44 KiB vectors on - measured against two: double n = 3072 .. 4000 0.71-0.75 -> 0.78-0.82,
+    //  float n = 5760 0.74 -> 0.76-0.79, n = 6000 .. 8000 0.70-0.75 -> 0.71-0.78; below that two groups keep the counter under its
+    //  ~80 M atomics/s.  PFFFT_HIP_STOCK_CHUNK=<bytes> overrides, A/B)
+    static const size_t chunk_bytes = [] { const char* e = getenv("PFFFT_HIP_STOCK_CHUNK"); return e ? (size_t)atol(e) : (size_t)44000; }();
     auto chunk_for = [&](size_t grid) -> unsigned {
-        size_t k = (65536 + gbytes - 1) / gbytes, cap = groups / (8 * grid);
+        size_t k = (chunk_bytes + gbytes - 1) / gbytes, cap = groups / (8 * grid);
         if (k > cap) k = cap;
         return (unsigned)(k < 1 ? 1 : (k > 64 ? 64 : k));
     };
