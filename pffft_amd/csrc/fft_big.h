@@ -177,7 +177,7 @@ template <typename T> struct BlkGeom {
 
 template <typename T, int MODE>
 __global__ void __launch_bounds__(BLK_WAVES * 64)
-big_block_kernel(const T* __restrict__ in, T* __restrict__ out, long long batch, long long n) {
+big_block_kernel(const T* __restrict__ in, T* __restrict__ out, long long batch, long long n, int kchunk) {
     typedef cx<T> CX;
     typedef BlkGeom<T> G;
     typedef vec4<float> U16;                                    // a 16-byte register quantum
@@ -191,7 +191,9 @@ big_block_kernel(const T* __restrict__ in, T* __restrict__ out, long long batch,
     // scalar position, inside the padded tile image, of (quarter q, part p) of this lane's position
     const int ipos = G::IBS * (lane >> 2) + (lane & 3);
     auto fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    for (long long tile = gw; tile < ntiles; tile += nw) {
+    // a wavefront takes CHUNKS of kchunk consecutive tiles (kchunk = 1: tile gw, gw + nw, ...)
+    for (long long task = gw; task * kchunk < ntiles; task += nw)
+    for (long long tile = task * kchunk; tile < (task + 1) * kchunk && tile < ntiles; ++tile) {
         const long long vec = tile / tpv, t0 = (tile - vec * tpv) << 6, t = t0 + lane;
         const bool act = t < n4;
         const CX* cin = reinterpret_cast<const CX*>(in) + vec * n;

@@ -783,14 +783,21 @@ template <typename T>
 static int launch_block(Setup* s, int mode, const T* in, T* out, size_t batch, hipStream_t st) {
     const long long n = s->n, tiles = (long long)batch * ((n / 4 + 63) / 64);
     long long grid = (tiles + BLK_WAVES - 1) / BLK_WAVES;
-    if (grid > (long long)num_cus() * 8) grid = (long long)num_cus() * 8;
+    // ONE tile per wavefront in hardware dispatch order (grid = every tile): real N = 2^18 forward unordered 0.210 -> 0.224 of the
+    // roofline for the whole transform, backward 0.200-0.204 -> 0.213-0.214, against persistent wavefronts on a static stride
+    // (PFFFT_HIP_BLOCK_CHUNK=0) or chunks of k consecutive tiles per wavefront (=k: 4 .. 32 measured, no better) - the order of
+    // the accesses again
+    static const int blk_k = [] { const char* e = getenv("PFFFT_HIP_BLOCK_CHUNK"); return e ? atoi(e) : 1; }();
+    int kchunk = 1;
+    if (blk_k > 0) { kchunk = blk_k; grid = (tiles + (long long)BLK_WAVES * kchunk - 1) / ((long long)BLK_WAVES * kchunk); if (grid > 0x7fffffffll) grid = 0x7fffffffll; }
+    else if (grid > (long long)num_cus() * 8) grid = (long long)num_cus() * 8;
     const dim3 g((unsigned)grid), b(BLK_WAVES * 64);
     switch (mode) {
-        case 0: hipLaunchKernelGGL((big_block_kernel<T, 0>), g, b, 0, st, in, out, (long long)batch, n); break;
-        case 1: hipLaunchKernelGGL((big_block_kernel<T, 1>), g, b, 0, st, in, out, (long long)batch, n); break;
-        case 2: hipLaunchKernelGGL((big_block_kernel<T, 2>), g, b, 0, st, in, out, (long long)batch, n); break;
-        case 3: hipLaunchKernelGGL((big_block_kernel<T, 3>), g, b, 0, st, in, out, (long long)batch, n); break;
-        default: hipLaunchKernelGGL((big_block_kernel<T, 4>), g, b, 0, st, in, out, (long long)batch, n); break;
+        case 0: hipLaunchKernelGGL((big_block_kernel<T, 0>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
+        case 1: hipLaunchKernelGGL((big_block_kernel<T, 1>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
+        case 2: hipLaunchKernelGGL((big_block_kernel<T, 2>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
+        case 3: hipLaunchKernelGGL((big_block_kernel<T, 3>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
+        default: hipLaunchKernelGGL((big_block_kernel<T, 4>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
     }
     PF_CHECK(hipGetLastError());
     return 0;
@@ -827,7 +834,11 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     }
     const bool real = s->transform == PFFFT_REAL;
     const bool fwd = dir == PFFFT_FORWARD;
-    const unsigned egrid = (unsigned)std::min<size_t>((batch * (size_t)s->n / 2 + 255) / 256, (size_t)num_cus() * 16);
+    // (pair pass in place: one pair per thread, every workgroup once, in dispatch order - PFFFT_HIP_PAIR_CAP=1: the persistent
+    //  grid-stride launch it replaces, A/B)
+    static const int pair_cap = [] { const char* e = getenv("PFFFT_HIP_PAIR_CAP"); return e ? atoi(e) : 0; }();
+    const size_t pair_wgs = (batch * ((size_t)s->n / 2 + 1) + 255) / 256;
+    const unsigned egrid = (unsigned)std::min<size_t>(pair_wgs, pair_cap ? (size_t)num_cus() * 16 : (size_t)0x7fffffff);
     const cx<T>* cur = (const cx<T>*)in;
     int rc;
     // variant 87: the separate sweeps (zreorder_kernel + in-place pair pass) instead of the one-sweep block kernels (A/B)
