@@ -24,6 +24,19 @@ __device__ long long pf_dbg[64];
 #define PF_STAMP(i) do { } while (0)
 #endif
 
+// block index over all signals of a call -> (signal, block in the signal).  One signal (the reference's entry) needs no division;
+// otherwise 32-bit whenever the index fits: the 64-bit division is a ~200-instruction loop, and the LDS-DMA kernel ran it once PER
+// PIECE (tools/dma_timeline.hip: 350 cycles per piece, 3 300 of the 24 000 cycles of an iteration)
+__device__ __forceinline__ void fc_split(long long ba, int nblk, int nsig, int& sig, int& blk) {
+    if (nsig == 1) { sig = 0; blk = (int)ba; return; }
+    if (ba <= 0xffffffffll) {
+        const unsigned s = (unsigned)ba / (unsigned)nblk;
+        sig = (int)s; blk = (int)((unsigned)ba - s * (unsigned)nblk);
+        return;
+    }
+    sig = (int)(ba / nblk); blk = (int)(ba - (long long)sig * nblk);
+}
+
 struct __attribute__((packed, aligned(4))) F4u { float a, b, c, d; };  // block offsets are multiples of 4 bytes only
 
 template <class C>
@@ -78,8 +91,8 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         }
         const long long blk_all = (long long)g * C::T_PER_WG + slot;
         const bool active = blk_all < nblk_all;
-        const int sig = active ? (int)(blk_all / nblk) : nsig - 1;
-        const int blk = active ? (int)(blk_all - (long long)sig * nblk) : nblk - 1;
+        int sig = nsig - 1, blk = nblk - 1;
+        if (active) fc_split(blk_all, nblk, nsig, sig, blk);
         const long off = (long)blk * step;  // first input / output sample of the block
         const int numOut = (active && blk == nblk - 1) ? lastOut : step;
         const float* xs = x + (size_t)sig * xstride;
@@ -117,6 +130,7 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         KF::template xread<0>(v, t, img); KF::xsync(); KF::template butterflies<1>(v, t, wf, twg);
         if constexpr (NS > 2) { KF::template xwrite<1>(v, t, img); KF::xsync(); KF::template xread<1>(v, t, img); KF::xsync(); KF::template butterflies<2>(v, t, wf, twg); }
         if constexpr (NS > 3) { KF::template xwrite<2>(v, t, img); KF::xsync(); KF::template xread<2>(v, t, img); KF::xsync(); KF::template butterflies<3>(v, t, wf, twg); }
+        if constexpr (NS > 4) { KF::template xwrite<3>(v, t, img); KF::xsync(); KF::template xread<3>(v, t, img); KF::xsync(); KF::template butterflies<4>(v, t, wf, twg); }
         PF_STAMP(4);
         KF::pair_regs(v, t, wf);                       // packed spectrum -> half-complex spectrum X[k]
         // ---- X[k] * H[k] (already scaled by 1/Nfft, src/pffastconv.c:97,238); bin 0 carries (DC, Nyquist),
@@ -140,6 +154,7 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         KB::template xread<0>(v, t, img); KB::xsync(); KB::template butterflies<1>(v, t, wb, twg);
         if constexpr (NS > 2) { KB::template xwrite<1>(v, t, img); KB::xsync(); KB::template xread<1>(v, t, img); KB::xsync(); KB::template butterflies<2>(v, t, wb, twg); }
         if constexpr (NS > 3) { KB::template xwrite<2>(v, t, img); KB::xsync(); KB::template xread<2>(v, t, img); KB::xsync(); KB::template butterflies<3>(v, t, wb, twg); }
+        if constexpr (NS > 4) { KB::template xwrite<3>(v, t, img); KB::xsync(); KB::template xread<3>(v, t, img); KB::xsync(); KB::template butterflies<4>(v, t, wb, twg); }
         PF_STAMP(7);
         // ---- scatter the first numOut samples (src/pffastconv.c:255) ----
         if (active) {
@@ -187,6 +202,11 @@ struct FirCfg {
     typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 8, 3, 0, 128, 2> C2048;
     typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 0, 256, 2> C4096;
     typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 0, 512, 2> C8192;
+    // round 4, calls with few blocks (the stated C4 call: 255 blocks of 8192 samples on 256 CUs): twice the threads per block,
+    // eight points per thread - two wavefronts per SIMD and half the dependent chain per thread, one more exchange per transform
+    typedef TiledCfg<float, 12, 512, 5, 4, 8, 8, 4, 8, 4, 3, 0, 512, 2, 4> C4096m;
+    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 0, 1024, 2, 4> C8192m;
+    typedef TiledCfg<float, 11, 256, 5, 4, 8, 4, 4, 8, 4, 3, 0, 256, 2, 4> C2048m;
 };
 
 }  // namespace pf

@@ -1,0 +1,278 @@
+// Overlap-save FIR block kernel with WAVE-LOCAL middle stages (round 4) - the throughput regime of pffastconv for filters
+// beyond 1024 taps (BASELINE configs[3]; reference: the block loop of pffastconv_apply, src/pffastconv.c:207-261, on
+// 16384-sample internal blocks: what a caller observes is the number of samples produced and the values of the convolution).
+//
+// Why: tools/dma_timeline.hip put numbers on fastconv_dma_kernel (fft_dma.h) - of the 22 400 cycles a block costs its CU,
+// the butterflies of both 8192-point transforms take 5 600; the SIX workgroup-wide LDS exchanges (write, barrier, read, barrier:
+// 13 barriers per block) take 11 500, and because all eight wavefronts move through every phase in lock step nothing overlaps
+// (LDS stores run at 79 B/clk and CU, MI355X_MICROARCH.md LDS table: an exchange of a 64 KiB image cannot cost less than 1 100).
+// Here n = 8 x 1024, decimation in frequency for the forward transform and its mirror image for the inverse:
+//   A    all 8 wavefronts: radix-8 butterflies over z[j + 1024 q] straight from the landed block, times W_n^(j d), into row d
+//                                                                                                        -> barrier
+//   B    wavefront d: 1024-point transform of row d (8 x 16 x 8, two WAVE-LOCAL exchanges, no workgroup barrier): Z[d + 8 k2]
+//   M    Z into row d in natural order                                                                   -> barrier
+//        every thread fetches the mirrors conj Z[n - k] of its 16 bins (row 8 - d, index 1023 - k2)        -> barrier
+//        Z'[k] = A Z[k] + B conj Z[n - k]   (real finalize, x Hf / Nfft, real preprocess folded per bin: fft_fir.h)
+//   B'   wavefront d: inverse 1024-point transform of Z'[d + 8 k2], wave-local, into row d               -> barrier
+//   A'   radix-8 across the rows, times conj W_n^(j d): z'[j + 1024 q] = the block's output samples, 16-byte stores
+// Five workgroup barriers per block instead of thirteen, and during B, B' - two thirds of the arithmetic and four of the seven
+// exchanges - every wavefront runs on its own: the LDS traffic of one overlaps the butterflies of another.
+// The block lands by LDS-DMA (fft_dma.h glds16) in ONE buffer: stage A consumes it at the top of the iteration, the next block's
+// pieces are issued right behind A's barrier and have the rest of the iteration to land.
+#pragma once
+#include "fft_dma.h"
+
+namespace pf {
+
+struct SplitFir {
+    typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 0, 512, 1> Sub;   // the wave-local 1024-point transform
+    static constexpr int n = 8192, M = 1024, WAVES = 8, WG = 512;
+    static constexpr int ROW = (Sub::IMG_NAT > Sub::IMG_TRN ? Sub::IMG_NAT : Sub::IMG_TRN) + 8;   // points per wavefront region
+    static constexpr int LAND_BYTES = n * 8;                                   // the landed block: 16384 floats, linear
+    static constexpr size_t LDS_BYTES = (size_t)LAND_BYTES + (size_t)WAVES * ROW * 8 + 16;
+    static constexpr int PPW = (LAND_BYTES / 1024) / WAVES;                    // 1 KiB pieces per wavefront
+    static_assert((ROW * 8) % 16 == 0, "rows must keep 16-byte alignment");
+};
+
+__global__ void __launch_bounds__(SplitFir::WG, 2)
+fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const cx<float>* __restrict__ Hc,
+                      int nblk, int step, int inputLen, int lastOut,
+                      const cx<float>* __restrict__ twn,      // W_n^j, j < n
+                      const cx<float>* __restrict__ tw1024,   // W_1024^j
+                      const cx<float>* __restrict__ twr,      // W_N^k, k <= n/2, N = 2n
+                      unsigned* ctr, int nsig, size_t xstride, size_t ystride) {
+    typedef float T;
+    typedef cx<T> CX;
+    typedef SplitFir S;
+    typedef Tiled<S::Sub, FWD, 0> KF;
+    typedef Tiled<S::Sub, BWD, 0> KB;
+    constexpr int n = S::n, ROW = S::ROW;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const chunk16* land16 = reinterpret_cast<const chunk16*>(smem_raw);
+    CX* rows = reinterpret_cast<CX*>(smem_raw + S::LAND_BYTES);
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + S::LAND_BYTES + (size_t)S::WAVES * ROW * 8);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    CX* row = rows + (size_t)wave * ROW;
+
+    // ---- per-thread constants
+    typename KF::Tw wf;
+    typename KB::Tw wb;
+    KF::load_tw(wf, lane, tw1024, nullptr);
+    KB::load_tw(wb, lane, tw1024, nullptr);
+    const CX wa0 = twn[2 * tid], wa1 = twn[2 * tid + 1];   // W_n^j of this thread's two stage-A butterflies, j = 2 tid + u
+    // folded coefficients of this thread's 16 bins k = wave + 8 k2, k2 = 2 lane + u + 128 d (slot u * 8 + d): derivation in
+    // fft_fir.h (fastconv_part_kernel); bin 0 = (DC, Nyquist) and bin n/2 are their own mirrors
+    CX cA[16], cB[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = wave + 8 * (2 * lane + (i >> 3) + 128 * (i & 7));
+        const int km = (n - k) & (n - 1);
+        const CX w = k <= n / 2 ? twr[k] : conj(twr[n - k]) * (T)-1;
+        const CX Hk = Hc[k], Hm = Hc[km];
+        const CX iw = mk<T>(-w.y, w.x), iwc = mk<T>(w.y, w.x);   // i w, i conj(w)
+        const CX al = mk<T>(0.5f * (1.f - iw.x), -0.5f * iw.y), be = mk<T>(0.5f * (1.f + iw.x), 0.5f * iw.y);
+        const CX ga = mk<T>(1.f + iwc.x, iwc.y), de = mk<T>(1.f - iwc.x, -iwc.y);
+        const CX gH = cmul(ga, Hk), dHm = cmul(de, conj(Hm));
+        CX a = cmul(gH, al) + cmul(dHm, be), b = cmul(gH, be) + cmul(dHm, al);
+        if (k == 0) { a = mk<T>(Hk.x + Hk.y, 0.f); b = mk<T>(0.f, Hk.x - Hk.y); }
+        if (k == n / 2) { a = mk<T>(2.f * Hk.x, -2.f * Hk.y); b = mk<T>(0.f, 0.f); }
+        cA[i] = a; cB[i] = b;
+    }
+
+    const bool dyn = ctr != nullptr;
+    unsigned pend = 0;
+    unsigned g = blockIdx.x;
+    if (dyn && tid == 0) {
+        s_next[0] = atomicAdd(&ctr[0], 1u);
+        pend = atomicAdd(&ctr[0], 1u);
+    }
+    __syncthreads();
+    if (dyn) g = s_next[0];
+    const long long nblk_all = (long long)nblk * nsig;
+    // copies that would run past the signal are clamped to its last 16 bytes (their samples are replaced by the zero padding of
+    // src/pffastconv.c:231-233 when the operands are picked up)
+    auto issue = [&](unsigned grp) {
+        long long ba = (long long)grp;
+        if (ba >= nblk_all) ba = nblk_all - 1;
+        int sig, blk;
+        fc_split(ba, nblk, nsig, sig, blk);
+        const float* xs = x + (size_t)sig * xstride;
+        const long base = (long)blk * step + lane * 4;
+#pragma unroll
+        for (int i = 0; i < S::PPW; ++i) {
+            const int pv = wave + S::WAVES * i;
+            long e = base + pv * 256;                        // first of this lane's 4 floats
+            if (e > (long)inputLen - 4) e = inputLen >= 4 ? (long)inputLen - 4 : 0;
+            glds16(xs + e, lds0 + (unsigned)(pv * 1024));
+        }
+    };
+    issue(g);
+    for (unsigned it = 0; (long long)g < nblk_all; ++it) {
+        if (dyn && tid == 0) {
+            s_next[(it + 1) & 1] = pend;
+            pend = atomicAdd(&ctr[0], 1u);
+        }
+        PF_DSTAMP(0);
+        wait_vmcnt<0>();
+        wg_sync_raw();                                       // (1) the block has landed; the rows are free (A' of the block before is done)
+        PF_DSTAMP(1);
+        const unsigned gn = dyn ? s_next[(it + 1) & 1] : g + gridDim.x;
+        int sig, blk;
+        fc_split((long long)g, nblk, nsig, sig, blk);
+        const long off = (long)blk * step;
+        const int numOut = (blk == nblk - 1) ? lastOut : step;
+        float* ys = y + (size_t)sig * ystride;
+        // ================= A: radix 8 across the wavefronts, operands z[2 tid + u + 1024 q] = chunk tid + 512 q of the landed block
+        CX a0[8], a1[8];
+        {
+            const long avail = (long)inputLen - off;         // samples of this block that exist
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = tid + 512 * q;
+                const int e0 = 4 * c;
+                const chunk16 cc = land16[c];
+                float f0 = cc.x, f1 = cc.y, f2 = cc.z, f3 = cc.w;
+                if (e0 + 3 >= avail) {     // clamped copy (issue): element k is sample avail - 4 + k of the block
+                    const long sh = (long)e0 - (avail - 4);      // >= 1
+                    f0 = sh == 1 ? cc.y : sh == 2 ? cc.z : sh == 3 ? cc.w : 0.f;
+                    f1 = sh == 1 ? cc.z : sh == 2 ? cc.w : 0.f;
+                    f2 = sh == 1 ? cc.w : 0.f;
+                    f3 = 0.f;
+                }
+                a0[q] = mk<T>(f0, f1);
+                a1[q] = mk<T>(f2, f3);
+            }
+        }
+        dft8<FWD>(a0);
+        dft8<FWD>(a1);
+        // W_n^(j d), d = 1 .. 7, from W_n^j by products at most three deep (recomputed in A': 28 registers would stay pinned)
+        auto powers = [&](CX (&p0)[8], CX (&p1)[8]) {
+            p0[1] = wa0; p1[1] = wa1;
+            asm volatile("" : "+v"(p0[1].x), "+v"(p0[1].y), "+v"(p1[1].x), "+v"(p1[1].y));
+            p0[2] = cmul(p0[1], p0[1]); p0[3] = cmul(p0[2], p0[1]); p0[4] = cmul(p0[2], p0[2]); p0[5] = cmul(p0[4], p0[1]);
+            p0[6] = cmul(p0[3], p0[3]); p0[7] = cmul(p0[4], p0[3]);
+            p1[2] = cmul(p1[1], p1[1]); p1[3] = cmul(p1[2], p1[1]); p1[4] = cmul(p1[2], p1[2]); p1[5] = cmul(p1[4], p1[1]);
+            p1[6] = cmul(p1[3], p1[3]); p1[7] = cmul(p1[4], p1[3]);
+        };
+        {
+            CX p0[8], p1[8];
+            powers(p0, p1);
+#pragma unroll
+            for (int d = 1; d < 8; ++d) { a0[d] = cmul(a0[d], p0[d]); a1[d] = cmul(a1[d], p1[d]); }
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) lds_st2(rows + (size_t)d * ROW + 2 * tid, a0[d], a1[d]);
+        PF_DSTAMP(2);
+        wg_sync_raw();                                       // (2) rows complete; the landing buffer is free
+        PF_DSTAMP(3);
+        issue(gn);                                           // the next block has the rest of the iteration to land
+        PF_DSTAMP(4);
+        // ================= B: wavefront `wave` transforms row `wave`, wave-local
+        CX v[16];
+        {
+            const chunk16* r16 = reinterpret_cast<const chunk16*>(row);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const chunk16 c = r16[lane + 64 * q];        // points 2 lane + 128 q, + 1: operands q of butterflies 2 lane, 2 lane + 1
+                v[q] = mk<T>(c.x, c.y);
+                v[8 + q] = mk<T>(c.z, c.w);
+            }
+        }
+        KF::xsync();
+        KF::template butterflies<0>(v, lane, wf, tw1024);
+        KF::template xwrite<0>(v, lane, row); KF::xsync();
+        KF::template xread<0>(v, lane, row); KF::xsync();
+        KF::template butterflies<1>(v, lane, wf, tw1024);
+        KF::template xwrite<1>(v, lane, row); KF::xsync();
+        KF::template xread<1>(v, lane, row); KF::xsync();
+        KF::template butterflies<2>(v, lane, wf, tw1024);
+        PF_DSTAMP(5);
+        // ================= M: Z[wave + 8 k2], k2 = 2 lane + u + 128 d -> row[k2]; mirrors conj Z[n - k] from row 8 - wave
+#pragma unroll
+        for (int d = 0; d < 8; ++d) lds_st2(row + 2 * lane + 128 * d, v[d], v[8 + d]);
+        wg_sync_raw();                                       // (3) the whole packed spectrum sits in the rows
+        PF_DSTAMP(6);
+        CX zm[16];
+        if (wave != 0) {
+            // n - k = (8 - wave) + 8 (1023 - k2): the unit at point 1022 - 2 lane - 128 d holds the mirrors of u = 1, u = 0 in this order
+            const CX* mrow = rows + (size_t)(8 - wave) * ROW;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const vec4<float> m = lds_ld2(mrow + 1022 - 2 * lane - 128 * d);
+                zm[8 + d] = mk<T>(m.x, m.y);
+                zm[d] = mk<T>(m.z, m.w);
+            }
+        } else {
+            // wave 0: n - 8 k2 = 8 (1024 - k2): the same row, index (1024 - k2) mod 1024
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                zm[d] = lds_ld(row + ((1024 - 2 * lane - 128 * d) & 1023));
+                zm[8 + d] = lds_ld(row + (1023 - 2 * lane - 128 * d));
+            }
+        }
+        wg_sync_raw();                                       // (3') every mirror is read: the rows are exchange buffers again
+        PF_DSTAMP(7);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const CX a = cA[i], bq = cB[i], zz = v[i], m = zm[i];
+            v[i] = mk<T>(fma_(a.x, zz.x, fma_(-a.y, zz.y, fma_(bq.x, m.x, bq.y * m.y))),
+                         fma_(a.x, zz.y, fma_(a.y, zz.x, fma_(bq.y, m.x, -(bq.x * m.y)))));
+        }
+        // ================= B': inverse transform of Z'[wave + 8 k2] (first-stage operands are in place), wave-local
+        KB::template butterflies<0>(v, lane, wb, tw1024);
+        KB::template xwrite<0>(v, lane, row); KB::xsync();
+        KB::template xread<0>(v, lane, row); KB::xsync();
+        KB::template butterflies<1>(v, lane, wb, tw1024);
+        KB::template xwrite<1>(v, lane, row); KB::xsync();
+        KB::template xread<1>(v, lane, row); KB::xsync();
+        KB::template butterflies<2>(v, lane, wb, tw1024);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) lds_st2(row + 2 * lane + 128 * d, v[d], v[8 + d]);   // b_wave[j], j = 2 lane + u + 128 d
+        PF_DSTAMP(8);
+        wg_sync_raw();                                       // (4)
+        PF_DSTAMP(9);
+        // ================= A': z'[j + 1024 q] = sum_d W_8^(-q d) conj(W_n^(j d)) b_d[j], j = 2 tid + u
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const vec4<float> c = lds_ld2(rows + (size_t)d * ROW + 2 * tid);
+            a0[d] = mk<T>(c.x, c.y);
+            a1[d] = mk<T>(c.z, c.w);
+        }
+        {
+            CX p0[8], p1[8];
+            powers(p0, p1);
+#pragma unroll
+            for (int d = 1; d < 8; ++d) { a0[d] = cmulc(a0[d], p0[d]); a1[d] = cmulc(a1[d], p1[d]); }
+        }
+        dft8<BWD>(a0);
+        dft8<BWD>(a1);
+        // ---- the first numOut samples (src/pffastconv.c:255)
+        {
+            float* dst = ys + off;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e0 = 4 * (tid + 512 * q);
+                if (e0 + 3 < numOut) {
+                    F4u q4; q4.a = a0[q].x; q4.b = a0[q].y; q4.c = a1[q].x; q4.d = a1[q].y;
+                    *reinterpret_cast<F4u*>(dst + e0) = q4;
+                } else {
+                    if (e0 < numOut) dst[e0] = a0[q].x;
+                    if (e0 + 1 < numOut) dst[e0 + 1] = a0[q].y;
+                    if (e0 + 2 < numOut) dst[e0 + 2] = a1[q].x;
+                }
+            }
+        }
+        PF_DSTAMP(40);
+        g = gn;
+    }
+    wait_vmcnt<0>();
+    if (dyn && tid == 0) {
+        __threadfence();
+        unsigned d = atomicAdd(&ctr[1], 1u);
+        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+}
+
+}  // namespace pf

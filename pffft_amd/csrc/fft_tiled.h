@@ -31,8 +31,9 @@ namespace pf {
 
 // TWMODE: 0 = every twiddle in registers, 1 = W_n^j table in LDS, 2 = global table (L2),
 //         3 = one base twiddle per butterfly in registers, its powers w^2..w^(R-1) recomputed (<= 4 products deep)
+//         4 = the same base twiddles from a compact LDS table (TiledCfg::ctw_off), nothing resident in registers
 template <typename T, int LOGN_, int TPT_, int NS_, int R0_, int R1_, int R2_, int R3_, int PAD0_, int PADN_,
-          int TWMODE_, int PREFETCH_, int WGT_ = 512, int OCC_ = 2>
+          int TWMODE_, int PREFETCH_, int WGT_ = 512, int OCC_ = 2, int R4_ = 1>
 struct TiledCfg {
     typedef T real_t;
     static constexpr int LOGN = LOGN_, n = 1 << LOGN_, TPT = TPT_, E = n / TPT_, NS = NS_;
@@ -40,7 +41,7 @@ struct TiledCfg {
     static constexpr int CH = 16 / (int)sizeof(T);         // scalars per 16-byte chunk: 4 float, 2 double
     static constexpr int NCH = E * 2 / CH;                  // 16-byte chunks per thread
     static constexpr int PAD0 = PAD0_, PADN = PADN_, TWMODE = TWMODE_, PREFETCH = PREFETCH_, OCC = OCC_;
-    __host__ __device__ static constexpr int rad(int s) { return s == 0 ? R0_ : s == 1 ? R1_ : s == 2 ? R2_ : R3_; }
+    __host__ __device__ static constexpr int rad(int s) { return s == 0 ? R0_ : s == 1 ? R1_ : s == 2 ? R2_ : s == 3 ? R3_ : R4_; }
     __host__ __device__ static constexpr int ns(int s) {
         int p = 1;
         for (int i = 0; i < s; ++i) p *= rad(i);
@@ -52,7 +53,16 @@ struct TiledCfg {
         for (int i = 1; i < s; ++i) o += (E / rad(i)) * (TWMODE_ == 3 ? 1 : rad(i) - 1);
         return o;
     }
-    static constexpr int TW_COUNT = tw_off(NS_);
+    static constexpr int TW_COUNT = TWMODE_ == 4 ? 0 : tw_off(NS_);
+    // TWMODE 4: one base twiddle per butterfly from a COMPACT table in LDS - W_{Ns R}^k, k < Ns, of every stage s >= 1, one
+    // after the other (n = 8192 as 8 x 8 x 16 x 8: 8 + 64 + 1024 entries = 8.6 KiB against 64 KiB for the whole W_n^j) -, its
+    // powers recomputed as in mode 3: no twiddle lives in a register across the persistent loop
+    __host__ __device__ static constexpr int ctw_off(int s) {
+        int o = 0;
+        for (int i = 1; i < s; ++i) o += ns(i);
+        return o;
+    }
+    static constexpr int CTW_COUNT = ctw_off(NS_);
     static constexpr int IMG_NAT = n + PADN_ * (n / 64);
     static constexpr int IMG_TRN = R0_ * (n / R0_ + PAD0_);
     // image of the pffft-internal layout: blocks of 32 scalars padded to IBS scalars (bank-conflict-free
@@ -63,7 +73,8 @@ struct TiledCfg {
     static constexpr int IMG = (IMG_A > IMG_INT ? IMG_A : IMG_INT) + 8;
     static constexpr int WG_THREADS = TPT > WGT_ ? TPT : WGT_;
     static constexpr int T_PER_WG = WG_THREADS / TPT;
-    static constexpr size_t TABLE_BYTES = TWMODE_ == 1 ? (size_t)n * 2 * sizeof(T) : 0;
+    static constexpr size_t TABLE_BYTES = TWMODE_ == 1 ? (size_t)n * 2 * sizeof(T)
+                                          : TWMODE_ == 4 ? ((size_t)CTW_COUNT * 2 * sizeof(T) + 15) / 16 * 16 : 0;
     static constexpr size_t LDS_BYTES = TABLE_BYTES + (size_t)T_PER_WG * IMG * 2 * sizeof(T) + 16;
 };
 
@@ -173,16 +184,17 @@ struct Tiled {
         if constexpr (REGTW) {
             load_tw_stage<1>(w, t, twg);
         }
-        if constexpr (REAL) {
-            // W_N^k of the RS mirror pairs this thread owns (pair_regs): t != 0: k = t + d n/RS;
-            // thread 0: butterfly 0 pairs d = 1..RS/2-1 at k = d n/RS, butterfly 1 pairs d = 0..RS/2-1 at
-            // k = (2d+1) n/(2 RS).  The table holds k <= n/2; W_N^k = -conj(W_N^(n-k)) beyond.
+        if constexpr (REAL) load_pair_tw(w.p, t, twrg);
+    }
+    // W_N^k of the RS mirror pairs this thread owns (pair_regs): t != 0: k = t + d n/RS;
+    // thread 0: butterfly 0 pairs d = 1..RS/2-1 at k = d n/RS, butterfly 1 pairs d = 0..RS/2-1 at
+    // k = (2d+1) n/(2 RS).  The table holds k <= n/2; W_N^k = -conj(W_N^(n-k)) beyond.
+    static __device__ __forceinline__ void load_pair_tw(CX (&p)[NPT], int t, const CX* __restrict__ twrg) {
 #pragma unroll
-            for (int d = 0; d < RS; ++d) {
-                int k = t + d * (n / RS);
-                if (t == 0) k = d < RS / 2 ? d * (n / RS) : (2 * (d - RS / 2) + 1) * (n / (2 * RS));
-                w.p[d] = k <= n / 2 ? twrg[k] : conj(twrg[n - k]) * (T)-1;
-            }
+        for (int d = 0; d < RS; ++d) {
+            int k = t + d * (n / RS);
+            if (t == 0) k = d < RS / 2 ? d * (n / RS) : (2 * (d - RS / 2) + 1) * (n / (2 * RS));
+            p[d] = k <= n / 2 ? twrg[k] : conj(twrg[n - k]) * (T)-1;
         }
     }
     template <int S> static __device__ __forceinline__ CX stage_tw(const Tw& w, int t, int u, int q, const CX* tab) {
@@ -203,9 +215,10 @@ struct Tiled {
             CX a[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) a[q] = v[u * R + q];
-            if constexpr (S > 0 && C::TWMODE == 3) {
+            if constexpr (S > 0 && (C::TWMODE == 3 || C::TWMODE == 4)) {
                 CX p[R < 16 ? R : 16];  // p[q] = w^q, every power at most 4 products away from the table value
-                p[1] = w.r[C::tw_off(S) + u];
+                if constexpr (C::TWMODE == 3) p[1] = w.r[C::tw_off(S) + u];
+                else p[1] = lds_ld(tab + C::ctw_off(S) + (jm<S>(t, u) & (SI::Ns - 1)));
                 // opaque per iteration: otherwise the powers are hoisted out of the persistent loop and
                 // pinned in registers again (which is TWMODE 0 and spills)
                 asm volatile("" : "+v"(p[1].x), "+v"(p[1].y));
@@ -364,23 +377,24 @@ struct Tiled {
     // Branch-free: every thread evaluates the regular pairing (bin of butterfly 0 with its mirror in
     // butterfly 1) and the pairing of thread 0 (both of its butterflies are self-mirrored), then selects.
     static __device__ __forceinline__ CX sel(bool c, CX a, CX b) { return mk<T>(c ? a.x : b.x, c ? a.y : b.y); }
-    static __device__ __forceinline__ void pair_regs(CX (&v)[E], int t, const Tw& w) {
+    static __device__ __forceinline__ void pair_regs(CX (&v)[E], int t, const Tw& w) { pair_regs_p(v, t, w.p); }
+    static __device__ __forceinline__ void pair_regs_p(CX (&v)[E], int t, const CX (&wp)[NPT]) {
         CX r0[2 * RS], r1[2 * RS];
 #pragma unroll
         for (int d = 0; d < RS; ++d) {
-            const Pair r = pair1(v[d], v[RS + (RS - 1 - d)], w.p[d]);
+            const Pair r = pair1(v[d], v[RS + (RS - 1 - d)], wp[d]);
             r0[d] = r.a; r0[RS + (RS - 1 - d)] = r.b;
         }
         r1[0] = mk<T>(v[0].x + v[0].y, v[0].x - v[0].y);  // bin 0 <-> (DC, Nyquist), the same map in both directions
 #pragma unroll
         for (int d = 1; d < RS / 2; ++d) {
-            const Pair r = pair1(v[d], v[RS - d], w.p[d]);
+            const Pair r = pair1(v[d], v[RS - d], wp[d]);
             r1[d] = r.a; r1[RS - d] = r.b;
         }
         r1[RS / 2] = DIR == FWD ? conj(v[RS / 2]) : mk<T>((T)2 * v[RS / 2].x, (T)-2 * v[RS / 2].y);  // k = n/2
 #pragma unroll
         for (int d = 0; d < RS / 2; ++d) {
-            const Pair r = pair1(v[RS + d], v[RS + (RS - 1 - d)], w.p[RS / 2 + d]);
+            const Pair r = pair1(v[RS + d], v[RS + (RS - 1 - d)], wp[RS / 2 + d]);
             r1[RS + d] = r.a; r1[RS + (RS - 1 - d)] = r.b;
         }
         const bool first = (t == 0);
@@ -388,6 +402,16 @@ struct Tiled {
         for (int i = 0; i < 2 * RS; ++i) v[i] = sel(first, r1[i], r0[i]);
     }
 };
+
+// compact base-twiddle table of TWMODE 4 (entry ctw_off(S) + k = W_{Ns R}^k = W_n^(k n / (Ns R))), filled by the whole workgroup
+template <class C, int S = 1>
+__device__ __forceinline__ void fill_ctw(cx<typename C::real_t>* tab, const cx<typename C::real_t>* __restrict__ twg, int tid, int nthreads) {
+    if constexpr (S < C::NS) {
+        constexpr int Ns = C::ns(S), step = C::n / (Ns * C::rad(S));
+        for (int k = tid; k < Ns; k += nthreads) tab[C::ctw_off(S) + k] = twg[k * step];
+        fill_ctw<C, S + 1>(tab, twg, tid, nthreads);
+    }
+}
 
 #ifdef PF_TILED_DEBUG
 __device__ long long pf_tdbg[64];
@@ -398,7 +422,7 @@ __device__ long long pf_tdbg[64];
 
 // flags: bit0 = input in internal layout, bit1 = output in internal layout
 template <class C, int DIR, int REAL>
-__global__ void __launch_bounds__(C::WG_THREADS, C::WG_THREADS >= 1024 ? 4 : C::OCC)
+__global__ void __launch_bounds__(C::WG_THREADS, C::WG_THREADS >= 1024 ? (C::OCC > 4 ? C::OCC : 4) : C::OCC)
 fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned batch, int flags,
                  const cx<typename C::real_t>* __restrict__ twg, const cx<typename C::real_t>* __restrict__ twrg,
                  unsigned* ctr) {
@@ -427,6 +451,10 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
     const CX* twt = twg;
     if constexpr (C::TWMODE == 1) {
         for (int i = threadIdx.x; i < n; i += C::WG_THREADS) tab[i] = twg[i];
+        twt = tab;
+    }
+    if constexpr (C::TWMODE == 4) {
+        fill_ctw<C>(tab, twg, threadIdx.x, C::WG_THREADS);
         twt = tab;
     }
     // ctr == nullptr: static assignment (the grid covers every group exactly once): small batches are
@@ -538,6 +566,7 @@ fft_tiled_kernel(const typename C::real_t* in, typename C::real_t* out, unsigned
         if constexpr (C::NS > 1) { K::template xread<0>(v, t, img); K::xsync(); PF_TSTAMP(4); K::template butterflies<1>(v, t, w, twt); PF_TSTAMP(5); }
         if constexpr (C::NS > 2) { K::template xwrite<1>(v, t, img); K::xsync(); PF_TSTAMP(6); K::template xread<1>(v, t, img); K::xsync(); PF_TSTAMP(7); K::template butterflies<2>(v, t, w, twt); PF_TSTAMP(8); }
         if constexpr (C::NS > 3) { K::template xwrite<2>(v, t, img); K::xsync(); PF_TSTAMP(9); K::template xread<2>(v, t, img); K::xsync(); PF_TSTAMP(10); K::template butterflies<3>(v, t, w, twt); PF_TSTAMP(11); }
+        if constexpr (C::NS > 4) { K::template xwrite<3>(v, t, img); K::xsync(); K::template xread<3>(v, t, img); K::xsync(); K::template butterflies<4>(v, t, w, twt); }
 
         // ------------------------------------------------------------------ output
         if (plain_out) {
@@ -714,6 +743,19 @@ struct TiledAltF32b {
     typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 2, 0, 3, 0, 512, 2> T16384np;
     typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 4, 8, 3, 1, 512, 2> T16384b;   // the paddings of the 1024-thread one
 };
+// Multi-wave skeleton (round 4): 1024 threads own one n = 8192 vector, EIGHT points per thread, five stages 4 x 8 x 8 x 8 x 4
+// (first and last radix 4 keep two adjacent butterflies per thread = 16-byte global accesses in lane order; tools/skel_probe.hip
+// puts a 64 KiB vector per 1024 threads at 0.82-0.84 of the roofline as a bare copy against 0.73-0.77 per 256 / 512 threads).
+// Paddings from tools/tiled_lds_search.py (3584 LDS cycles per transform against 3072 conflict-free).
+struct TiledMwF32 {
+    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 1, 1024, 4, 4> M8192;      // one workgroup per CU, register prefetch
+    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 0, 1024, 4, 4> M8192np;    // ... without
+    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 0, 1024, 8, 4> M8192x2;    // two workgroups per CU within 64 VGPRs
+    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 2, 0, 1024, 8, 4> M8192x2g;   // ... twiddles from the global table (L2)
+    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 1, 1024, 8, 4> M8192x2p;   // ... with the register prefetch
+    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 4, 1, 1024, 4, 4> M8192l;     // one workgroup per CU, LDS table, prefetch
+};
+
 template <> struct TiledPick<double> {
     typedef TiledCfg<double, 4, 2, 2, 4, 4, 1, 1, 1, 0, 0, 0, 256> C16;
     typedef TiledCfg<double, 5, 4, 3, 4, 2, 4, 1, 1, 0, 0, 0, 256> C32;

@@ -1,0 +1,57 @@
+// libpffft_hip.so, translation unit of the multi-wave register-tiled configurations (fft_tiled.h TiledMwF32: 1024 threads per
+// vector, eight points per thread): instantiations + launcher, compiled on their own so that they can be iterated on in seconds.
+#include <hip/hip_runtime.h>
+
+#include "../../include/pffft_hip.h"
+#include "pf_host.h"
+#include "fft_tiled.h"
+
+namespace pf {
+
+template <typename T, class C>
+static int mw_launch(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    const bool real = s->transform == PFFFT_REAL, fwd = dir == PFFFT_FORWARD;
+    void (*k)(const T*, T*, unsigned, int, const cx<T>*, const cx<T>*, unsigned*);
+    if (fwd) k = real ? fft_tiled_kernel<C, FWD, 1> : fft_tiled_kernel<C, FWD, 0>;
+    else k = real ? fft_tiled_kernel<C, BWD, 1> : fft_tiled_kernel<C, BWD, 0>;
+    int rc = allow_big_lds(k, C::LDS_BYTES);
+    if (rc) return rc;
+    static int per_cu_cache[4] = {0, 0, 0, 0};           // constant per (kernel, LDS bytes): queried once
+    int& per_cu = per_cu_cache[(fwd ? 0 : 2) + (real ? 1 : 0)];
+    if (!per_cu) {
+        PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, C::LDS_BYTES));
+        if (per_cu < 1) per_cu = 1;
+    }
+    const size_t groups = (batch + C::T_PER_WG - 1) / C::T_PER_WG;
+    size_t grid = (size_t)num_cus() * per_cu;
+    if (grid > groups) grid = groups;
+    const int flags = ((!fwd && !ordered) ? 1 : 0) | ((fwd && !ordered) ? 2 : 0);
+    unsigned* ctr = groups <= grid ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), C::LDS_BYTES, st, in, out, (unsigned)batch, flags,
+                       (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+// which: 0 = the adopted configuration; 1 .. = alternatives (development build / A/B).  -1: no such configuration for this size
+int launch_tiled_mw(Setup* s, const void* in, void* out, size_t batch, int dir, int ordered, hipStream_t st, int which) {
+    if (s->is_double) return -1;
+    const float* i = (const float*)in;
+    float* o = (float*)out;
+    if (s->n == 8192) {
+        switch (which) {
+            case 0: return mw_launch<float, TiledMwF32::M8192>(s, i, o, batch, dir, ordered, st);
+#ifndef PFFFT_HIP_NO_MW_ALTERNATIVES
+            case 1: return mw_launch<float, TiledMwF32::M8192np>(s, i, o, batch, dir, ordered, st);
+            case 2: return mw_launch<float, TiledMwF32::M8192x2>(s, i, o, batch, dir, ordered, st);
+            case 3: return mw_launch<float, TiledMwF32::M8192x2g>(s, i, o, batch, dir, ordered, st);
+            case 4: return mw_launch<float, TiledMwF32::M8192x2p>(s, i, o, batch, dir, ordered, st);
+            case 7: return mw_launch<float, TiledMwF32::M8192l>(s, i, o, batch, dir, ordered, st);
+#endif
+            default: return -1;
+        }
+    }
+    return -1;
+}
+
+}  // namespace pf

@@ -90,6 +90,10 @@ struct FcBatch { int nsig; size_t xstride, ystride; };   // signals of one pffas
 int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
                    hipStream_t st, const FcBatch& fb);
 
+// mw_tu.hip: the multi-wave register-tiled configurations (fft_tiled.h TiledMwF32: 1024 threads per vector); -1 when the size
+// has none.  which: 0 = adopted, 1 .. = measured alternatives
+int launch_tiled_mw(Setup* s, const void* in, void* out, size_t batch, int dir, int ordered, hipStream_t st, int which);
+
 // tile_tu.hip: power-of-two sizes beyond LDS in two / three passes (fft_tile.h); canonical complex, in -> out through `work`
 // (same size, distinct from both; in may equal out).  -1 when the size has no tile plan.  layout 1 (forward only): the
 // spectrum is stored in the pffft-internal layout by the last pass; layout 2 (backward only): it is read from that layout

@@ -435,7 +435,8 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
             // The LDS-DMA staged block kernel (fft_dma.h) where it measured faster (tools/dma_ab.py, fraction of the 8 B / sample
             // roofline, register-staged -> DMA): Nfft 16384: 2^26 samples 0.190 -> 0.209, 256 signals x 2^20 0.204 -> 0.246;
             // Nfft 8192: a tie (0.22-0.29 both).  Variant 97 / PFFASTCONV_HIP_DMA=1 force it, =0 switches it off (A/B).
-            const bool use_dma = g_variant == 97 || (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && nbig == 16384)));
+            const bool use_dma = g_variant == 97 || (g_variant >= 110 && g_variant < 120) ||
+                                 (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && nbig == 16384)));
             if (use_dma) {
                 rc = launch_fir_dma(s->st_big, s->d_Hc_big, d_x, d_y, bblk, bstep, inputLen, blast, st, fb);
                 if (rc != -1) return rc;
@@ -481,9 +482,15 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         switch (Nfft / 2) {
             case 512: return fc_launch_fused<FirCfg::C512>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            case 2048: return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            case 4096: return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            case 8192: return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            case 2048:
+                if (g_variant == 115) return fc_launch_fused<FirCfg::C2048m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+                return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            case 4096:
+                if (g_variant == 115) return fc_launch_fused<FirCfg::C4096m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+                return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            case 8192:
+                if (g_variant == 115) return fc_launch_fused<FirCfg::C8192m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+                return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             default: break;
         }
     }

@@ -953,6 +953,10 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         if (s->kernel == K_C1024_F32 && g_variant != 50 && batch < (1ull << 32))
             return launch_c1024(s, in, out, batch, dir, ordered, st);
     }
+    if (s->kernel == K_TILED && g_variant >= 100 && g_variant < 110 && batch < (1ull << 32)) {   // A/B: multi-wave configurations
+        const int rc2 = launch_tiled_mw(s, in, out, batch, dir, ordered, st, g_variant - 100);
+        if (rc2 != -1) return rc2;
+    }
     if (s->kernel == K_TILED && g_variant != 50 && batch < (1ull << 32)) {
         // power-of-two sizes where the Stockham kernel instantiated on its compile-time plan measured faster than
         // the register-tiled one (float, 1 GiB of vectors, tools/stock_ab.py; variant 54 = always tiled):
