@@ -27,29 +27,6 @@ static int fir_dma_cfg(Setup* ps, const float* d_Hc, const float* d_x, float* d_
     return 0;
 }
 
-template <class C>
-static int fir_dma1_cfg(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen,
-                        int lastOut, hipStream_t st, const FcBatch& fb) {
-    auto k = fastconv_dma1_kernel<C>;
-    const size_t lds = Dma1Geom<C>::LDS_BYTES;
-    int rc = allow_big_lds(k, lds);
-    if (rc) return rc;
-    static int per_cu = 0;
-    if (!per_cu) {
-        PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, lds));
-        if (per_cu < 1) per_cu = 1;
-    }
-    const size_t groups = (size_t)nblk * fb.nsig;
-    size_t grid = (size_t)num_cus() * per_cu;
-    if (grid > groups) grid = groups;
-    unsigned* ctr = groups <= grid ? nullptr : ps->d_ctr + 2 * (ps->ctr_slot.fetch_add(1) % CTR_RING);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), lds, st, d_x, d_y, (const cx<float>*)d_Hc,
-                       nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, ctr,
-                       fb.nsig, fb.xstride, fb.ystride);
-    PF_CHECK(hipGetLastError());
-    return 0;
-}
-
 // W_1024^j for the wave-local sub-transforms of fastconv_split_kernel: one table per device, generated in extended precision
 static int split_sub_table(const cx<float>** out) {
     static std::mutex mu;
@@ -73,9 +50,10 @@ static int split_sub_table(const cx<float>** out) {
     return 0;
 }
 
+template <int PSYNC, int SPREAD>
 static int fir_split(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen,
                      int lastOut, hipStream_t st, const FcBatch& fb) {
-    auto k = fastconv_split_kernel;
+    auto k = fastconv_split_kernel<PSYNC, SPREAD>;
     int rc = allow_big_lds(k, SplitFir::LDS_BYTES);
     if (rc) return rc;
     const cx<float>* tw1024 = nullptr;
@@ -96,16 +74,13 @@ int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, i
                    hipStream_t st, const FcBatch& fb) {
     switch (ps->n) {
         case 2048: return fir_dma_cfg<DmaCfgF32::D2048>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-        case 4096:
-            if (g_variant == 111) return fir_dma1_cfg<Dma1CfgF32::D4096>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            return fir_dma_cfg<DmaCfgF32::D4096>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+        case 4096: return fir_dma_cfg<DmaCfgF32::D4096>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
         case 8192:
-            if (g_variant == 116) return fir_split(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            if (g_variant == 111) return fir_dma1_cfg<Dma1CfgF32::D8192>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            if (g_variant == 112) return fir_dma1_cfg<Dma1CfgF32::D8192l>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            if (g_variant == 113) return fir_dma1_cfg<Dma1CfgF32::D8192l5>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            if (g_variant == 110) return fir_dma_cfg<DmaCfgF32::D8192m>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            return fir_dma_cfg<DmaCfgF32::D8192>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            // 16384-sample blocks: cross-wave radix 8 + wave-local 1024-point transforms (fft_split.h); variant 97 = the lock-step
+            // LDS-DMA kernel it replaced, 116 = without the pairwise flags and the spread pieces (A/B)
+            if (g_variant == 97) return fir_dma_cfg<DmaCfgF32::D8192>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            if (g_variant == 116) return fir_split<0, 0>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            return fir_split<1, 1>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
         default: return -1;
     }
 }

@@ -266,214 +266,14 @@ fastconv_dma_kernel(const float* __restrict__ x, float* __restrict__ y, const cx
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-template <class C> struct Dma1Geom {
-    // one image, no internal-layout image (the FIR kernels never use it): natural / transposed exchange images only
-    static constexpr int IMG_PTS = (C::IMG_NAT > C::IMG_TRN ? C::IMG_NAT : C::IMG_TRN) + 8;
-    static constexpr int IMG_BYTES = IMG_PTS * 8;
-    static constexpr size_t LDS_BYTES = (size_t)IMG_BYTES + C::TABLE_BYTES + 16;
-    static_assert(C::n * 8 <= IMG_BYTES, "the landed block must fit the image");
-};
-
-// The same block kernel with ONE image per workgroup and TWO co-resident workgroups per CU (round 4): the cover for a
-// workgroup's DMA landing, LDS exchanges and barriers is the OTHER workgroup's arithmetic (four wavefronts per SIMD from two
-// independent barrier domains) instead of a second image inside one lock-stepped workgroup.  The image is free from the last
-// exchange of the backward transform on: the next block's pieces are issued there and land while the last butterflies run
-// and the outputs are stored.  128 VGPRs per lane: the per-bin coefficients do not fit next to the transform any more, so
-// the three steps between the transforms (real finalize, x Hf, real preprocess: src/pffft_priv_impl.h:1330-1372,
-// :1632-1684, :1423-1462) are done as such, in registers, with the filter spectrum read per block (64 KiB, L2-resident).
-template <class C>
-__global__ void __launch_bounds__(C::WG_THREADS, C::OCC)
-fastconv_dma1_kernel(const float* __restrict__ x, float* __restrict__ y, const cx<float>* __restrict__ Hc,
-                     int nblk, int step, int inputLen, int lastOut,
-                     const cx<float>* __restrict__ twg, const cx<float>* __restrict__ twrg, unsigned* ctr,
-                     int nsig, size_t xstride, size_t ystride) {
-    typedef float T;
-    typedef cx<T> CX;
-    typedef Tiled<C, FWD, 1> KF;
-    typedef Tiled<C, BWD, 1> KB;
-    typedef DmaGeom<C> G;
-    constexpr int n = C::n, E = C::E, TPT = C::TPT, NS = C::NS;
-    constexpr int R0 = C::rad(0), RL = C::rad(NS - 1);
-    static_assert(R0 == RL && E / R0 == 2 && C::VEC == 2 && C::T_PER_WG == 1, "fused FIR needs R0 == RL, two butterflies per thread, float");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
-    const int t = threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // LDS: [image][compact base-twiddle table (TWMODE 4)][next-group slots]
-    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + (size_t)Dma1Geom<C>::IMG_BYTES + C::TABLE_BYTES);
-    CX* img = reinterpret_cast<CX*>(smem_raw);
-    const CX* twt = twg;
-    if constexpr (C::TWMODE == 4) {
-        CX* tab = reinterpret_cast<CX*>(smem_raw + (size_t)Dma1Geom<C>::IMG_BYTES);
-        fill_ctw<C>(tab, twg, threadIdx.x, C::WG_THREADS);
-        twt = tab;
-    }
-    const chunk16* land16 = reinterpret_cast<const chunk16*>(img);
-
-    typename KF::Tw wf;
-    typename KB::Tw wb;
-    if constexpr (KF::REGTW) {          // stage twiddles only: the pair twiddles are fetched per block (below)
-        KF::template load_tw_stage<1>(wf, t, twg);
-        KB::template load_tw_stage<1>(wb, t, twg);
-    }
-
-    const bool dyn = ctr != nullptr;
-    unsigned pend = 0;
-    unsigned g = blockIdx.x;
-    if (dyn && threadIdx.x == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
-    __syncthreads();
-    if (dyn) g = s_next[0];
-    const long long nblk_all = (long long)nblk * nsig;
-    auto issue = [&](unsigned grp) {
-#pragma unroll
-        for (int i = 0; i < G::PPW; ++i) {
-            const int pv = wave + G::WAVES * i;
-            long long ba = (long long)grp;
-            if (ba >= nblk_all) ba = nblk_all - 1;
-            int sig, blk;
-            fc_split(ba, nblk, nsig, sig, blk);
-            long e = (long)blk * step + pv * 256 + lane * 4;     // first of this lane's 4 floats
-            if (e > (long)inputLen - 4) e = inputLen >= 4 ? (long)inputLen - 4 : 0;
-            glds16(x + (size_t)sig * xstride + e, lds0 + (unsigned)(pv * 1024));
-        }
-    };
-    issue(g);
-    for (unsigned it = 0; (long long)g < nblk_all; ++it) {
-        if (dyn && threadIdx.x == 0) {
-            s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
-        }
-        PF_DSTAMP(0);
-        wait_vmcnt<0>();
-        wg_sync_raw();
-        PF_DSTAMP(1);
-        const unsigned gn = dyn ? s_next[(it + 1) & 1] : g + gridDim.x;
-        const long long blk_all = (long long)g;
-        int sig, blk;
-        fc_split(blk_all, nblk, nsig, sig, blk);
-        const long off = (long)blk * step;
-        const int numOut = (blk == nblk - 1) ? lastOut : step;
-        float* ys = y + (size_t)sig * ystride;
-        CX v[E];
-        {
-            const long avail = (long)inputLen - off;  // samples of this block that exist
-#pragma unroll
-            for (int q = 0; q < R0; ++q) {
-                const int c = t + q * (n / (2 * R0));
-                const int e0 = 4 * c;
-                const chunk16 cc = land16[c];
-                float f0 = cc.x, f1 = cc.y, f2 = cc.z, f3 = cc.w;
-                if (e0 + 3 >= avail) {     // clamped copy (issue): element k is sample avail - 4 + k of the block
-                    const long sh = (long)e0 - (avail - 4);      // >= 1
-                    f0 = sh == 1 ? cc.y : sh == 2 ? cc.z : sh == 3 ? cc.w : 0.f;
-                    f1 = sh == 1 ? cc.z : sh == 2 ? cc.w : 0.f;
-                    f2 = sh == 1 ? cc.w : 0.f;
-                    f3 = 0.f;
-                }
-                v[q] = mk<T>(f0, f1);
-                v[R0 + q] = mk<T>(f2, f3);
-            }
-        }
-        // ---- forward transform ----
-        PF_DSTAMP(3);
-        KF::template butterflies<0>(v, t, wf, twt);
-        PF_DSTAMP(4);
-        wg_sync_raw();                                     // every wave has picked up its operands: the image is the exchange buffer now
-        PF_DSTAMP(5);
-#define PF_DMA1_FWD(S, B)                                                                                        \
-        if constexpr (NS > S + 1) {                                                                              \
-            KF::template xwrite<S>(v, t, img); wg_sync_raw(); PF_DSTAMP(B); KF::template xread<S>(v, t, img);    \
-            wg_sync_raw(); PF_DSTAMP(B + 1); KF::template butterflies<S + 1>(v, t, wf, twt); PF_DSTAMP(B + 2);    \
-        }
-        PF_DMA1_FWD(0, 6) PF_DMA1_FWD(1, 9) PF_DMA1_FWD(2, 12) PF_DMA1_FWD(3, 15)
-#undef PF_DMA1_FWD
-        // ---- packed spectrum -> X[k]; X[k] H[k] (H pre-scaled by 1/Nfft; bin 0 = (DC, Nyquist): two real products,
-        //      src/pffft_priv_impl.h:1680-1683); -> packed spectrum of the inverse
-        {
-            // W_N^k of this thread's mirror pairs and the filter spectrum of its bins come from L2 per block: resident in
-            // registers (they depend on the thread only, the compiler would hoist them out of the loop) they cost 48 VGPRs of
-            // the 128 — hence the index made opaque per iteration
-            int tl = t;
-            asm volatile("" : "+v"(tl));
-            CX pw[RL];
-            KF::load_pair_tw(pw, tl, twrg);
-            CX h[E];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int d = 0; d < RL; ++d) h[u * RL + d] = Hc[KF::template jm<NS - 1>(tl, u) + d * (n / RL)];
-            KF::pair_regs_p(v, t, pw);
-#pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const CX p = cmul(v[i], h[i]);
-                if (i == 0) v[0] = KF::sel(t == 0, mk<T>(v[0].x * h[0].x, v[0].y * h[0].y), p);
-                else v[i] = p;
-            }
-            KB::pair_regs_p(v, t, pw);       // the same W_N^k (R0 == RL)
-        }
-        // ---- backward transform (first-stage operands are already in place).  The last exchange is behind every wave at the
-        //      barrier after its xread: from there on the image is free and the next block's pieces are issued, to land
-        //      while the last butterflies run and the outputs are stored ----
-        PF_DSTAMP(20);
-        KB::template butterflies<0>(v, t, wb, twt);
-        PF_DSTAMP(21);
-#define PF_DMA1_BWD(S, B)                                                                                        \
-        if constexpr (NS > S + 1) {                                                                              \
-            KB::template xwrite<S>(v, t, img); wg_sync_raw(); PF_DSTAMP(B); KB::template xread<S>(v, t, img);    \
-            wg_sync_raw(); PF_DSTAMP(B + 1);                                                                     \
-            if constexpr (S == NS - 2) issue(gn);                                                                \
-            KB::template butterflies<S + 1>(v, t, wb, twt); PF_DSTAMP(B + 2);                                     \
-        }
-        PF_DMA1_BWD(0, 22) PF_DMA1_BWD(1, 25) PF_DMA1_BWD(2, 28) PF_DMA1_BWD(3, 31)
-#undef PF_DMA1_BWD
-        // ---- the first numOut samples (src/pffastconv.c:255) ----
-        {
-            float* dst = ys + off;
-#pragma unroll
-            for (int d = 0; d < RL; ++d) {
-                const int e0 = 4 * (t + d * (n / (2 * RL)));
-                const CX a = v[d], bb = v[RL + d];
-                if (e0 + 3 < numOut) {
-                    F4u q4; q4.a = a.x; q4.b = a.y; q4.c = bb.x; q4.d = bb.y;
-                    *reinterpret_cast<F4u*>(dst + e0) = q4;
-                } else {
-                    if (e0 < numOut) dst[e0] = a.x;
-                    if (e0 + 1 < numOut) dst[e0 + 1] = a.y;
-                    if (e0 + 2 < numOut) dst[e0 + 2] = bb.x;
-                }
-            }
-        }
-        PF_DSTAMP(40);
-        g = gn;
-    }
-    wait_vmcnt<0>();
-    if (dyn && threadIdx.x == 0) {
-        __threadfence();
-        unsigned d = atomicAdd(&ctr[1], 1u);
-        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
-    }
-}
-
 // ---- configurations: <T, log2 n, threads/transform, stages, R0..R3, PAD0, PADN, TWMODE, PREFETCH(unused), WG threads, OCC> ----
 // 16 points per thread, 512-thread workgroups: n = 8192 one vector per workgroup iteration, 4096 two, 2048 four.
 struct DmaCfgF32 {
     typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 0, 512, 1> D8192;
     typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 0, 512, 1> D4096;
     typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 8, 3, 0, 512, 1> D2048;
-    // round 4: 1024 threads per 16384-sample block, eight points per thread, five stages (fft_tiled.h TiledMwF32): four
-    // wavefronts per SIMD and half the per-thread chain of D8192
-    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 0, 1024, 1, 4> D8192m;
-};
-// one image, two workgroups per CU (fastconv_dma1_kernel)
-struct Dma1CfgF32 {
-    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 0, 512, 4> D8192;      // twiddle bases in registers
-    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 4, 4, 0, 512, 4> D8192l;     // ... in the compact LDS table
-    typedef TiledCfg<float, 13, 512, 5, 8, 8, 4, 4, 4, 4, 4, 0, 512, 4, 8> D8192l5;  // ... and radix <= 8: 8 x 8 x 4 x 4 x 8
-    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 0, 256, 4> D4096;
+    // (round 4: 1024 threads per 16384-sample block, eight points per thread, five stages - four wavefronts per SIMD and half the
+    //  per-thread chain - measured 0.22 / 0.26 against 0.26 / 0.32 for D8192: one more exchange per transform)
 };
 
 }  // namespace pf

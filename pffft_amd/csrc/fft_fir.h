@@ -60,17 +60,6 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + C::TABLE_BYTES + (size_t)C::T_PER_WG * C::IMG * sizeof(CX));
 
     PF_STAMP(0);
-    typename KF::Tw wf;
-    typename KB::Tw wb;
-    KF::load_tw(wf, t, twg, twrg);
-    KB::load_tw(wb, t, twg, twrg);
-    // filter spectrum of the bins this thread owns after the forward transform: k = jm(t,u) + d n/R
-    CX h[E];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int d = 0; d < RL; ++d) h[u * RL + d] = Hc[KF::template jm<NS - 1>(t, u) + d * (n / RL)];
-
     // ctr == nullptr: static assignment (grid covers every block group once) — no atomics on the latency path
     const bool dyn = ctr != nullptr;
     unsigned pend = 0;
@@ -84,6 +73,43 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         g = s_next[0];
     }
     const long long nblk_all = (long long)nblk * nsig;
+    // ---- gather of block group grp: stage-0 operand order, zero beyond the end of the signal (src/pffastconv.c:231-233).
+    //      The FIRST block's samples are requested before anything else: the twiddle / filter tables below are cold on a call
+    //      with few blocks, and their misses then overlap the block's instead of preceding it (tools/fir_timeline.hip: the
+    //      prologue cost 5 000-6 000 of the 21 000 cycles of the stated C4 call before the first sample was even requested)
+    typedef vec4<float> F4;
+    F4 raw[R0];
+    auto gather = [&](unsigned grp) {
+        const long long ba = (long long)grp * C::T_PER_WG + slot;
+        int sg = nsig - 1, bk = nblk - 1;
+        if (ba < nblk_all) fc_split(ba, nblk, nsig, sg, bk);
+        const float* src = x + (size_t)sg * xstride + (long)bk * step;
+        const long avail = (long)inputLen - (long)bk * step;  // samples of this block that exist
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            const int e0 = 4 * (t + q * (n / (2 * R0)));      // first of 4 consecutive samples
+            F4 r;
+            if (e0 + 3 < avail) {
+                const F4u q4 = *reinterpret_cast<const F4u*>(src + e0);  // 16 bytes, 4-byte aligned
+                r.x = q4.a; r.y = q4.b; r.z = q4.c; r.w = q4.d;
+            } else {
+                r.x = e0 < avail ? src[e0] : 0.f; r.y = e0 + 1 < avail ? src[e0 + 1] : 0.f;
+                r.z = e0 + 2 < avail ? src[e0 + 2] : 0.f; r.w = e0 + 3 < avail ? src[e0 + 3] : 0.f;
+            }
+            raw[q] = r;
+        }
+    };
+    gather(g);
+    typename KF::Tw wf;
+    typename KB::Tw wb;
+    KF::load_tw(wf, t, twg, twrg);
+    KB::load_tw(wb, t, twg, twrg);
+    // filter spectrum of the bins this thread owns after the forward transform: k = jm(t,u) + d n/R
+    CX h[E];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int d = 0; d < RL; ++d) h[u * RL + d] = Hc[KF::template jm<NS - 1>(t, u) + d * (n / RL)];
     for (unsigned it = 0; (long long)g * C::T_PER_WG < nblk_all; ++it) {
         if (dyn && threadIdx.x == 0) {
             s_next[(it + 1) & 1] = pend;
@@ -95,30 +121,13 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         if (active) fc_split(blk_all, nblk, nsig, sig, blk);
         const long off = (long)blk * step;  // first input / output sample of the block
         const int numOut = (active && blk == nblk - 1) ? lastOut : step;
-        const float* xs = x + (size_t)sig * xstride;
         float* ys = y + (size_t)sig * ystride;
         CX v[E];
         PF_STAMP(1);
-        // ---- gather: stage-0 operand order, zero beyond the end of the signal (src/pffastconv.c:231-233) ----
-        {
-            const float* src = xs + off;
-            const long avail = (long)inputLen - off;  // samples of this block that exist
 #pragma unroll
-            for (int ii = 0; ii < 1; ++ii)
-#pragma unroll
-                for (int q = 0; q < R0; ++q) {
-                    const int e0 = 4 * (t + TPT * ii + q * (n / (2 * R0)));  // first of 4 consecutive samples
-                    float f0, f1, f2, f3;
-                    if (e0 + 3 < avail) {
-                        const F4u q4 = *reinterpret_cast<const F4u*>(src + e0);  // 16 bytes, 4-byte aligned
-                        f0 = q4.a; f1 = q4.b; f2 = q4.c; f3 = q4.d;
-                    } else {
-                        f0 = e0 < avail ? src[e0] : 0.f; f1 = e0 + 1 < avail ? src[e0 + 1] : 0.f;
-                        f2 = e0 + 2 < avail ? src[e0 + 2] : 0.f; f3 = e0 + 3 < avail ? src[e0 + 3] : 0.f;
-                    }
-                    v[(2 * ii) * R0 + q] = mk<T>(f0, f1);
-                    v[(2 * ii + 1) * R0 + q] = mk<T>(f2, f3);
-                }
+        for (int q = 0; q < R0; ++q) {
+            v[q] = mk<T>(raw[q].x, raw[q].y);
+            v[R0 + q] = mk<T>(raw[q].z, raw[q].w);
         }
         // ---- forward transform ----
         KF::template butterflies<0>(v, t, wf, twg);
@@ -178,6 +187,7 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         KB::xsync();
         PF_STAMP(8);
         g = gn;
+        if ((long long)g * C::T_PER_WG < nblk_all) gather(g);
     }
     if (dyn && threadIdx.x == 0) {
         __threadfence();
@@ -205,7 +215,6 @@ struct FirCfg {
     // round 4, calls with few blocks (the stated C4 call: 255 blocks of 8192 samples on 256 CUs): twice the threads per block,
     // eight points per thread - two wavefronts per SIMD and half the dependent chain per thread, one more exchange per transform
     typedef TiledCfg<float, 12, 512, 5, 4, 8, 8, 4, 8, 4, 3, 0, 512, 2, 4> C4096m;
-    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 0, 1024, 2, 4> C8192m;
     typedef TiledCfg<float, 11, 256, 5, 4, 8, 4, 4, 8, 4, 3, 0, 256, 2, 4> C2048m;
 };
 

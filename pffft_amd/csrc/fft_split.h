@@ -29,11 +29,24 @@ struct SplitFir {
     static constexpr int n = 8192, M = 1024, WAVES = 8, WG = 512;
     static constexpr int ROW = (Sub::IMG_NAT > Sub::IMG_TRN ? Sub::IMG_NAT : Sub::IMG_TRN) + 8;   // points per wavefront region
     static constexpr int LAND_BYTES = n * 8;                                   // the landed block: 16384 floats, linear
-    static constexpr size_t LDS_BYTES = (size_t)LAND_BYTES + (size_t)WAVES * ROW * 8 + 16;
+    static constexpr size_t LDS_BYTES = (size_t)LAND_BYTES + (size_t)WAVES * ROW * 8 + 16 + 64;   // + next-group slots + pair flags
     static constexpr int PPW = (LAND_BYTES / 1024) / WAVES;                    // 1 KiB pieces per wavefront
+    static_assert(PPW == 8, "the spread schedule places eight pieces");
     static_assert((ROW * 8) % 16 == 0, "rows must keep 16-byte alignment");
 };
 
+// pairwise hand-over through LDS flags (PSYNC): the mirror exchange couples wavefront d with wavefront 8 - d only (0 and 4 with
+// themselves), so the two workgroup barriers around it become waits for ONE partner
+__device__ __forceinline__ void lds_flag_set(unsigned* f, unsigned v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // everything this wave wrote / read before is done
+    *(volatile unsigned*)f = v;
+}
+__device__ __forceinline__ void lds_flag_wait(const unsigned* f, unsigned v) {
+    while (*(volatile const unsigned*)f != v) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+template <int PSYNC, int SPREAD = 0>
 __global__ void __launch_bounds__(SplitFir::WG, 2)
 fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const cx<float>* __restrict__ Hc,
                       int nblk, int step, int inputLen, int lastOut,
@@ -52,9 +65,13 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     const chunk16* land16 = reinterpret_cast<const chunk16*>(smem_raw);
     CX* rows = reinterpret_cast<CX*>(smem_raw + S::LAND_BYTES);
     unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + S::LAND_BYTES + (size_t)S::WAVES * ROW * 8);
+    unsigned* flagZ = s_next + 4;                            // [8] spectrum of wavefront d is in its row (tag = iteration + 1)
+    unsigned* flagR = s_next + 12;                           // [8] wavefront d has read its partner's row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     CX* row = rows + (size_t)wave * ROW;
+    if (tid < 16) s_next[4 + tid] = 0u;
+    const bool paired = wave != 0 && wave != 4;              // 0 and 4 are their own partners
 
     // ---- per-thread constants
     typename KF::Tw wf;
@@ -93,22 +110,28 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     const long long nblk_all = (long long)nblk * nsig;
     // copies that would run past the signal are clamped to its last 16 bytes (their samples are replaced by the zero padding of
     // src/pffastconv.c:231-233 when the operands are picked up)
-    auto issue = [&](unsigned grp) {
+    const float* nx_src = x;                                 // the next block's signal and first sample for this lane (issue_pieces)
+    long nx_base = 0;
+    auto issue_prep = [&](unsigned grp) {
         long long ba = (long long)grp;
         if (ba >= nblk_all) ba = nblk_all - 1;
         int sig, blk;
         fc_split(ba, nblk, nsig, sig, blk);
-        const float* xs = x + (size_t)sig * xstride;
-        const long base = (long)blk * step + lane * 4;
+        nx_src = x + (size_t)sig * xstride;
+        nx_base = (long)blk * step + lane * 4;
+    };
+    // pieces lo .. hi-1 of this wavefront's share (piece pv = wave + 8 i covers floats 256 pv .. of the block)
+    auto issue_pieces = [&](int lo, int hi) {
 #pragma unroll
-        for (int i = 0; i < S::PPW; ++i) {
+        for (int i = lo; i < hi; ++i) {
             const int pv = wave + S::WAVES * i;
-            long e = base + pv * 256;                        // first of this lane's 4 floats
+            long e = nx_base + pv * 256;                     // first of this lane's 4 floats
             if (e > (long)inputLen - 4) e = inputLen >= 4 ? (long)inputLen - 4 : 0;
-            glds16(xs + e, lds0 + (unsigned)(pv * 1024));
+            glds16(nx_src + e, lds0 + (unsigned)(pv * 1024));
         }
     };
-    issue(g);
+    issue_prep(g);
+    issue_pieces(0, S::PPW);
     for (unsigned it = 0; (long long)g < nblk_all; ++it) {
         if (dyn && tid == 0) {
             s_next[(it + 1) & 1] = pend;
@@ -167,8 +190,13 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         PF_DSTAMP(2);
         wg_sync_raw();                                       // (2) rows complete; the landing buffer is free
         PF_DSTAMP(3);
-        issue(gn);                                           // the next block has the rest of the iteration to land
+        // The next block's pieces go out ONE AT A TIME between the steps of B and B': issued back to back here, the 64 pieces of a
+        // workgroup pass the CU's vector-memory queue one after the other (~50 cycles each) and the wavefront served last started B
+        // 2 500 cycles behind the first - every later barrier waited for it (tools/dma_timeline.hip)
+        issue_prep(gn);
+        if constexpr (!SPREAD) issue_pieces(0, S::PPW);
         PF_DSTAMP(4);
+#define PF_SPLIT_PIECE(I) do { if constexpr (SPREAD) issue_pieces(I, (I) + 1); } while (0)
         // ================= B: wavefront `wave` transforms row `wave`, wave-local
         CX v[16];
         {
@@ -182,17 +210,28 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         }
         KF::xsync();
         KF::template butterflies<0>(v, lane, wf, tw1024);
+        PF_SPLIT_PIECE(0);
         KF::template xwrite<0>(v, lane, row); KF::xsync();
         KF::template xread<0>(v, lane, row); KF::xsync();
+        PF_SPLIT_PIECE(1);
         KF::template butterflies<1>(v, lane, wf, tw1024);
+        PF_SPLIT_PIECE(2);
         KF::template xwrite<1>(v, lane, row); KF::xsync();
         KF::template xread<1>(v, lane, row); KF::xsync();
+        PF_SPLIT_PIECE(3);
         KF::template butterflies<2>(v, lane, wf, tw1024);
+        PF_SPLIT_PIECE(4);
         PF_DSTAMP(5);
         // ================= M: Z[wave + 8 k2], k2 = 2 lane + u + 128 d -> row[k2]; mirrors conj Z[n - k] from row 8 - wave
 #pragma unroll
         for (int d = 0; d < 8; ++d) lds_st2(row + 2 * lane + 128 * d, v[d], v[8 + d]);
-        wg_sync_raw();                                       // (3) the whole packed spectrum sits in the rows
+        const unsigned tag = it + 1;
+        if constexpr (PSYNC) {
+            if (lane == 0) lds_flag_set(flagZ + wave, tag);
+            if (paired) lds_flag_wait(flagZ + (8 - wave), tag);
+        } else {
+            wg_sync_raw();                                   // (3) the whole packed spectrum sits in the rows
+        }
         PF_DSTAMP(6);
         CX zm[16];
         if (wave != 0) {
@@ -212,7 +251,11 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
                 zm[8 + d] = lds_ld(row + (1023 - 2 * lane - 128 * d));
             }
         }
-        wg_sync_raw();                                       // (3') every mirror is read: the rows are exchange buffers again
+        if constexpr (PSYNC) {
+            if (lane == 0) lds_flag_set(flagR + wave, tag);
+        } else {
+            wg_sync_raw();                                   // (3') every mirror is read: the rows are exchange buffers again
+        }
         PF_DSTAMP(7);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -222,12 +265,17 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         }
         // ================= B': inverse transform of Z'[wave + 8 k2] (first-stage operands are in place), wave-local
         KB::template butterflies<0>(v, lane, wb, tw1024);
+        if constexpr (PSYNC) { if (paired) lds_flag_wait(flagR + (8 - wave), tag); }   // the partner is done with this row
+        PF_SPLIT_PIECE(5);
         KB::template xwrite<0>(v, lane, row); KB::xsync();
         KB::template xread<0>(v, lane, row); KB::xsync();
         KB::template butterflies<1>(v, lane, wb, tw1024);
+        PF_SPLIT_PIECE(6);
         KB::template xwrite<1>(v, lane, row); KB::xsync();
         KB::template xread<1>(v, lane, row); KB::xsync();
+        PF_SPLIT_PIECE(7);
         KB::template butterflies<2>(v, lane, wb, tw1024);
+#undef PF_SPLIT_PIECE
 #pragma unroll
         for (int d = 0; d < 8; ++d) lds_st2(row + 2 * lane + 128 * d, v[d], v[8 + d]);   // b_wave[j], j = 2 lane + u + 128 d
         PF_DSTAMP(8);

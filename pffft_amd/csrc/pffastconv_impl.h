@@ -435,8 +435,7 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
             // The LDS-DMA staged block kernel (fft_dma.h) where it measured faster (tools/dma_ab.py, fraction of the 8 B / sample
             // roofline, register-staged -> DMA): Nfft 16384: 2^26 samples 0.190 -> 0.209, 256 signals x 2^20 0.204 -> 0.246;
             // Nfft 8192: a tie (0.22-0.29 both).  Variant 97 / PFFASTCONV_HIP_DMA=1 force it, =0 switches it off (A/B).
-            const bool use_dma = g_variant == 97 || (g_variant >= 110 && g_variant < 120) ||
-                                 (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && nbig == 16384)));
+            const bool use_dma = g_variant == 97 || g_variant == 116 || (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && nbig == 16384)));
             if (use_dma) {
                 rc = launch_fir_dma(s->st_big, s->d_Hc_big, d_x, d_y, bblk, bstep, inputLen, blast, st, fb);
                 if (rc != -1) return rc;
@@ -473,7 +472,7 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         PF_CHECK(hipGetLastError());
         return 0;
     }
-    if (mode == 0 && (g_variant == 97 || (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && Nfft == 16384)))) &&
+    if (mode == 0 && (g_variant == 97 || g_variant == 116 || (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && Nfft == 16384)))) &&
         (long)nblk * fb.nsig >= 2L * num_cus()) {
         rc = launch_fir_dma(s->st, s->d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);   // many reference-sized blocks
         if (rc != -1) return rc;
@@ -482,15 +481,16 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         switch (Nfft / 2) {
             case 512: return fc_launch_fused<FirCfg::C512>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            // 2048 / 4096 points: twice the threads per block, eight points per thread (FirCfg::C*m, round 4): the stated C4 call
+            // 10.9 -> 9.5 us, 2048 taps on 2^19 samples 8.8 -> 7.3 us; n = 8192 on 1024 threads measured slower (15.9 -> 17.9 us).
+            // Variant 114 = the 16-points-per-thread configurations (A/B)
             case 2048:
-                if (g_variant == 115) return fc_launch_fused<FirCfg::C2048m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+                if (g_variant != 114) return fc_launch_fused<FirCfg::C2048m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
                 return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             case 4096:
-                if (g_variant == 115) return fc_launch_fused<FirCfg::C4096m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+                if (g_variant != 114) return fc_launch_fused<FirCfg::C4096m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
                 return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            case 8192:
-                if (g_variant == 115) return fc_launch_fused<FirCfg::C8192m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-                return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            case 8192: return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             default: break;
         }
     }

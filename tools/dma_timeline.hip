@@ -31,12 +31,7 @@ static int run(const char* name, const float* x, float* y, const cx<float>* dH, 
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipMemset(ctr, 0, 8));
         if constexpr (ONE) {
-            auto k = fastconv_dma1_kernel<C>;
-            lds = Dma1Geom<C>::LDS_BYTES;
-            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, C::WG_THREADS, lds));
-            CK(hipEventRecord(a));
-            hipLaunchKernelGGL(k, dim3(cus * per_cu), dim3(C::WG_THREADS), lds, 0, x, y, dH, (int)nblk, step, (int)L, lastOut, dtw, dtwr, ctr, 1, (size_t)0, (size_t)0);
+            return 1;   // (the one-image / two-workgroup kernel of round 4 was removed: git history)
         } else {
             auto k = fastconv_dma_kernel<C, SPREAD>;
             lds = DmaGeom<C>::LDS_BYTES;
@@ -55,12 +50,13 @@ static int run(const char* name, const float* x, float* y, const cx<float>* dH, 
     return 0;
 }
 
+template <int PSYNC, int SPREAD>
 static int run_split(const float* x, float* y, const cx<float>* dH, const cx<float>* dtw, const cx<float>* dtw1024, const cx<float>* dtwr,
                      unsigned* ctr, long L, int taps, int cus) {
     const int n = 8192, Nfft = 2 * n, step = Nfft - taps + 1;
     const long nblk = (L - taps + 1 + step - 1) / step;
     const int lastOut = (int)(L - taps + 1 - (nblk - 1) * step);
-    auto k = fastconv_split_kernel;
+    auto k = fastconv_split_kernel<PSYNC, SPREAD>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitFir::LDS_BYTES));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int rep = 0; rep < 4; ++rep) {
@@ -71,7 +67,7 @@ static int run_split(const float* x, float* y, const cx<float>* dH, const cx<flo
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (rep == 3) {
             printf("[lds %zu B, fraction of the 8 B / sample roofline %.3f] ", (size_t)SplitFir::LDS_BYTES, 8.0 * (L - taps + 1) / (ms * 1e-3) / 8e12);
-            report("split: cross-wave radix 8 + wave-local 1024-point transforms", ms * 1e3f, nblk, cus, 1);
+            report(PSYNC ? (SPREAD ? "split, pairwise flags, pieces spread" : "split, pairwise flags around the mirror exchange") : (SPREAD ? "split, pieces spread over B and B'" : "split: cross-wave radix 8 + wave-local 1024-point transforms"), ms * 1e3f, nblk, cus, 1);
         }
     }
     return 0;
@@ -96,12 +92,10 @@ int main() {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("clock rate %d kHz, %d CUs\n", prop.clockRate, cus);
-    if (run_split(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;
+    if (run_split<0, 0>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;
+    if (run_split<0, 1>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;
+    if (run_split<1, 1>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;
     if (run<DmaCfgF32::D8192, false>("two images, 512 threads (D8192)", x, y, dH, dtw, dtwr, ctr, L, taps, cus)) return 1;
     if (run<DmaCfgF32::D8192, false, 1>("two images, 512 threads, pieces spread over the phases", x, y, dH, dtw, dtwr, ctr, L, taps, cus)) return 1;
-    if (run<DmaCfgF32::D8192m, false, 1>("two images, 1024 threads, pieces spread", x, y, dH, dtw, dtwr, ctr, L, taps, cus)) return 1;
-    if (run<DmaCfgF32::D8192m, false>("two images, 1024 threads (D8192m)", x, y, dH, dtw, dtwr, ctr, L, taps, cus)) return 1;
-    if (run<Dma1CfgF32::D8192, true>("one image, 2 WG/CU, register twiddles", x, y, dH, dtw, dtwr, ctr, L, taps, cus)) return 1;
-    if (run<Dma1CfgF32::D8192l, true>("one image, 2 WG/CU, LDS twiddles", x, y, dH, dtw, dtwr, ctr, L, taps, cus)) return 1;
     return 0;
 }
