@@ -140,6 +140,21 @@ int pffftd_hip_zreorder_batch(PFFFTD_Setup *, const double *in, double *out, siz
 int pffftd_hip_zconvolve_batch(PFFFTD_Setup *, const double *a, const double *b, double *ab, double scaling,
                                size_t batch, int accumulate, int b_broadcast, void *stream);
 
+/* Spectral convolution in one call (round 4):   out[i] (+)= backward( forward(in[i]) . H[i or 0] ) * scaling
+ * - the sequence pffft_transform(FORWARD), pffft_zconvolve_no_accu, pffft_transform(BACKWARD) of every FFT convolution
+ * (src/pffft_priv_impl.h:1465-1532, :1632-1684; src/pffastconv.c:235-254 is one instance), with `in` / `out` in the TIME domain
+ * and H a spectrum in the INTERNAL layout (what pffft_transform(…, PFFFT_FORWARD) produced for the filter).  The transforms are
+ * unscaled like the reference's: pass scaling = 1/N for a true circular convolution.  accumulate != 0 adds the result to `out`
+ * (by linearity the same values as accumulating spectra with pffft_zconvolve_accumulate before one inverse transform).
+ * h_broadcast != 0: ONE filter spectrum for the whole batch - for the power-of-two sizes up to N = 8192 complex / 16384 real
+ * (float; 4096 / 8192 double) this runs as ONE kernel, one read and one write of every vector instead of seven vector passes;
+ * every other case (per-vector spectra, sizes with factors 3 / 5, sizes beyond LDS) is composed from the three batched entries
+ * on `stream` through a per-stream scratch image of the batch.  in == out is allowed; H must not alias out. */
+int pffft_hip_convolve_batch(PFFFT_Setup *, const float *in, const float *H, float *out, float scaling, size_t batch,
+                             int accumulate, int h_broadcast, void *stream);
+int pffftd_hip_convolve_batch(PFFFTD_Setup *, const double *in, const double *H, double *out, double scaling, size_t batch,
+                              int accumulate, int h_broadcast, void *stream);
+
 /* Frequency shift fused into the forward transform (the mixers themselves:
  * include/pfdsp_hip.h, reference src/pf_mixer.cpp:142-165).  `in` is ONE stream of batch*N interleaved
  * complex samples; sample g is multiplied by exp(j*(phase_rad + 2*pi*rate*g)) — shift_math_cc's

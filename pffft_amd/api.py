@@ -74,6 +74,9 @@ def lib():
         g("hip_zconvolve_batch").restype = C.c_int
         g("hip_zconvolve_batch").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, ct, C.c_size_t,
                                              C.c_int, C.c_int, C.c_void_p]
+        g("hip_convolve_batch").restype = C.c_int
+        g("hip_convolve_batch").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, ct, C.c_size_t,
+                                            C.c_int, C.c_int, C.c_void_p]
         getattr(L, f"validate_{pfx}_simd").restype = C.c_int
         getattr(L, f"validate_{pfx}_simd_ex").restype = C.c_int
         getattr(L, f"validate_{pfx}_simd_ex").argtypes = [C.c_void_p]
@@ -263,6 +266,23 @@ class Setup:
         _check(fn(self.handle, a.data_ptr(), b.data_ptr(), ab.data_ptr(), scaling, batch, int(bool(accumulate)),
                   int(bool(b_broadcast)), self._stream()), "hip_zconvolve_batch")
         return ab
+
+    def convolve_batch(self, x, H, out=None, scaling=1.0, accumulate=False):
+        """pffft_hip_convolve_batch: out (+)= backward(forward(x) . H) * scaling; H = ONE spectrum in the internal layout
+        (1-D tensor, broadcast) or one per vector (same shape as x)."""
+        import torch
+        batch = self._tcheck(x)
+        if out is None:
+            assert not accumulate
+            out = torch.empty_like(x)
+        self._tcheck(out)
+        bc = H.numel() == self.vec_scalars
+        assert bc or H.numel() == x.numel()
+        assert H.is_cuda and H.dtype == x.dtype and H.is_contiguous()
+        fn = getattr(self._L, f"{self._pfx}_hip_convolve_batch")
+        _check(fn(self.handle, x.data_ptr(), H.data_ptr(), out.data_ptr(), scaling, batch, int(bool(accumulate)), int(bc),
+                  self._stream()), "hip_convolve_batch")
+        return out
 
     # ---------------- host (numpy): the legacy single-vector entries ----------------
     def _legacy(self, name, x, direction):

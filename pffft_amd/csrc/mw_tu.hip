@@ -16,12 +16,8 @@ static int mw_launch(Setup* s, const T* in, T* out, size_t batch, int dir, int o
     else k = real ? fft_tiled_kernel<C, BWD, 1> : fft_tiled_kernel<C, BWD, 0>;
     int rc = allow_big_lds(k, C::LDS_BYTES);
     if (rc) return rc;
-    static int per_cu_cache[4] = {0, 0, 0, 0};           // constant per (kernel, LDS bytes): queried once
-    int& per_cu = per_cu_cache[(fwd ? 0 : 2) + (real ? 1 : 0)];
-    if (!per_cu) {
-        PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, C::LDS_BYTES));
-        if (per_cu < 1) per_cu = 1;
-    }
+    int per_cu = 0;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), C::WG_THREADS, C::LDS_BYTES, &per_cu))) return rc;
     const size_t groups = (batch + C::T_PER_WG - 1) / C::T_PER_WG;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;

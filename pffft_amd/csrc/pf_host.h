@@ -31,13 +31,17 @@ int fail(hipError_t e, const char* what);
 
 int num_cus();
 
+// opt-in to more than 64 KiB of dynamic LDS: once per (kernel, size) - the attribute call sat on every launch
+int allow_big_lds_impl(const void* kernel, size_t bytes);
 template <typename K>
 static int allow_big_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024)
-        PF_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes > 64 * 1024) return allow_big_lds_impl(reinterpret_cast<const void*>(kernel), bytes);
     return 0;
 }
+
+// hipOccupancyMaxActiveBlocksPerMultiprocessor is constant per (kernel, threads, LDS bytes): asked once, then served from a table
+// (it sat on the launch path of every tile pass and FIR call: pure host latency for the one-vector legacy entries)
+int cached_occupancy(const void* kernel, int threads, size_t lds, int* per_cu);
 
 enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1, K_TILED = 2, K_BIG = 3 };
 constexpr size_t LDS_MAX = 160 * 1024;
@@ -74,9 +78,14 @@ struct Setup {
     void* d_bigtw[2] = {nullptr, nullptr};
     // HBM work buffers of the beyond-LDS path: one pair PER STREAM (kernels of one stream serialise; two streams running
     // the same setup concurrently must not share scratch).  big_mu is held while a call enqueues its passes (launch_big).
-    struct Scratch { void* buf[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; };
+    struct Scratch { void* buf[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; unsigned long long last_use = 0; };
+    unsigned long long scratch_clock = 0;      // (under big_mu) orders the streams' last uses: the idlest one is evicted first
     std::mutex big_mu;
     std::map<hipStream_t, Scratch> big_scratch;
+    // spectrum image of the composed pffft_hip_convolve_batch route: one per stream, conv_mu held while a call enqueues
+    std::mutex conv_mu;
+    std::map<hipStream_t, Scratch> conv_scratch;
+    unsigned long long conv_clock = 0;
     void* d_stage[3] = {nullptr, nullptr, nullptr};  // staging for host-pointer legacy calls
     size_t stage_bytes[3] = {0, 0, 0};
     void* h_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned host images the kernels read / write directly (small vectors)
@@ -93,6 +102,9 @@ int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, i
 // mw_tu.hip: the multi-wave register-tiled configurations (fft_tiled.h TiledMwF32: 1024 threads per vector); -1 when the size
 // has none.  which: 0 = adopted, 1 .. = measured alternatives
 int launch_tiled_mw(Setup* s, const void* in, void* out, size_t batch, int dir, int ordered, hipStream_t st, int which);
+
+// conv_tu.hip: forward -> x H (one filter spectrum, internal layout) -> backward in ONE kernel (fft_conv.h); -1: no fused kernel
+int launch_conv_fused(Setup* s, const void* in, const void* H, void* out, size_t batch, double scaling, int accumulate, hipStream_t st);
 
 // tile_tu.hip: power-of-two sizes beyond LDS in two / three passes (fft_tile.h); canonical complex, in -> out through `work`
 // (same size, distinct from both; in may equal out).  -1 when the size has no tile plan.  layout 1 (forward only): the

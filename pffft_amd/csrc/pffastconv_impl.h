@@ -31,7 +31,8 @@ struct FastConv {
     std::vector<float> h_td;  // y[m] = sum_i h_td[i] x[m + i]: the filter as the time-domain kernel applies it (zero padded to 8)
     float* d_td = nullptr;
     // work image of the composed path: one per stream (two streams running one setup must not share scratch)
-    struct Work { float* p = nullptr; size_t floats = 0; };
+    struct Work { float* p = nullptr; size_t floats = 0; unsigned long long last_use = 0; };
+    unsigned long long work_clock = 0;
     std::map<hipStream_t, Work> work;
     float* d_x = nullptr; size_t x_floats = 0;   // staging of pffastconv_apply's host pointers (large signals)
     float* d_y = nullptr; size_t y_floats = 0;
@@ -184,8 +185,7 @@ static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, 
     int rc = allow_big_lds(k, C::LDS_BYTES);
     if (rc) return rc;
     int per_cu = 0;
-    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, C::LDS_BYTES));
-    if (per_cu < 1) per_cu = 1;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), C::WG_THREADS, C::LDS_BYTES, &per_cu))) return rc;
     size_t groups = ((size_t)nblk * fb.nsig + C::T_PER_WG - 1) / C::T_PER_WG;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
@@ -290,8 +290,7 @@ static int fc_launch_part(FastConv* s, const float* d_x, float* d_y, long produc
     int rc = allow_big_lds(k, lds);
     if (rc) return rc;
     int per_cu = 0;
-    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, lds));
-    if (per_cu < 1) per_cu = 1;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), C::WG_THREADS, lds, &per_cu))) return rc;
     const int nblk = (int)((produced + PART_B - 1) / PART_B);
     const int lastOut = (int)(produced - (long)(nblk - 1) * PART_B);
     const long waves = (long)num_cus() * per_cu * C::T_PER_WG;
@@ -325,8 +324,7 @@ static int fc_launch_wave(FastConv* s, const float* d_x, float* d_y, long produc
     int rc = allow_big_lds(k, lds);
     if (rc) return rc;
     int per_cu = 0;
-    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), C::WG_THREADS, lds));
-    if (per_cu < 1) per_cu = 1;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), C::WG_THREADS, lds, &per_cu))) return rc;
     const int step = (2 * PART_B - s->filterLen + 1) & ~3;        // valid samples per block, 16-byte store units
     const int nblk = (int)((produced + step - 1) / step);
     const int lastOut = (int)(produced - (long)(nblk - 1) * step);
@@ -495,11 +493,15 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         }
     }
     // composed path (complex-I/O modes with long filters): signal by signal on the same stream through one work image
-    if (s->work.size() >= 8 && !s->work.count(st)) {   // idle streams do not pin their work image for ever (hipFree waits for their kernels)
-        for (auto& kv : s->work) if (kv.second.p) (void)hipFree(kv.second.p);
-        s->work.clear();
+    if (s->work.size() >= 8 && !s->work.count(st)) {   // the stream that used this setup longest ago gives up its image (hipFree waits for its kernels)
+        auto victim = s->work.begin();
+        for (auto it = s->work.begin(); it != s->work.end(); ++it)
+            if (it->second.last_use < victim->second.last_use) victim = it;
+        if (victim->second.p) (void)hipFree(victim->second.p);
+        s->work.erase(victim);
     }
     FastConv::Work& wk = s->work[st];
+    wk.last_use = ++s->work_clock;
     rc = fc_grow(&wk.p, &wk.floats, (size_t)nblk * Nfft);
     if (rc) return rc;
     float* const d_work = wk.p;

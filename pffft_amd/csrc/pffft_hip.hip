@@ -180,9 +180,8 @@ static Setup* new_setup(int N, int transform, int is_double) {
         s->skw_ok = sk_build(s->n, is_double != 0, transform == PFFFT_REAL, s->skw, &s->skw_threads, &wl, true, LDS_MAX) && wl;
     }
     const bool pow2_tiled = (s->n & (s->n - 1)) == 0 && s->n >= 16 && s->n <= 16384 && (size_t)s->n * esz <= 128 * 1024;
-    // sizes with ONE image in LDS (two do not fit: complex float n = 9600 .. 20480) would run the radix 2-5 in-place kernel
-    // of fft_generic.h at 0.10-0.14 of the roofline; as R x N2 with the rows on a fast kernel the three streaming passes
-    // below measure 0.17-0.24
+    // sizes with ONE image in LDS (two do not fit: complex float n = 9600 .. 20480): as R x N2 with the rows on a fast kernel
+    // the three streaming passes below measure 0.17-0.24
     // (the same holds for a size whose Stockham plan fits but has no compile-time twin: the run-time-plan kernel measured 0.07
     //  at n = 9600)
     const bool single_image = s->glds <= LDS_MAX && !pow2_tiled && !sub_is_fast(s) && s->n >= 2048;
@@ -206,10 +205,13 @@ static Setup* new_setup(int N, int transform, int is_double) {
             s->sub = sub; s->bigR = R;
             if (fast) break;
         }
-        if (single_image && !(s->sub && sub_is_fast(s->sub))) {   // no fast factorization: stays on the in-place kernel
+        if (single_image && !(s->sub && sub_is_fast(s->sub))) {
+            // no factorisation with fast rows: the balanced two-pass strided plan below (launch_strided) - decided HERE, at setup
+            // time (the in-place kernel this branch used to fall back to is gone: such a setup would have been created and then
+            // failed on every transform).  No legal size reaches this today (tests/test_generated_sources.py: every size has a
+            // compile-time plan); the route exists so that a gap in the generated tables costs speed, not correctness.
             if (s->sub) destroy_setup(s->sub);
             s->sub = nullptr; s->bigR = 0;
-            s->kernel = K_GENERIC;
         }
         // larger still: peel the largest register-sized factor and recurse (n = R x (R' x N2')): five passes, seven, ...
         if (!s->sub && s->kernel == K_BIG) {
@@ -257,6 +259,13 @@ static Setup* new_setup(int N, int transform, int is_double) {
     // every other size that fits: mixed-radix Stockham kernel (fft_stock.h); the in-place kernel of
     // fft_generic.h keeps the sizes whose two images exceed LDS
     if (s->kernel == K_BIG) s->sk_ok = s->skw_ok = false;
+    if (s->kernel == K_GENERIC && !PF_HAS_VARIANTS && !sub_is_fast(s)) {
+        // product build: only compile-time Stockham plans exist.  A size without one (none today) must not yield a setup whose
+        // every transform fails: refuse it here, where the reference reports unsupported sizes too (NULL, src/pffft_priv_impl.h:1105-1109)
+        g_last_error = "pffft_hip: no kernel plan for this size in the product build";
+        destroy_setup(s);
+        return nullptr;
+    }
     return s;
 }
 
@@ -271,6 +280,7 @@ static void destroy_setup(Setup* s) {
     if (s->sub) destroy_setup(s->sub);
     for (void* p : s->d_bigtw) if (p) (void)hipFree(p);
     for (auto& kv : s->big_scratch) for (void* p : kv.second.buf) if (p) (void)hipFree(p);
+    for (auto& kv : s->conv_scratch) for (void* p : kv.second.buf) if (p) (void)hipFree(p);
     for (void* p : s->d_stage) if (p) (void)hipFree(p);
     for (void* p : s->h_stage) if (p) (void)hipHostFree(p);
     s->magic = 0;
@@ -369,6 +379,36 @@ static int ensure_device(Setup* s) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+int allow_big_lds_impl(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<const void*, size_t> done;           // largest size already granted per kernel
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = done.find(kernel);
+    if (it != done.end() && it->second >= bytes) return 0;
+    PF_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done[kernel] = bytes;
+    return 0;
+}
+
+int cached_occupancy(const void* kernel, int threads, size_t lds, int* per_cu) {
+    struct Key { const void* k; int th; size_t lds; bool operator<(const Key& o) const { return k != o.k ? k < o.k : th != o.th ? th < o.th : lds < o.lds; } };
+    static std::mutex mu;
+    static std::map<Key, int> tab;
+    const Key key{kernel, threads, lds};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = tab.find(key);
+        if (it != tab.end()) { *per_cu = it->second; return 0; }
+    }
+    int v = 0;
+    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, threads, lds));
+    if (v < 1) v = 1;
+    std::lock_guard<std::mutex> lk(mu);
+    tab[key] = v;
+    *per_cu = v;
+    return 0;
+}
+
 int num_cus() {
     static int cus = 0;
     if (!cus) {
@@ -575,8 +615,7 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
     int rc = allow_big_lds(e.fn, e.lds);
     if (rc) return rc;
     int per_cu = 0;
-    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(e.fn), e.wg, e.lds));
-    if (per_cu < 1) per_cu = 1;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(e.fn), e.wg, e.lds, &per_cu))) return rc;
     if (g_variant >= 10 && g_variant < 20 && per_cu > g_variant - 10 && g_variant > 10) per_cu = g_variant - 10;  // A/B: cap WGs per CU
     size_t groups = (batch + e.t_per_wg - 1) / e.t_per_wg;
     size_t grid = (size_t)num_cus() * per_cu;
@@ -653,8 +692,7 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
             int rc = allow_big_lds(cf, lds);
             if (rc) return rc;
             int per_cu = 0;
-            PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(cf), threads, lds));
-            if (per_cu < 1) per_cu = 1;
+            if ((rc = cached_occupancy(reinterpret_cast<const void*>(cf), threads, lds, &per_cu))) return rc;
             if (g_variant > 10 && g_variant < 20 && per_cu > g_variant - 10) per_cu = g_variant - 10;  // A/B: cap WGs per CU
             if (g_variant > 20 && g_variant < 30) per_cu = g_variant - 20;                             // A/B: force WGs per CU
             size_t grid = (size_t)num_cus() * per_cu;
@@ -685,8 +723,7 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
     int rc = allow_big_lds(k, lds);
     if (rc) return rc;
     int per_cu = 0;
-    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), threads, lds));
-    if (per_cu < 1) per_cu = 1;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), threads, lds, &per_cu))) return rc;
     if (g_variant >= 10 && g_variant < 20 && per_cu > g_variant - 10 && g_variant > 10) per_cu = g_variant - 10;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
@@ -817,10 +854,16 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     {
         constexpr size_t BIG_SCRATCH_STREAMS = 8;
         if (s->big_scratch.size() >= BIG_SCRATCH_STREAMS && !s->big_scratch.count(st)) {
-            for (auto& kv : s->big_scratch) for (void* p : kv.second.buf) if (p) (void)hipFree(p);
-            s->big_scratch.clear();
+            // ONE entry goes - the stream that used this setup longest ago (hipFree waits for its kernels) - not the whole map:
+            // a caller cycling through nine streams would otherwise free and re-allocate every stream's pair on every call
+            auto victim = s->big_scratch.begin();
+            for (auto it = s->big_scratch.begin(); it != s->big_scratch.end(); ++it)
+                if (it->second.last_use < victim->second.last_use) victim = it;
+            for (void* p : victim->second.buf) if (p) (void)hipFree(p);
+            s->big_scratch.erase(victim);
         }
         Setup::Scratch& sc = s->big_scratch[st];
+        sc.last_use = ++s->scratch_clock;
         for (int i = 0; i < 2; ++i)
             if (sc.bytes[i] < bytes) {
                 // hipFree waits for the device: kernels of this stream still using the old buffer finish first
@@ -1151,6 +1194,69 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
     return 0;
 }
 
+// out += x, 16-byte units (the accumulate leg of the composed convolution)
+template <typename T>
+__global__ void vec_add_kernel(const T* __restrict__ x, T* __restrict__ out, size_t units) {
+    const vec4<float>* x16 = reinterpret_cast<const vec4<float>*>(x);
+    vec4<float>* o16 = reinterpret_cast<vec4<float>*>(out);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
+        const vec4<float> a = x16[i], b = o16[i];
+        if constexpr (sizeof(T) == 4) {
+            vec4<float> r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; r.w = a.w + b.w;
+            o16[i] = r;
+        } else {
+            const vec2<double> da = __builtin_bit_cast(vec2<double>, a), db = __builtin_bit_cast(vec2<double>, b);
+            vec2<double> r; r.x = da.x + db.x; r.y = da.y + db.y;
+            o16[i] = __builtin_bit_cast(vec4<float>, r);
+        }
+    }
+}
+
+// pffft_hip_convolve_batch: out (+)= backward(forward(in) . H) scaling.  One kernel where fft_conv.h has one (conv_tu.hip);
+// otherwise the three batched entries through a per-stream spectrum image (variant 120 forces the composition, A/B).
+template <typename T>
+static int convolve_batch(Setup* s, const T* in, const T* H, T* out, T scaling, size_t batch, int accumulate, int h_broadcast,
+                          hipStream_t st) {
+    if (!s || s->magic != MAGIC || s->is_double != (sizeof(T) == 8)) {
+        g_last_error = "pffft_hip: bad setup handle";
+        return (int)hipErrorInvalidHandle;
+    }
+    if (batch == 0) return 0;
+    int rc = ensure_device<T>(s);
+    if (rc) return rc;
+    if (h_broadcast && g_variant != 120) {
+        rc = launch_conv_fused(s, in, H, out, batch, (double)scaling, accumulate, st);
+        if (rc != -1) return rc;
+    }
+    const size_t bytes = batch * s->vec_scalars * sizeof(T);
+    std::lock_guard<std::mutex> lk(s->conv_mu);
+    if (s->conv_scratch.size() >= 8 && !s->conv_scratch.count(st)) {   // the idlest stream's image goes (hipFree waits for its kernels)
+        auto victim = s->conv_scratch.begin();
+        for (auto it = s->conv_scratch.begin(); it != s->conv_scratch.end(); ++it)
+            if (it->second.last_use < victim->second.last_use) victim = it;
+        if (victim->second.buf[0]) (void)hipFree(victim->second.buf[0]);
+        s->conv_scratch.erase(victim);
+    }
+    Setup::Scratch& sc = s->conv_scratch[st];
+    sc.last_use = ++s->conv_clock;
+    if (sc.bytes[0] < bytes) {
+        if (sc.buf[0]) (void)hipFree(sc.buf[0]);
+        sc.buf[0] = nullptr; sc.bytes[0] = 0;
+        PF_CHECK(hipMalloc(&sc.buf[0], bytes));
+        sc.bytes[0] = bytes;
+    }
+    T* X = (T*)sc.buf[0];
+    if ((rc = transform_batch<T>(s, in, X, batch, PFFFT_FORWARD, 0, st))) return rc;
+    if ((rc = zconvolve_batch<T>(s, X, H, X, scaling, batch, 0, h_broadcast, st))) return rc;
+    if (!accumulate) return transform_batch<T>(s, X, out, batch, PFFFT_BACKWARD, 0, st);
+    if ((rc = transform_batch<T>(s, X, X, batch, PFFFT_BACKWARD, 0, st))) return rc;
+    const size_t units = bytes / 16;
+    const unsigned grid = (unsigned)std::min<size_t>((units + 255) / 256, (size_t)num_cus() * 16);
+    hipLaunchKernelGGL((vec_add_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)X, out, units);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // legacy single-vector entries: host pointers are staged, device pointers are used in place
 // ------------------------------------------------------------------------------------------------
@@ -1380,6 +1486,10 @@ struct PFFFTD_Setup : pf::Setup {};
     PF_EXPORT int PFX##_hip_zconvolve_batch(SETUP* s, const T* a, const T* b, T* ab, T sc, size_t batch,            \
                                             int accumulate, int b_broadcast, void* stream) {                        \
         return pf::zconvolve_batch<T>(s, a, b, ab, sc, batch, accumulate, b_broadcast, (hipStream_t)stream);        \
+    }                                                                                                               \
+    PF_EXPORT int PFX##_hip_convolve_batch(SETUP* s, const T* in, const T* H, T* out, T sc, size_t batch,           \
+                                           int accumulate, int h_broadcast, void* stream) {                         \
+        return pf::convolve_batch<T>(s, in, H, out, sc, batch, accumulate, h_broadcast, (hipStream_t)stream);       \
     }
 
 PF_DEFINE_API(pffft, PFFFT_Setup, float, 0, "HIP-gfx950")

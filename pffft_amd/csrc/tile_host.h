@@ -37,8 +37,7 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     int rc = allow_big_lds(k, lds);
     if (rc) return rc;
     int per_cu = 0;
-    PF_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), G::WG, lds));
-    if (per_cu < 1) per_cu = 1;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), G::WG, lds, &per_cu))) return rc;
     unsigned long long grid = (unsigned long long)num_cus() * per_cu;
     if (grid > ntiles) grid = ntiles;
     // in-order tiles only where a tile is 64 KiB or more: one counter address serves ~80 M atomics/s, so 16-32 KiB tiles

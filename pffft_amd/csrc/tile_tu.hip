@@ -1,6 +1,7 @@
 // libpffft_hip.so, translation unit of the two / three-pass tile kernels beyond LDS (fft_tile.h): the power-of-two tile
 // lengths, the plans and the pass descriptors.  The tile lengths with an odd first stage are instantiated in tile_mr*_tu.hip.
 #include <algorithm>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -153,13 +154,33 @@ static const std::vector<TileLen>& tile_lengths(bool is_double) {
 }
 static bool tile_len_ok(const TileLen& t) { return (long long)t.len() >= g_mr_min && (long long)t.len() <= g_mr_max; }
 
-static bool tile_plan(long long n, bool is_double, bool deep, TileLen& a, TileLen& b) {
-    if (const char* e = getenv("PFFFT_HIP_TILE_MRPLAN")) {   // A/B: "R1,l1,R2,l2" forces the two tile lengths
+// PFFFT_HIP_TILE_MRPLAN="R1,l1,R2,l2" forces the two tile lengths of the sizes they multiply to (A/B): read ONCE, and only
+// lengths that are instantiated are accepted (an arbitrary pair used to surface as "tile pass length out of range" after the
+// first pass had been enqueued)
+struct ForcedPlan { bool ok = false; TileLen a{1, 0}, b{1, 0}; };
+static const ForcedPlan& forced_plan() {
+    static const ForcedPlan f = [] {
+        ForcedPlan r;
+        const char* e = getenv("PFFFT_HIP_TILE_MRPLAN");
         int r1, l1, r2, l2;
-        if (sscanf(e, "%d,%d,%d,%d", &r1, &l1, &r2, &l2) == 4 && ((long long)r1 << l1) * ((long long)r2 << l2) == n) {
-            a = TileLen{r1, l1}; b = TileLen{r2, l2};
-            return true;
+        if (e && sscanf(e, "%d,%d,%d,%d", &r1, &l1, &r2, &l2) == 4) {
+            auto known = [](int r0, int l) {
+                for (int dbl = 0; dbl < 2; ++dbl)
+                    for (const TileLen& t : tile_lengths(dbl != 0)) if (t.r0 == r0 && t.logl == l) return true;
+                return false;
+            };
+            if (known(r1, l1) && known(r2, l2)) { r.ok = true; r.a = TileLen{r1, l1}; r.b = TileLen{r2, l2}; }
+            else fprintf(stderr, "pffft_hip: PFFFT_HIP_TILE_MRPLAN=%s names a tile length that is not instantiated: ignored\n", e);
         }
+        return r;
+    }();
+    return f;
+}
+
+static bool tile_plan_search(long long n, bool is_double, bool deep, TileLen& a, TileLen& b) {
+    {
+        const ForcedPlan& f = forced_plan();
+        if (f.ok && (long long)f.a.len() * (long long)f.b.len() == n) { a = f.a; b = f.b; return true; }
     }
     const std::vector<TileLen>& V = tile_lengths(is_double);
     int best = deep ? 460 : 286;                         // (deep: the streaming route takes five sweeps, ~480)
@@ -179,7 +200,7 @@ static bool tile_plan(long long n, bool is_double, bool deep, TileLen& a, TileLe
 
 // Three tile passes n = L1 (L2 L3) (the shape of the power-of-two sizes beyond 2^20) for the sizes without a two-pass plan whose
 // streaming route would take five sweeps (its row length is itself beyond LDS: `deep`); ~330 us per GiB against ~450-550.
-static bool tile_plan3(long long n, bool is_double, TileLen& a, TileLen& b, TileLen& c) {
+static bool tile_plan3_search(long long n, bool is_double, TileLen& a, TileLen& b, TileLen& c) {
     const std::vector<TileLen>& V = tile_lengths(is_double);
     int best = 1 << 30;
     for (const TileLen& ta : V) {
@@ -197,6 +218,36 @@ static bool tile_plan3(long long n, bool is_double, TileLen& a, TileLen& b, Tile
         }
     }
     return best != (1 << 30);
+}
+
+// The plan of a size is a pure function of (n, precision, deep): searched once, then served from a table (launch_big asked
+// twice per transform, under the setup's lock; the three-pass search walks ~26^3 length triples)
+struct PlanEntry { int passes = 0; TileLen t[3] = {{1, 0}, {1, 0}, {1, 0}}; };
+static const PlanEntry& plan_of(long long n, bool is_double, bool deep) {
+    static std::mutex mu;
+    static std::map<long long, PlanEntry> tab;
+    const long long key = n * 4 + (is_double ? 2 : 0) + (deep ? 1 : 0);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tab.find(key);
+    if (it == tab.end()) {
+        PlanEntry e;
+        if (tile_plan_search(n, is_double, deep, e.t[0], e.t[1])) e.passes = 2;
+        else if (deep && n <= (1ll << 27) && tile_plan3_search(n, is_double, e.t[0], e.t[1], e.t[2])) e.passes = 3;
+        it = tab.emplace(key, e).first;
+    }
+    return it->second;
+}
+static bool tile_plan(long long n, bool is_double, bool deep, TileLen& a, TileLen& b) {
+    const PlanEntry& e = plan_of(n, is_double, deep);
+    if (e.passes != 2) return false;
+    a = e.t[0]; b = e.t[1];
+    return true;
+}
+static bool tile_plan3(long long n, bool is_double, TileLen& a, TileLen& b, TileLen& c) {
+    const PlanEntry& e = plan_of(n, is_double, true);
+    if (e.passes != 3) return false;
+    a = e.t[0]; b = e.t[1]; c = e.t[2];
+    return true;
 }
 
 bool tile_has_plan(long long n, bool is_double, bool deep) {

@@ -72,3 +72,93 @@ def test_fastconv_few_blocks_512_thread_configurations(ref, taps, L):
     finally:
         pa.set_variant(0)
     fc.close()
+
+
+# ------------------------------------------------------------------ pffft_hip_convolve_batch (fft_conv.h + composition)
+def _ref_convolve(rs, x2d, H2d, scaling, acc0=None):
+    """The reference's sequence, vector by vector: transform FORWARD, zconvolve_no_accu, transform BACKWARD (+ acc0)."""
+    from oracle.ref import FORWARD, BACKWARD
+    out = np.empty_like(x2d)
+    for i in range(x2d.shape[0]):
+        X = rs.transform_unordered(x2d[i], FORWARD)
+        Hh = H2d[i if H2d.shape[0] > 1 else 0]
+        Y = rs.zconvolve(X, Hh, np.zeros_like(X), scaling, accumulate=False)
+        out[i] = rs.transform_unordered(Y, BACKWARD)
+    return out if acc0 is None else out + acc0
+
+
+@pytest.mark.parametrize("dt,tol", [(np.float32, 1e-5), (np.float64, 1e-12)])
+@pytest.mark.parametrize("tr,N", [(pa.COMPLEX, 16), (pa.COMPLEX, 64), (pa.COMPLEX, 256), (pa.COMPLEX, 1024), (pa.COMPLEX, 4096),
+                                  (pa.COMPLEX, 8192), (pa.REAL, 32), (pa.REAL, 64), (pa.REAL, 128), (pa.REAL, 512), (pa.REAL, 2048),
+                                  (pa.REAL, 8192), (pa.REAL, 16384), (pa.COMPLEX, 96), (pa.REAL, 1920), (pa.COMPLEX, 32768),
+                                  (pa.REAL, 1 << 17)])
+def test_convolve_batch_against_the_reference_sequence(ref, dt, tol, tr, N):
+    """out = backward(forward(in) . H) scaling against pffft_transform / pffft_zconvolve_no_accu / pffft_transform of the reference,
+    per vector: fused kernel (power-of-two sizes, broadcast H), the composition it falls back to (variant 120, sizes with factors
+    3 / 5, beyond LDS, per-vector H), accumulate, in place.  Ragged batch (more vectors than one grid of workgroups takes at once
+    is covered by the C2 / C5 shapes below)."""
+    from oracle.ref import FORWARD
+    rs = ref.setup(N, tr, dt)
+    s = pa.Setup(N, tr, dt)
+    rng = np.random.default_rng(N + tr)
+    B = 5
+    if dt == np.float64 and N & (N - 1):
+        tol = 2e-7     # the reference's double build keeps float-suffixed radix-3 / 5 constants (DESIGN.md §4): it is the inexact side
+    x = rng.uniform(-1, 1, (B, s.vec_scalars)).astype(dt)
+    hv = rng.uniform(-1, 1, (B, s.vec_scalars)).astype(dt)
+    Hs = np.stack([rs.transform_unordered(hv[i], FORWARD) for i in range(B)])
+    scaling = 1.0 / N
+    xd = torch.from_numpy(x).cuda()
+    Hd = torch.from_numpy(Hs).cuda()
+    # real N = 32 in double is below the double minimum? (both precisions share the size rules) - every listed size is legal
+    want_b = _ref_convolve(rs, x, Hs[:1], scaling)
+    want_v = _ref_convolve(rs, x, Hs, scaling)
+    scale = lambda w: np.abs(w).max(axis=1, keepdims=True)
+    try:
+        for var in (0, 120):
+            pa.set_variant(var)
+            got = s.convolve_batch(xd, Hd[0].contiguous(), scaling=scaling).cpu().numpy()
+            assert (np.abs(got - want_b) / scale(want_b)).max() <= tol, ("broadcast", var)
+        pa.set_variant(0)
+        got = s.convolve_batch(xd, Hd, scaling=scaling).cpu().numpy()
+        assert (np.abs(got - want_v) / scale(want_v)).max() <= tol, "per vector"
+        # accumulate on top of a previous result, and in place
+        acc = torch.from_numpy(want_v.astype(dt)).cuda()
+        got = s.convolve_batch(xd, Hd[0].contiguous(), out=acc, scaling=scaling, accumulate=True).cpu().numpy()
+        w = want_b + want_v
+        assert (np.abs(got - w) / scale(w)).max() <= 2 * tol, "accumulate"
+        buf = xd.clone()
+        got = s.convolve_batch(buf, Hd[0].contiguous(), out=buf, scaling=scaling).cpu().numpy()
+        assert (np.abs(got - want_b) / scale(want_b)).max() <= tol, "in place"
+    finally:
+        pa.set_variant(0)
+    s.close(); rs.close()
+
+
+@pytest.mark.parametrize("dt,tol,N,B", [(np.float32, 1e-5, 1024, (1 << 18) + 37), (np.float64, 1e-12, 1024, (1 << 17) + 5)])
+def test_convolve_batch_c2_c5_shapes(ref, dt, tol, N, B):
+    """The C2 / C5 shapes (N = 1024 complex, float and double) on a long ragged batch: persistent workgroups, in-order pull,
+    prefetch - 600 sampled vectors against the reference's sequence, and every vector against the three-launch composition."""
+    from oracle.ref import FORWARD
+    rs = ref.setup(N, pa.COMPLEX, dt)
+    s = pa.Setup(N, pa.COMPLEX, dt)
+    rng = np.random.default_rng(7)
+    h = rng.uniform(-1, 1, 2 * N).astype(dt)
+    H = rs.transform_unordered(h, FORWARD)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    xd = torch.rand(B, 2 * N, device="cuda", dtype=tdt) * 2 - 1
+    Hd = torch.from_numpy(H).cuda()
+    got = s.convolve_batch(xd, Hd, scaling=1.0 / N)
+    try:
+        pa.set_variant(120)
+        comp = s.convolve_batch(xd, Hd, scaling=1.0 / N)
+    finally:
+        pa.set_variant(0)
+    den = comp.abs().amax(dim=1)
+    assert float(((got - comp).abs().amax(dim=1) / den).max()) <= tol
+    idx = np.unique(np.concatenate(([0, 1, 2, B - 3, B - 2, B - 1], rng.integers(0, B, 600))))
+    xs = xd[torch.from_numpy(idx).cuda()].cpu().numpy()
+    want = _ref_convolve(rs, xs, H[None, :], 1.0 / N)
+    g = got[torch.from_numpy(idx).cuda()].cpu().numpy()
+    assert (np.abs(g - want).max(axis=1) / np.abs(want).max(axis=1)).max() <= tol
+    s.close(); rs.close()
