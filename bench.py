@@ -343,23 +343,28 @@ REF_SIZES = [64, 96, 128, 160, 192, 256, 384, 480, 512, 640, 768, 800, 1024, 204
 BEYOND_LDS_35 = [12000, 15360, 61440, 102400, 368640, 1024000]
 
 
-def sizes_table(torch, pa, dev, timer):
+def sizes_table(torch, pa, dev, timer, R=None):
     """The reference's benchmark table (benchmarks/bench_pffft.c:445,547-550: every size of its lists, real and complex,
     "PFFFT" = ordered and "PFFFT-U" = unordered, forward and backward - the reference times the pair; both halves are listed
     here) in float and double: 1 GiB of vectors per launch, 60 untimed launches per size, then 10 untimed + 20 timed launches per combination, fraction of 8 TB/s on
     2 x vector bytes per transform (a 256 MiB launch lasts ~80 us: start-up, tail and the gap to the next launch cost 15-20 %).  One line per kernel family and layout, so that a regression shows up in the driver's
     record without profiles/."""
     out = {"workload": "1 GiB of vectors per launch, 10 + 20 launches; [fwd ordered, fwd unordered, bwd ordered, bwd unordered] "
-                       "as fractions of 8 TB/s on 2 x vector bytes",
+                       "as fractions of 8 TB/s on 2 x vector bytes; after timing the last vector of every launch is checked against "
+                       "oracle/_ref (parity_worst_rel_err: per precision, over all sizes and combinations)",
            "sizes": REF_SIZES, "sizes_with_factors_3_5_beyond_lds": BEYOND_LDS_35}
+    worst = {}
     for tag, dt, tdt in (("f32", np.float32, torch.float32), ("f64", np.float64, torch.float64)):
         isz = np.dtype(dt).itemsize
         pool = make_input(torch, dev, 1, (1 << 30) // isz, tdt, seed=7).reshape(-1)
         ypool = torch.empty_like(pool)
         for tr, name in ((pa.COMPLEX, "complex"), (pa.REAL, "real")):
             tab = {}
+            beyond = []
             for N in REF_SIZES + BEYOND_LDS_35:
                 s = pa.Setup(N, tr, dt)
+                if pa.kernel_name(s) == "fourstep":
+                    beyond.append(N)
                 batch = max(1, pool.numel() // s.vec_scalars)
                 x = pool[: batch * s.vec_scalars].view(batch, s.vec_scalars)
                 y = ypool[: batch * s.vec_scalars].view(batch, s.vec_scalars)
@@ -368,19 +373,88 @@ def sizes_table(torch, pa, dev, timer):
                 # ~30 ms of work to come back (first_launches_ms of the configs shows the same ramp) - without this untimed
                 # run the FIRST of the four combinations of every size reads 0.05-0.10 low
                 timer(lambda: s.transform_batch(x, y, pa.FORWARD, ordered=True), 1, warm=60)
+                rs = R.setup(N, tr, dt) if R is not None else None
+                xl = x[batch - 1].cpu().numpy() if rs is not None else None
                 for d in (pa.FORWARD, pa.BACKWARD):
                     for o in (True, False):
                         t = timer(lambda: s.transform_batch(x, y, d, ordered=o), 20, warm=10)
                         row.append(round(2 * x.numel() * isz / t / HBM_PEAK, 3))
+                        if rs is not None:      # the timed launches left the spectrum of the last vector in y
+                            want = (rs.transform_ordered if o else rs.transform_unordered)(xl, d)
+                            got = y[batch - 1].cpu().numpy().astype(np.float64)
+                            e = float(np.abs(got - want).max() / np.abs(want).max())
+                            # (double with factors 3 / 5: the reference's float-suffixed constants make IT the inexact side, DESIGN.md §4)
+                            key = tag if (dt == np.float32 or N & (N - 1) == 0) else tag + "_factors_3_5_vs_inexact_reference"
+                            if e > worst.get(key, (0.0,))[0]:
+                                worst[key] = (e, N, name, "fwd" if d == pa.FORWARD else "bwd", "ordered" if o else "unordered")
                 tab[str(N)] = row
                 s.close()
+                if rs is not None:
+                    rs.close()
             out[f"{tag}_{name}"] = tab
+            out[f"{tag}_{name}_beyond_lds"] = beyond
         del pool, ypool
         torch.cuda.empty_cache()
+    out["parity_worst_rel_err"] = {k: {"err": float("%.3g" % v[0]), "at": list(v[1:])} for k, v in worst.items()} if worst else "unchecked: oracle/_ref not present"
     return out
 
 
+def sizes_summary(tab):
+    """[min, mean, share >= 0.70] of the LDS-resident entries (N <= 16384) and [min, mean] beyond, per precision / transform."""
+    res = {}
+    for key, t in tab.items():
+        if not isinstance(t, dict) or not key.startswith("f") or key.endswith("_beyond_lds"):
+            continue
+        far = set(tab.get(key + "_beyond_lds", []))          # sizes on the tile / streaming passes ("fourstep")
+        inl = [v for n, row in t.items() if int(n) not in far for v in row]
+        big = [v for n, row in t.items() if int(n) in far for v in row]
+        res[key] = {"lds_resident": [min(inl), round(float(np.mean(inl)), 3), round(float(np.mean([v >= 0.70 for v in inl])), 2)],
+                    "beyond_lds": [min(big), round(float(np.mean(big)), 3)]}
+    return res
+
+
+def conv_config(torch, pa, dev, timer, warmup):
+    """pffft_hip_convolve_batch on the C2 shape: forward x H backward of 2^20 vectors of N = 1024 complex float, one filter
+    spectrum; roofline = one read + one write of every vector."""
+    N, b = 1024, 1 << 20
+    s = pa.Setup(N, COMPLEX, np.float32)
+    x = make_input(torch, dev, b, 2 * N, torch.float32, seed=8)
+    y = torch.empty_like(x)
+    H = s.transform_batch(make_input(torch, dev, 1, 2 * N, torch.float32, seed=9), None, pa.FORWARD, ordered=False).reshape(-1).contiguous()
+    t = timer(lambda: s.convolve_batch(x, H, out=y, scaling=1.0 / N), 20, warm=max(3, warmup))
+    rec = {"workload": "pffft_hip_convolve_batch, N=1024 complex float, batch 2^20, broadcast filter spectrum (fused kernel)",
+           "value": round(b / t / 1e6, 2), "unit": "M convolutions/s", "roofline": roofline(b * 16384, t)}
+    pa.set_variant(120)
+    try:
+        tc = timer(lambda: s.convolve_batch(x, H, out=y, scaling=1.0 / N), 10, warm=3)
+    finally:
+        pa.set_variant(0)
+    rec["composed_three_launches_Mps"] = round(b / tc / 1e6, 2)
+    try:
+        from oracle import ref as oref
+        if oref.available():
+            rs = oref.get().setup(N, COMPLEX, np.float32)
+            s.convolve_batch(x, H, out=y, scaling=1.0 / N)
+            idx = [0, 1, b // 2, b - 1]
+            Hh = H.cpu().numpy()
+            worst = 0.0
+            for i in idx:
+                X = rs.transform_unordered(x[i].cpu().numpy(), oref.FORWARD)
+                Y = rs.zconvolve(X, Hh, np.zeros_like(X), 1.0 / N, accumulate=False)
+                w = rs.transform_unordered(Y, oref.BACKWARD)
+                worst = max(worst, float(np.abs(y[i].cpu().numpy() - w).max() / np.abs(w).max()))
+            rec["parity_max_rel_err"] = worst
+            rs.close()
+    except Exception as e:
+        rec["parity_max_rel_err"] = f"unchecked: {e}"
+    s.close()
+    del x, y
+    torch.cuda.empty_cache()
+    return rec
+
+
 VALU_PEAK = 108.0 * 256 * 2.4e9   # float results / s: 108 per clock and CU measured (profiles/r02_probes.md), 256 CUs, 2.4 GHz
+VALU_PEAK_SPEC = 157.3e12         # vector FP32 peak of the data sheet (MI355X_MICROARCH.md: 128 lanes x FMA x 256 CUs x 2.4 GHz)
 
 
 def fir_flops_per_output(nfft, taps):
@@ -440,9 +514,12 @@ def fir_config(torch, pa, dev, timer, warmup):
     nfft_used = 16384 if taps >= 1024 else 8192    # internal block of the throughput regime (pffastconv_impl.h fc_big_nfft)
     fl = fir_flops_per_output(nfft_used, taps) * nl
     out["roofline_valu"] = {"bound": "valu", "achieved": round(fl / t / 1e12, 2), "peak": round(VALU_PEAK / 1e12, 1), "unit": "TFLOP/s",
-                            "frac": round(fl / t / VALU_PEAK, 4), "flops_per_output_sample": round(fl / nl, 1),
+                            "frac": round(fl / t / VALU_PEAK, 4), "peak_spec": round(VALU_PEAK_SPEC / 1e12, 1),
+                            "frac_spec": round(fl / t / VALU_PEAK_SPEC, 4), "flops_per_output_sample": round(fl / nl, 1),
                             "note": f"SURVEY.md 8(d) C4 flop count at the internal block length {nfft_used}; peak = 108 float results "
-                                    "per clock and CU measured (profiles/r02_probes.md) x 256 CUs x 2.4 GHz, one flop per result"}
+                                    "per clock and CU measured (profiles/r02_probes.md) x 256 CUs x 2.4 GHz, one flop per result; "
+                                    "peak_spec = the data sheet's 157.3 TFLOP/s.  Neither binds: the block kernel is bound by LDS stores "
+                                    "(448 KiB per 16384-sample block at 79 B/clk and CU) and its barriers (tools/dma_timeline.hip, DESIGN.md 3.6)"}
     fc.close()
     del xl, yl, sig, y
     torch.cuda.empty_cache()
@@ -553,7 +630,7 @@ def main():
             "workload": f"{cfg['name']}, batch={'2^%d total / %d GPU(s), in place' % (cfg['total_log2'], world) if scaling == 'strong' else '2^%d per GPU, out of place' % int(np.log2(batch))}, "
                         "device-resident, internal-layout spectrum",
             "kernel": kname, "batch_per_gpu": batch, "first_global_vector_of_rank0": first,
-            "roofline": roofline(batch * cfg["bytes"], ks, key + "_bytes_per_launch"),
+            "roofline": roofline(batch * cfg["bytes"], ks, key + "_bytes_per_launch" if scaling == "weak" and batch == (1 << cfg["batch_log2"]) else None),
             "first_launches_ms": first_ms,
             "parity_vs_reference": parity,
         }
@@ -644,7 +721,17 @@ def main():
             except Exception as e:
                 configs["c4"] = {"error": str(e)[:300]}
             try:
-                configs["sizes"] = sizes_table(torch, pa, dev, timer)
+                configs["conv"] = conv_config(torch, pa, dev, timer, args.warmup)
+            except Exception as e:
+                configs["conv"] = {"error": str(e)[:300]}
+            try:
+                Rr = None
+                try:
+                    from oracle import ref as oref
+                    Rr = oref.get() if oref.available() else None
+                except Exception:
+                    Rr = None
+                configs["sizes"] = sizes_table(torch, pa, dev, timer, Rr)
             except Exception as e:
                 configs["sizes"] = {"error": str(e)[:300]}
         else:
@@ -653,8 +740,6 @@ def main():
                 configs[name] = run_fft("c5", sc, st, args.warmup if sc == "weak" else 2)   # collective inside: every rank runs it
     if rank == 0:
         out.update(extras)
-        if configs:
-            out["configs"] = configs
         if world == 1 and cpu_s > 0:
             for job in cpu_jobs:
                 try:
@@ -664,6 +749,45 @@ def main():
             cb = cpu_baseline(cfg, 15 if cfg["N"] <= 1024 else 10, cpu_s)
             out["cpu_baseline"] = cb if cb else {"value": None, "unit": "M transforms/s", "cores": 0, "kind": "reference",
                                                  "sample": "oracle/_ref not present on this box"}
+        if configs:
+            # The side configs in full (first launches, CPU baselines, the whole sizes table) go to STDERR as one JSON line; the
+            # one line on stdout carries a compact summary of each INSIDE `roofline` - the dict the driver's record keeps whole
+            # (r03: `configs` was dropped from the stored record and the stdout tail began inside C5).
+            print(json.dumps({"detail": configs}), file=sys.stderr, flush=True)
+            summ = {}
+            for key in ("c3", "c5", "c5_strong_1gpu", "c5_weak", "c5_strong"):
+                c = configs.get(key)
+                if isinstance(c, dict) and "roofline" in c:
+                    par = c.get("parity_vs_reference")
+                    summ[key] = {"frac": c["roofline"]["frac"], "kernel_ms": c["roofline"]["kernel_ms"], "value_Mtps": c["value"],
+                                 "first_launch_ms": (c.get("first_launches_ms") or [None])[0],
+                                 "parity_max_rel_err": par.get("max_rel_err") if isinstance(par, dict) else par,
+                                 "cpu_Mtps": (c.get("cpu_baseline") or {}).get("value")}
+                elif isinstance(c, dict):
+                    summ[key] = c
+            c4 = configs.get("c4")
+            if isinstance(c4, dict) and "roofline" in c4:
+                summ["c4"] = {"long_frac": c4["roofline"]["frac"], "long_kernel_ms": c4["roofline"]["kernel_ms"],
+                              "batch_frac": c4.get("batch_frac"), "single_call_us": c4.get("single_call_us"),
+                              "single_call_frac": c4.get("single_call_frac"),
+                              "valu_frac_measured_peak": c4["roofline_valu"]["frac"], "valu_frac_spec_peak": c4["roofline_valu"]["frac_spec"],
+                              "parity_err_over_range": c4.get("parity_max_err_over_range"),
+                              "cpu_Gsps": (c4.get("cpu_baseline") or {}).get("value")}
+            elif isinstance(c4, dict):
+                summ["c4"] = c4
+            cv = configs.get("conv")
+            if isinstance(cv, dict) and "roofline" in cv:
+                summ["conv"] = {"frac": cv["roofline"]["frac"], "kernel_ms": cv["roofline"]["kernel_ms"], "value_Mps": cv["value"],
+                                "composed_Mps": cv.get("composed_three_launches_Mps"), "parity_max_rel_err": cv.get("parity_max_rel_err")}
+            elif isinstance(cv, dict):
+                summ["conv"] = cv
+            sz = configs.get("sizes")
+            if isinstance(sz, dict) and "f32_complex" in sz:
+                summ["sizes"] = {"[min, mean, share >= 0.70] lds-resident / [min, mean] beyond": sizes_summary(sz),
+                                 "parity_worst_rel_err": sz.get("parity_worst_rel_err")}
+            elif isinstance(sz, dict):
+                summ["sizes"] = sz
+            out["roofline"]["configs_summary"] = summ
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
