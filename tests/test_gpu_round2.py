@@ -385,7 +385,10 @@ def test_stockham_direct_first_stage_steady_state(ref, dt, tr, N):
     vec_bytes = s.vec_scalars * (4 if dt == np.float32 else 8)
     B = ((4 << 30) if vec_bytes <= 4096 else (1 << 30)) // vec_bytes + 3      # ragged tail
     x = _uniform((B, s.vec_scalars), 500 + N, tdt)
-    idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1})
+    # product build (pffft_hip_has_variants() == 0): selectors 54 / 55 reach the SAME kernel (one variant per plan is instantiated),
+    # so the bit-for-bit comparison below compares a kernel with itself - the reference then checks >= 512 sampled vectors
+    nsamp = 6 if pa.has_variants() else 512
+    idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1} | set(np.random.default_rng(N).integers(0, B, nsamp).tolist()))
     xh = x[idx].cpu().numpy()
     tol = tol_for("f32" if dt == np.float32 else "f64", N)
     try:

@@ -162,3 +162,41 @@ def test_convolve_batch_c2_c5_shapes(ref, dt, tol, N, B):
     g = got[torch.from_numpy(idx).cuda()].cpu().numpy()
     assert (np.abs(g - want).max(axis=1) / np.abs(want).max(axis=1)).max() <= tol
     s.close(); rs.close()
+
+
+# ------------------------------------------------------------------ long batches of the in-order families against the reference
+def _uniform(shape, seed, tdt):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    return torch.rand(shape, device="cuda", dtype=tdt, generator=g) * 2 - 1
+
+
+@pytest.mark.parametrize("dt,tr,N", [(np.float32, pa.COMPLEX, 4320), (np.float32, pa.COMPLEX, 8192), (np.float32, pa.COMPLEX, 8640),
+                                     (np.float64, pa.COMPLEX, 2160), (np.float64, pa.COMPLEX, 3072), (np.float64, pa.COMPLEX, 4096),
+                                     (np.float32, pa.COMPLEX, 480 * 256), (np.float64, pa.COMPLEX, 480 * 128),
+                                     (np.float32, pa.REAL, 16384), (np.float32, pa.COMPLEX, 1024)])
+def test_in_order_families_on_long_ragged_batches(ref, dt, tr, N):
+    """The kernels that pull their groups in order from the {next, done} counter pair run MANY iterations per workgroup here
+    (>= 4 x the groups one grid of resident workgroups takes at once, ragged tail): the large Stockham plans switched to in-order
+    pulling in round 3 (float n = 4320 / 8192 / 8640, double n = 2160 / 3072 / 4096), tile passes of 60 KiB and more (L = 480
+    column / row tiles), the register-tiled family (C3's size) and the headline kernel.  >= 512 sampled vectors against
+    oracle/_ref in all four direction / layout combinations (the every-size walks use batches of 2 - 3)."""
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    s = pa.Setup(N, tr, dt)
+    rs = ref.setup(N, tr, dt)
+    vec_bytes = s.vec_scalars * np.dtype(dt).itemsize
+    B = max(4 * 256 * 4 + 7, (1 << 29) // vec_bytes + 7)          # >= 4 groups per resident workgroup slot, ragged
+    x = _uniform((B, s.vec_scalars), 40 + N % 1000, tdt)
+    rng = np.random.default_rng(N)
+    idx = sorted({0, 1, 2, B // 2, B - 3, B - 2, B - 1} | set(rng.integers(0, B, 512).tolist()))
+    it = torch.tensor(idx, device="cuda")
+    xh = x[it].cpu().numpy()
+    tol = (1e-5 if dt == np.float32 else 1e-12) if N & (N - 1) == 0 or dt == np.float32 else 2e-7
+    for d in (pa.FORWARD, pa.BACKWARD):
+        for o in (False, True):
+            y = s.transform_batch(x, None, d, o)
+            got = y[it].cpu().numpy().astype(np.float64)
+            want = rs.batch(xh, d, o)
+            err = (np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)).max()
+            assert err <= tol, (N, d, o, err)
+            del y
+    s.close(); rs.close()
