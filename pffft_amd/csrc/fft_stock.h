@@ -412,6 +412,7 @@ __device__ __forceinline__ void sk_run(const StockStage& st, const SkArgs<T>& a)
         case 5: sk_stage<T, 5, SRC, DST>(st, a); break;
         case 6: sk_stage<T, 6, SRC, DST>(st, a); break;
         case 8: sk_stage<T, 8, SRC, DST>(st, a); break;
+        case 9: sk_stage<T, 9, SRC, DST>(st, a); break;
         case 10: sk_stage<T, 10, SRC, DST>(st, a); break;
         case 12: sk_stage<T, 12, SRC, DST>(st, a); break;
         default:
@@ -438,6 +439,7 @@ __device__ __forceinline__ void sk_run_last_real(const StockStage& st, const SkA
         case 5: sk_last_real<T, 5, DST>(st, a); break;
         case 6: sk_last_real<T, 6, DST>(st, a); break;
         case 8: sk_last_real<T, 8, DST>(st, a); break;
+        case 9: sk_last_real<T, 9, DST>(st, a); break;
         case 10: sk_last_real<T, 10, DST>(st, a); break;
         case 12: sk_last_real<T, 12, DST>(st, a); break;
         default:
@@ -460,6 +462,7 @@ __device__ __forceinline__ void sk_run_first_real(const StockStage& st, const Sk
         case 5: sk_first_real<T, 5, SRC>(st, a); break;
         case 6: sk_first_real<T, 6, SRC>(st, a); break;
         case 8: sk_first_real<T, 8, SRC>(st, a); break;
+        case 9: sk_first_real<T, 9, SRC>(st, a); break;
         case 10: sk_first_real<T, 10, SRC>(st, a); break;
         case 12: sk_first_real<T, 12, SRC>(st, a); break;
         default:

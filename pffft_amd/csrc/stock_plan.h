@@ -155,6 +155,15 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         sk_search(n, 0, setf32, cur2, best2);
         if (!best2.empty() && best2.size() < best.size()) best = best2;
     }
+    if (best.empty()) {
+        // n = 16 x 3^5 (3888) and 32 x 3^5 (7776) have no plan within four stages in the radices above (the reference's decompose(),
+        // src/pffft_priv_impl.h:904-928, takes any 2^a 3^b 5^c): radix 9 (3 x 3 with constant twiddles, cxmath.h dft_ct) gives them
+        // 3 x 9 x 9 x 16 / 6 x 9 x 9 x 16 - one HBM pass instead of the three streaming passes (0.16-0.24 of the roofline, round 3)
+        static const std::vector<int> setf9 = {16, 15, 12, 10, 9, 8, 6, 5, 4, 3};
+        static const std::vector<int> setd9 = {12, 10, 9, 8, 6, 5, 4, 3};
+        cur.clear();
+        sk_search(n, 0, is_double ? setd9 : setf9, cur, best);
+    }
     if (best.size() < 2 || best.size() > SK_MAX_STAGES) return false;
     const int nchk = n * esz / 16;
     // small n: wave-local kernel, 4 wavefronts per workgroup, each owning Gw vectors (<= 4 KiB, or one vector)

@@ -36,8 +36,8 @@ def expected_family(N, transform, dt):
     if n & (n - 1) == 0:
         return "tiled" if n * esz <= 128 * 1024 else "fourstep"
     # mixed-radix Stockham plans: two exchange images in LDS (n * esz <= 80 000 B); n = 16 * 3^5 (* 2) has no plan in
-    # radices 3 .. 24 within four stages and takes the streaming passes
-    if n * esz <= 80000 and n not in (3888, 7776):
+    # radices 3 .. 24 within four stages: radix 9 (round 4: 3 x 9 x 9 x 16, 6 x 9 x 9 x 16)
+    if n * esz <= 80000:
         return "stockham"
     return "fourstep"
 
