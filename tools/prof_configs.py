@@ -24,10 +24,31 @@ x = torch.empty(1 << 26, device="cuda").uniform_(-1, 1); y = torch.empty_like(x)
 for _ in range(reps + 1):
     fc.apply(x, True, out=y)
 torch.cuda.synchronize()
-fc.close(); del x, y; torch.cuda.empty_cache()
+xb = torch.empty(256, 1 << 20, device="cuda").uniform_(-1, 1); yb = torch.empty_like(xb)
+for _ in range(reps + 1):
+    fc.apply_batch(xb, True, out=yb)                          # the same split kernel on 256 signals of 2^20 (tools/pmc_r04.py: second half of its dispatches)
+torch.cuda.synchronize()
+xs = xb[0].contiguous(); ys = torch.empty_like(xs)
+for _ in range(4 * reps):
+    fc.apply(xs, True, out=ys)                                # the stated C4 call: 255 reference-sized blocks, fused kernel
+torch.cuda.synchronize()
+fc.close(); del x, y, xb, yb; torch.cuda.empty_cache()
+fw = pa.FastConv(np.random.default_rng(5).uniform(-1, 1, 200).astype(np.float32), 0, 0)
+x = torch.empty(1 << 26, device="cuda").uniform_(-1, 1); y = torch.empty_like(x)
+for _ in range(reps + 1):
+    fw.apply(x, True, out=y)                                  # one wavefront per 2048-sample block (round 3)
+torch.cuda.synchronize()
+fw.close(); del x, y; torch.cuda.empty_cache()
+s = pa.Setup(1024, pa.COMPLEX, np.float32)
+x = torch.empty(1 << 20, 2048, device="cuda").uniform_(-1, 1); y = torch.empty_like(x)
+H = s.transform_batch(x[:1].contiguous(), None, pa.FORWARD, False).reshape(-1).contiguous()
+for _ in range(reps + 1):
+    s.convolve_batch(x, H, out=y, scaling=1.0 / 1024)         # round 4: forward x H backward in one kernel
+torch.cuda.synchronize()
+s.close(); del x, y; torch.cuda.empty_cache()
+fft(3888, pa.COMPLEX, np.float32, 34521, ordered=False)       # round 4: Stockham plan with a radix-9 stage
 fft(1 << 16, pa.COMPLEX, np.float32, 2048, ordered=True)
 fft(1 << 16, pa.COMPLEX, np.float32, 2048, ordered=False)     # round 3: the last tile pass stores the internal layout itself
 fft(1 << 20, pa.COMPLEX, np.float32, 128, ordered=True)
 fft(1 << 18, pa.REAL, np.float32, 1024, ordered=False)        # round 3: pair pass + internal layout as one block-kernel sweep
 fft(4000, pa.COMPLEX, np.float32, 1 << 15, ordered=False)     # a mixed-radix Stockham plan (workgroup kernel)
-fft(115200, pa.COMPLEX, np.float32, 1165, ordered=True)        # round 3: 480 x 240, both tile passes with an odd first stage (radix 15)
