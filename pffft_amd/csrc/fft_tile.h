@@ -40,6 +40,11 @@ struct TileDesc {
     // ragged last tile along a (float only: a tile is 16 sequences, a tile length may be 8 mod 16): 16-byte units of sequences
     // that exist in tile a = TA - 1 (every other tile: all of them).  0 = not ragged.
     unsigned last_units;
+    // tiles per grab of the work counter (1 or 2).  2 for the column tiles with 64-byte runs (8 float / 4 double columns): two
+    // adjacent tiles share every 128-byte line of their point rows, and taken by DIFFERENT workgroups they are fetched through
+    // two XCDs' L2s - rocprofv3 counted 1.456 x the algorithmic bytes on pass A of N = 2^20 (profiles/r03_pmc.md); one workgroup
+    // taking both, back to back, finds the second half in its own L2
+    unsigned group;
 };
 
 template <typename T> struct TileUnit;                // one 16-byte LDS / global unit
@@ -211,7 +216,9 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     // prefetch knows its tile.  ctr == nullptr: static stride.
     unsigned* s_next = reinterpret_cast<unsigned*>(w3 + ((lv3 ? 3 : 2) << WB));
     const bool dyn = ctr != nullptr;
-    unsigned long long tile = blockIdx.x, tile1 = (unsigned long long)blockIdx.x + gridDim.x;
+    // ids of the counter / the static stride are GROUPS of K consecutive tiles: gcur = the group in work, gnext = the one after
+    const unsigned K = D.group > 1 ? D.group : 1u;
+    unsigned long long gcur = blockIdx.x, gnext = (unsigned long long)blockIdx.x + gridDim.x;
     unsigned pend = 0;
     if (dyn) {
         if (tid == 0) {
@@ -220,16 +227,19 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
             pend = atomicAdd(&ctr[0], 1u);
         }
         __syncthreads();
-        tile = s_next[0]; tile1 = s_next[1];
+        gcur = s_next[0]; gnext = s_next[1];
         __syncthreads();
     }
+    unsigned sub = 0;                                 // tile of the group in work
+    unsigned long long tile = gcur * K, tile1 = K > 1 ? tile + 1 : gnext * K;
     LD nxt[NLD];
     if constexpr (PF) {
         if (tile < ntiles) { const CX* s0; CX* d0; unsigned cc; unsigned long long e0 = 0; int pv0; tile_bases(tile, s0, d0, cc, e0, pv0); issue_loads(s0, nxt, e0, pv0); }
     }
+    unsigned gi = 0;                                  // groups begun so far
     for (unsigned it = 0; tile < ntiles; ++it) {
-        if (dyn && tid == 0) {
-            s_next[it & 1] = pend;                   // tile of iteration it + 2, read by everyone after the first barrier below
+        if (dyn && tid == 0 && sub == 0) {
+            s_next[gi & 1] = pend;                   // the group after the next one, read by everyone after the first barrier below
             pend = atomicAdd(&ctr[0], 1u);
         }
         const CX* src; CX* dst; unsigned col0; unsigned long long ebase = 0;
@@ -478,9 +488,13 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
             if (pu < pv) __builtin_nontemporal_store(img[pt * PITCH + pu], reinterpret_cast<U*>(dst + (unsigned long long)pt * D.ops + S * pu));
         }
         }
-        const unsigned long long tile2 = dyn ? (unsigned long long)s_next[it & 1] : tile1 + gridDim.x;
+        // next tile: the group's next one, or the first of the next group (whose successor was published at this group's start)
+        unsigned long long gnn = gnext;
+        if (sub + 1 == K) gnn = dyn ? (unsigned long long)s_next[gi & 1] : gnext + gridDim.x;
         __syncthreads();
-        tile = tile1; tile1 = tile2;
+        tile = tile1;
+        if (++sub == K) { sub = 0; gcur = gnext; gnext = gnn; ++gi; }
+        tile1 = sub + 1 < K ? tile + 1 : gnext * K;
     }
     if (dyn && tid == 0) {
         __threadfence();

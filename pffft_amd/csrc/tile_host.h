@@ -39,13 +39,14 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     int per_cu = 0;
     if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), G::WG, lds, &per_cu))) return rc;
     unsigned long long grid = (unsigned long long)num_cus() * per_cu;
-    if (grid > ntiles) grid = ntiles;
+    const unsigned long long ngroups = D.group > 1 ? (ntiles + D.group - 1) / D.group : ntiles;   // the counter hands out groups of tiles
+    if (grid > ngroups) grid = ngroups;
     // in-order tiles only where a tile is 64 KiB or more: one counter address serves ~80 M atomics/s, so 16-32 KiB tiles
     // are throttled by the grab (2^15: 0.30 static, 0.20 in order; 2^18 .. 2^20: 0.27-0.31 / 0.19 static, 0.29-0.32 / 0.24 in
     // order).  PFFFT_HIP_TILE_DYN=0/1 forces it (A/B).
     static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_TILE_DYN"); return e ? atoi(e) : -1; }();
     const bool want_dyn = dyn_env >= 0 ? dyn_env != 0 : (size_t)G::L * G::C * sizeof(cx<T>) >= 60 * 1024;   // (L = 480: 60 KiB)
-    unsigned* ctr = (ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = (ngroups <= grid || !want_dyn || ntiles >= 0xfffffff0ull) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D, ctr);
     PF_CHECK(hipGetLastError());
     return 0;

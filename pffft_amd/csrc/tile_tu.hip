@@ -89,6 +89,11 @@ static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long lon
     D.vstride = tl.len() * cols;
     D.in_a = C; D.out_a = C; D.ips = cols; D.iss = 1; D.ops = cols;
     D.col_a = (unsigned)C; D.M = D.vstride; D.seq_contig = 1;
+    // 64-byte runs (L = 1024: 8 float / 4 double columns per tile): adjacent tiles in pairs per grab (TileDesc::group; TA even so that
+    // a pair never straddles two vectors) - built in round 4 against the 1.456 x traffic of this pass, measured SLOWER (N = 2^20 complex
+    // float 0.236 -> 0.211, double 0.248 -> 0.226, real 2^21 0.181 -> 0.162): off; PFFFT_HIP_TILE_GROUP=2 switches it on (A/B)
+    static const int g_env = [] { const char* e = getenv("PFFFT_HIP_TILE_GROUP"); return e ? atoi(e) : 1; }();
+    D.group = (pp == 4 && D.TA % 2 == 0 && !D.last_units && g_env == 2) ? 2u : 1u;
     const unsigned long long ntiles = nvec * D.TA;
     return tile_any<T>(tl, pp, in, out, ntiles, D, dir, st, s, false, in_int);
 }
