@@ -45,6 +45,10 @@ struct TileDesc {
     // two XCDs' L2s - rocprofv3 counted 1.456 x the algorithmic bytes on pass A of N = 2^20 (profiles/r03_pmc.md); one workgroup
     // taking both, back to back, finds the second half in its own L2
     unsigned group;
+    // real transforms in two sweeps (RMODE, round 4): output vector stride when it differs from the input's (0 = the same), and the
+    // column length N1 of the real four-step split (rows k1 <= N1 / 2 exist)
+    unsigned long long ovstride;
+    unsigned rn1;
 };
 
 template <typename T> struct TileUnit;                // one 16-byte LDS / global unit
@@ -116,7 +120,15 @@ template <int WB, typename CX> __device__ __forceinline__ CX tile_w3(const CX* w
 //   DPP exchange turns the (re group, im group) units into the image's (re, im) sequence units.
 // RAG = 1 (float only): the last tile along a may be ragged (TileDesc::last_units); RAG = 0 compiles the predicates away (they cost
 // the L = 512 kernels 4 % when left to run time)
-template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0, int IINT = 0, int R0 = 1, int RAG = 0>
+// RMODE (round 4, power-of-two L): REAL transforms of N = N1 N2 points in TWO sweeps.  The real vector is the
+// N1 x N2/2 complex matrix z[j1][m] = (x[j1 N2 + 2m], x[j1 N2 + 2m + 1]): adjacent real columns in pairs.
+//   1 (pass A, forward): column transforms of length L = N1 as always; the spectra of the two real columns of every complex column
+//     are split off INSIDE the tile - E = (C[k1] + conj C[N1 - k1]) / 2, O = -i (C[k1] - conj C[N1 - k1]) / 2, the mirror is in the same
+//     column -, twiddled by W_N^(k1 j2) and stored as rows k1 = 0 .. N1/2 of N2 complex values (runs of 2 C adjacent values)
+//   2 (pass B, forward): row transforms of length L = N2 of the rows k1 <= N1/2: X[k1 + N1 k2]; k2 < N2/2 goes straight to its bin, k2 >=
+//     N2/2 conjugated to bin N - k = (N1 - k1) + N1 (N2 - 1 - k2) (Hermitian symmetry: the rows k1 > N1/2 are never computed) - every
+//     tile stores to two places instead of needing its mirror tile; bin 0 carries (DC, Nyquist) (include/pffft/pffft.h:144-155)
+template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0, int IINT = 0, int R0 = 1, int RAG = 0, int RMODE = 0>
 __global__ void __launch_bounds__((R0 << LOGL) / 8 * PP, PF ? 2 : 3)
 tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned long long ntiles, TileDesc D, unsigned* ctr) {
     typedef cx<T> CX;
@@ -170,6 +182,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
         if constexpr (IINT) { eb = a * D.in_a + b * D.in_b; src = in + vec * D.vstride; }
         else src = in + vec * D.vstride + a * D.in_a + b * D.in_b;
         if constexpr (OINT) { eb = a * D.out_a + b * D.out_b; dst = out + vec * D.vstride; }
+        else if constexpr (RMODE != 0) { eb = a; dst = out + vec * D.ovstride; }               // the epilogue addresses the vector itself
         else dst = out + vec * D.vstride + a * D.out_a + b * D.out_b;
         col0 = a * D.col_a + b * D.col_b;
     };
@@ -419,7 +432,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                     }
                     dftR<R, DIR>(o[sq]);
                 }
-                if constexpr (SEQC && s == NS - 1 && NS > 1) {
+                if constexpr (SEQC && s == NS - 1 && NS > 1 && RMODE != 1) {
                     // the last stage is a radix 8 with one butterfly per thread: outputs k = t + d L/8
                     static_assert(R == 8 && B == 1 && Ns == L / 8, "last stage shape");
                     const CX A = tile_w3<WB>(w3, (unsigned)t * col0, lv3), Bc = tile_w3<WB>(w3, (unsigned)(L / 8) * col0, lv3);
@@ -456,7 +469,97 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
         if constexpr (NS > 4) stage(std::integral_constant<int, 4>{});
         __syncthreads();
         // ---- the image holds the spectrum [k][sequence]: runs of C adjacent sequences per point
-        if constexpr (OINT) {
+        if constexpr (RMODE == 1) {
+            // one item = (row k1 <= L/2, unit pu): the unit's S complex columns are 2 S real columns -> 2 S values of output row k1,
+            // 32 bytes per lane, consecutive lanes consecutive: runs of 2 C values
+            static_assert(RMODE != 1 || (SEQC && DIR == FWD && R0 == 1 && !OINT && !IINT), "real split: forward column pass");
+            constexpr int ITEMS = (L / 2 + 1) * PP;
+            const unsigned long long N2 = 2ull * D.ips;                      // values per output row (D.ips = complex columns of the input)
+#pragma unroll
+            for (int i = 0; i < (ITEMS + WG - 1) / WG; ++i) {
+                const int g = tid + i * WG;
+                if (g >= ITEMS) break;
+                const int k1 = g / PP, pu = g % PP;
+                const U u = img[k1 * PITCH + pu], m = img[((L - k1) & (L - 1)) * PITCH + pu];
+                const unsigned mc = col0 + (unsigned)(S * pu);              // first complex column of the unit
+                CX tw = tile_w3<WB>(w3, (unsigned)k1 * (2u * mc), lv3);     // W_N^(k1 j2), j2 = 2 mc, then j2 + 1, ...
+                const CX wk = tile_w3<WB>(w3, (unsigned)k1, lv3);
+                CX y[2 * S];
+#pragma unroll
+                for (int sq = 0; sq < S; ++sq) {
+                    const CX ck = TU::get(u, sq), cm = conj(TU::get(m, sq));
+                    const CX e = (ck + cm) * (T)0.5, dm = (ck - cm) * (T)0.5;
+                    const CX o = mk<T>(dm.y, -dm.x);                         // -i dm
+                    y[2 * sq] = cmul(e, tw); tw = cmul(tw, wk);
+                    y[2 * sq + 1] = cmul(o, tw); tw = cmul(tw, wk);
+                }
+                U o0, o1;
+                if constexpr (S == 2) { TU::set(o0, 0, y[0]); TU::set(o0, 1, y[1]); TU::set(o1, 0, y[2]); TU::set(o1, 1, y[3]); }
+                else { TU::set(o0, 0, y[0]); TU::set(o1, 0, y[1]); }
+                U* dp = reinterpret_cast<U*>(dst + (unsigned long long)k1 * N2 + 2ull * mc);
+                __builtin_nontemporal_store(o0, dp);
+                __builtin_nontemporal_store(o1, dp + 1);
+            }
+        } else if constexpr (RMODE == 2) {
+            static_assert(RMODE != 2 || (!SEQC && DIR == FWD && R0 == 1 && !OINT && !IINT), "real Hermitian store: forward row pass");
+            const unsigned N1 = D.rn1, k10 = (unsigned)ebase * (unsigned)C;   // ebase = tile index a along the rows
+            const CX* imgc = reinterpret_cast<const CX*>(img);
+            // direct half, k2 < L/2: bin k1 + N1 k2, units of S adjacent k1
+#pragma unroll
+            for (int i = 0; i < (L / 2) * PP / WG; ++i) {
+                const int g = tid + i * WG, pt = g / PP, pu = g % PP;
+                U x = img[pt * PITCH + pu];
+                const unsigned k1 = k10 + (unsigned)(S * pu);
+                if (k1 == 0 && pt == 0) {            // bin 0 = (DC, Nyquist): X[0] and X[N/2] = row 0, k2 = L/2, both real
+                    const CX ny = imgc[(L / 2) * (PITCH * S)];
+                    CX b0 = TU::get(x, 0);
+                    b0.y = ny.x;
+                    TU::set(x, 0, b0);
+                }
+                CX* dp = dst + (unsigned long long)pt * N1 + k1;
+                if (k1 + (S - 1) <= N1 / 2) __builtin_nontemporal_store(x, reinterpret_cast<U*>(dp));
+                else if (k1 <= N1 / 2) *dp = TU::get(x, 0);                  // (the last row N1/2 of the last tile: its unit partner does not exist)
+            }
+            // mirrored half, k2 >= L/2, rows 0 < k1 < N1/2: conj X -> bin (N1 - k1) + N1 (L - 1 - k2).  The run of a tile's C rows is
+            // DESCENDING in k1 and off by one element against the 16-byte grid (N - k): float stores the C/2 - 1 aligned pairs inside
+            // it as 16-byte units and only the two end elements alone (8-byte stores of all 16 measured the pass at 630 us per GiB
+            // against 441 for the plain row pass); double: an element is a unit
+            if (k10 + (unsigned)C <= N1 / 2 + (unsigned)C - 1 && k10 < N1 / 2) {      // (the last tile holds row N1/2 only: nothing to mirror)
+                if constexpr (S == 2) {
+                    constexpr int IPP = C / 2 + 1;                                   // items per point: C/2 - 1 units + 2 end elements
+#pragma unroll
+                    for (int i = 0; i < ((L / 2) * IPP + WG - 1) / WG; ++i) {
+                        const int g = tid + i * WG;
+                        if (g >= (L / 2) * IPP) break;
+                        const int pt = L / 2 + g / IPP, j = g % IPP;
+                        const CX* row = imgc + pt * (PITCH * S);
+                        CX* rbase = dst + (unsigned long long)N1 * (unsigned)(L - 1 - pt) + (N1 - k10 - (unsigned)(C - 1));   // bin of sequence C - 1
+                        if (j < C / 2 - 1) {                                          // bins rbase + 1 + 2j, + 2 + 2j = sequences C - 2 - 2j, C - 3 - 2j
+                            const unsigned sa = (unsigned)(C - 2 - 2 * j);
+                            if (k10 + sa - 1 < N1 / 2) {                              // (both rows below N1/2; k10 + sa - 1 >= 1 always)
+                                U o;
+                                TU::set(o, 0, conj(row[sa])); TU::set(o, 1, conj(row[sa - 1]));
+                                __builtin_nontemporal_store(o, reinterpret_cast<U*>(rbase + 1 + 2 * j));
+                            } else if (k10 + sa < N1 / 2) {
+                                rbase[1 + 2 * j] = conj(row[sa]);
+                            }
+                        } else if (j == C / 2 - 1) {                                  // sequence C - 1: the run's first bin
+                            if (k10 + (unsigned)(C - 1) < N1 / 2) rbase[0] = conj(row[C - 1]);
+                        } else {                                                      // sequence 0: the run's last bin (row 0 has no mirror)
+                            if (k10 >= 1) rbase[C - 1] = conj(row[0]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < (L / 2) * C / WG; ++i) {
+                        const int g = tid + i * WG, pt = L / 2 + g / C, sq = g % C;
+                        const unsigned k1 = k10 + (unsigned)sq;
+                        if (k1 >= 1 && k1 < N1 / 2)
+                            dst[(unsigned long long)(N1 - k1) + (unsigned long long)N1 * (unsigned)(L - 1 - pt)] = conj(imgc[pt * (PITCH * S) + sq]);
+                    }
+                }
+            }
+        } else if constexpr (OINT) {
             // one item = ONE 16-byte unit of the layout, consecutive lanes = consecutive units: every store instruction is
             // dense (two stores per lane, 16 bytes each at a 32-byte stride, measured 0.25 against 0.31 for the canonical store).  The units of a point k' < L/4 form a run of C/4 whole blocks.
             constexpr int BPT = C / 4, UPB = 2 * (int)sizeof(T);               // blocks per point; 16-byte units per block: 8 (float) / 16 (double)

@@ -103,6 +103,12 @@ int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, i
 // has none.  which: 0 = adopted, 1 .. = measured alternatives
 int launch_tiled_mw(Setup* s, const void* in, void* out, size_t batch, int dir, int ordered, hipStream_t st, int which);
 
+// tile_real_tu.hip: REAL transforms beyond LDS in two sweeps (fft_tile.h RMODE): N real points -> canonical half spectrum through a
+// work buffer of tile_rfft_work_elems(N) complex elements per vector; -1: no plan for this length / direction
+int launch_tile_rfft(Setup* s, const void* in, void* work, void* out, size_t batch, long long N, int dir, hipStream_t st);
+bool tile_rfft_has_plan(long long N, bool is_double, bool adopted = true);   // adopted: only where it measured faster
+size_t tile_rfft_work_elems(long long N, bool is_double);
+
 // conv_tu.hip: forward -> x H (one filter spectrum, internal layout) -> backward in ONE kernel (fft_conv.h); -1: no fused kernel
 int launch_conv_fused(Setup* s, const void* in, const void* H, void* out, size_t batch, double scaling, int accumulate, hipStream_t st);
 

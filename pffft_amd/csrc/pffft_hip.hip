@@ -844,7 +844,13 @@ static int launch_block(Setup* s, int mode, const T* in, T* out, size_t batch, h
 // internal layout composed around it (fft_big.h)
 template <typename T>
 static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
-    const size_t bytes = batch * (size_t)s->n * sizeof(cx<T>);
+    size_t bytes = batch * (size_t)s->n * sizeof(cx<T>);
+    // real forward into the canonical spectrum, power-of-two N = 2^16 .. 2^20: two sweeps where they measured faster
+    // (tile_real_tu.hip; variant 121 = always the three sweeps - complex transform + pair sweep -, 122 = two sweeps wherever the
+    // length splits, A/B and tests).  Its work rows (k1 <= N1/2, whole row tiles) need a little more than n.
+    const bool rfft2 = s->transform == PFFFT_REAL && dir == PFFFT_FORWARD && ordered && g_variant != 121 && g_variant != 80 &&
+                       g_variant != 82 && tile_rfft_has_plan(2LL * s->n, s->is_double != 0, g_variant != 122);
+    if (rfft2) bytes = std::max(bytes, batch * tile_rfft_work_elems(2LL * s->n, s->is_double != 0) * sizeof(cx<T>));
     cx<T>*bufA, *bufB;
     // big_mu is held until EVERY pass of this call is enqueued: it guards host-side enqueue only, and a second thread
     // growing the same stream's scratch (hipFree synchronises with the device) can then never free buffers whose kernels
@@ -877,6 +883,10 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     }
     const bool real = s->transform == PFFFT_REAL;
     const bool fwd = dir == PFFFT_FORWARD;
+    if (rfft2) {
+        const int r2 = launch_tile_rfft(s, in, bufB, out, batch, 2LL * s->n, dir, st);
+        if (r2 != -1) return r2;
+    }
     // (pair pass in place: one pair per thread, every workgroup once, in dispatch order - PFFFT_HIP_PAIR_CAP=1: the persistent
     //  grid-stride launch it replaces, A/B)
     static const int pair_cap = [] { const char* e = getenv("PFFFT_HIP_PAIR_CAP"); return e ? atoi(e) : 0; }();

@@ -200,3 +200,39 @@ def test_in_order_families_on_long_ragged_batches(ref, dt, tr, N):
             assert err <= tol, (N, d, o, err)
             del y
     s.close(); rs.close()
+
+
+# ------------------------------------------------------------------ real transforms beyond LDS in two sweeps (fft_tile.h RMODE)
+@pytest.mark.parametrize("dt,tol", [(np.float32, 1e-5), (np.float64, 1e-12)])
+@pytest.mark.parametrize("lg", [16, 17, 18, 19, 20])
+def test_real_forward_two_sweeps(ref, dt, tol, lg):
+    """Real forward into the canonical half spectrum, N = 2^16 .. 2^20, as TWO tile passes (half spectra split inside the column
+    tiles, Hermitian partner bins stored by the row tiles; variant 122 forces the route for every length that splits, 0 = the
+    adopted table, 121 = complex transform + pair sweep): against the reference, against the three-sweep route, in place,
+    ragged batch, bin 0 = (DC, Nyquist)."""
+    N = 1 << lg
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    s = pa.Setup(N, pa.REAL, dt)
+    rs = ref.setup(N, pa.REAL, dt)
+    B = 5
+    x = _uniform((B, N), 90 + lg, tdt)
+    xh = x.cpu().numpy()
+    from oracle.ref import FORWARD
+    want = rs.batch(xh, FORWARD, True)
+    try:
+        outs = {}
+        for var in (122, 0, 121):
+            pa.set_variant(var)
+            y = s.transform_batch(x, None, pa.FORWARD, True)
+            got = y.cpu().numpy().astype(np.float64)
+            err = (np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)).max()
+            assert err <= tol, (var, lg, err)
+            outs[var] = y
+            z = x.clone()
+            s.transform_batch(z, z, pa.FORWARD, True)
+            assert torch.equal(z, y), (var, lg)
+        den = outs[121].abs().amax(dim=1, keepdim=True)
+        assert float(((outs[122] - outs[121]).abs() / den).max()) <= tol
+    finally:
+        pa.set_variant(0)
+    s.close(); rs.close()
