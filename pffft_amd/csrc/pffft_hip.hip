@@ -24,6 +24,7 @@
 #include "stock_plan.h"
 #include "stock_ct.h"
 #include "stock_df_gen.h"
+#include "stock_grid_gen.h"
 #include "fft_aux.h"
 #include "fft_tiny.h"
 #include "pfdsp_mix.h"
@@ -703,8 +704,20 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
             // resident set.  One group per workgroup (variant 94) is slower (0.32-0.66).
             // PFFFT_HIP_STOCK_GRIDMUL=<m> overrides the factor (A/B).
             static const int gridmul_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_GRIDMUL"); return e ? atoi(e) : 0; }();
+            // Round 4: what the static-stride kernels respond to is the number of GROUPS PER WORKGROUP, not the factor: N = 384 / 768
+            // complex float and N = 640 / 800 double peak at the same ~3-4 groups per workgroup on 0.5 GiB (16 x) and on 1 GiB (32 x)
+            // launches (0.71-0.75 -> 0.77-0.79), real transforms near 8-12, vectors of 32 KiB near 64 (tools/r4_stock_sweep.py,
+            // tools/tune_stock_grid.py).  A measured table per plan (stock_grid_gen.h: groups per workgroup) overrides the size
+            // rule where it beat it by more than the noise; the grid never drops below the resident set.  Variants 210 + k force
+            // SK_ITS[k] groups per workgroup (the tuner's knob), 200 + k the factor 2^k, 208 the size rule alone (A/B).
+            static const int SK_ITS[12] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+            const int tab_its = stock_grid_its(sizeof(T) == 8, (flags & 8) != 0, sp.n);
+            auto by_its = [&](int its) { const size_t want = (groups + (size_t)its - 1) / (size_t)its; if (want > grid) grid = want; };
             if (g_variant == 94) grid = groups;
+            else if (g_variant >= 200 && g_variant <= 207) grid *= (size_t)1 << (g_variant - 200);
+            else if (g_variant >= 210 && g_variant <= 221) by_its(SK_ITS[g_variant - 210]);
             else if (gridmul_env > 0) grid *= (size_t)gridmul_env;
+            else if (tab_its > 0 && g_variant != 208) by_its(tab_its);
             else if ((size_t)sp.n * sizeof(cx<T>) <= 4096) grid *= 16;
             else if ((size_t)sp.n * sizeof(cx<T>) <= 20480) grid *= 8;
             if (grid > groups) grid = groups;
