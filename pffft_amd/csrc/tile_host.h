@@ -40,6 +40,15 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), G::WG, lds, &per_cu))) return rc;
     unsigned long long grid = (unsigned long long)num_cus() * per_cu;
     const unsigned long long ngroups = D.group > 1 ? (ntiles + D.group - 1) / D.group : ntiles;   // the counter hands out groups of tiles
+    // Static-stride passes (tiles below 60 KiB) launch ntiles / 3 workgroups - three tiles each - instead of the resident set (round 4:
+    // what the static-stride Stockham kernels showed, tools/tune_stock_grid.py, holds here too - N = 2^15 complex float 0.31-0.33 ->
+    // 0.33-0.37, N = 15360 0.31 -> 0.36, 61440 0.33 -> 0.36, double 2^15 0.31-0.33 -> 0.34-0.36 at 2 .. 4 tiles per workgroup, back
+    // to the old figures from 16 on).  PFFFT_HIP_TILE_ITS=<k> sets the count, 0 = the resident set (A/B)
+    static const int its_env = [] { const char* e = getenv("PFFFT_HIP_TILE_ITS"); return e ? atoi(e) : 3; }();
+    if (its_env > 0 && (size_t)G::L * G::C * sizeof(cx<T>) < 60 * 1024) {
+        const unsigned long long want = (ntiles + its_env - 1) / its_env;
+        if (want > grid) grid = want;
+    }
     if (grid > ngroups) grid = ngroups;
     // in-order tiles only where a tile is 64 KiB or more: one counter address serves ~80 M atomics/s, so 16-32 KiB tiles
     // are throttled by the grab (2^15: 0.30 static, 0.20 in order; 2^18 .. 2^20: 0.27-0.31 / 0.19 static, 0.29-0.32 / 0.24 in
