@@ -50,19 +50,22 @@ static int split_sub_table(const cx<float>** out) {
     return 0;
 }
 
-template <int PSYNC, int SPREAD>
+template <int PSYNC, int SPREAD, int W = 8>
 static int fir_split(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen,
                      int lastOut, hipStream_t st, const FcBatch& fb) {
-    auto k = fastconv_split_kernel<PSYNC, SPREAD>;
-    int rc = allow_big_lds(k, SplitFir::LDS_BYTES);
+    typedef SplitFirT<W> S;
+    auto k = fastconv_split_kernel<PSYNC, SPREAD, W>;
+    int rc = allow_big_lds(k, S::LDS_BYTES);
     if (rc) return rc;
     const cx<float>* tw1024 = nullptr;
     if ((rc = split_sub_table(&tw1024))) return rc;
+    int per_cu = 0;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), S::WG, S::LDS_BYTES, &per_cu))) return rc;
     const size_t groups = (size_t)nblk * fb.nsig;
-    size_t grid = (size_t)num_cus();
+    size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
     unsigned* ctr = groups <= grid ? nullptr : ps->d_ctr + 2 * (ps->ctr_slot.fetch_add(1) % CTR_RING);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(SplitFir::WG), SplitFir::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(S::WG), S::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
                        nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, tw1024, (const cx<float>*)ps->d_twr, ctr,
                        fb.nsig, fb.xstride, fb.ystride);
     PF_CHECK(hipGetLastError());
@@ -74,7 +77,11 @@ int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, i
                    hipStream_t st, const FcBatch& fb) {
     switch (ps->n) {
         case 2048: return fir_dma_cfg<DmaCfgF32::D2048>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-        case 4096: return fir_dma_cfg<DmaCfgF32::D4096>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+        case 4096:
+            // (the split kernel on FOUR wavefronts and 8192-sample blocks, two workgroups per CU - fft_split.h W = 4, tools/dma_timeline.hip -
+            //  moves 6 % more samples per CU and second than the eight-wavefront one: not enough to pay for 75 % instead of 87 % overlap-save
+            //  efficiency at 2048 taps (0.394 against 0.428); not instantiated here)
+            return fir_dma_cfg<DmaCfgF32::D4096>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
         case 8192:
             // 16384-sample blocks: cross-wave radix 8 + wave-local 1024-point transforms (fft_split.h); variant 97 = the lock-step
             // LDS-DMA kernel it replaced, 116 = without the pairwise flags and the spread pieces (A/B)

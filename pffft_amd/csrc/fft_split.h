@@ -24,16 +24,22 @@
 
 namespace pf {
 
-struct SplitFir {
+// W = 8: 16384-sample blocks, one 512-thread workgroup per CU;  W = 4: 8192-sample blocks on 256 threads, TWO workgroups per CU
+// (67 KiB of LDS each) - two barrier domains, one's waits covered by the other's work - for the filters the shorter block still
+// serves at 75 % overlap-save efficiency (<= 2048 taps)
+template <int W> struct SplitFirT {
     typedef TiledCfg<float, 10, 64, 3, 8, 16, 8, 1, 4, 4, 3, 0, 512, 1> Sub;   // the wave-local 1024-point transform
-    static constexpr int n = 8192, M = 1024, WAVES = 8, WG = 512;
+    static constexpr int WAVES = W, M = 1024, n = W * M, WG = 64 * W;
+    static constexpr int CPT = 8 / W;                                          // 16-byte chunks (two adjacent j) per thread and row
     static constexpr int ROW = (Sub::IMG_NAT > Sub::IMG_TRN ? Sub::IMG_NAT : Sub::IMG_TRN) + 8;   // points per wavefront region
-    static constexpr int LAND_BYTES = n * 8;                                   // the landed block: 16384 floats, linear
+    static constexpr int LAND_BYTES = n * 8;                                   // the landed block: 2 n floats, linear
     static constexpr size_t LDS_BYTES = (size_t)LAND_BYTES + (size_t)WAVES * ROW * 8 + 16 + 64;   // + next-group slots + pair flags
     static constexpr int PPW = (LAND_BYTES / 1024) / WAVES;                    // 1 KiB pieces per wavefront
     static_assert(PPW == 8, "the spread schedule places eight pieces");
     static_assert((ROW * 8) % 16 == 0, "rows must keep 16-byte alignment");
+    static_assert(W == 8 || W == 4, "cross-wave radix 8 or 4");
 };
+typedef SplitFirT<8> SplitFir;
 
 // pairwise hand-over through LDS flags (PSYNC): the mirror exchange couples wavefront d with wavefront 8 - d only (0 and 4 with
 // themselves), so the two workgroup barriers around it become waits for ONE partner
@@ -46,8 +52,8 @@ __device__ __forceinline__ void lds_flag_wait(const unsigned* f, unsigned v) {
     asm volatile("" ::: "memory");
 }
 
-template <int PSYNC, int SPREAD = 0>
-__global__ void __launch_bounds__(SplitFir::WG, 2)
+template <int PSYNC, int SPREAD = 0, int W = 8>
+__global__ void __launch_bounds__(SplitFirT<W>::WG, 2)
 fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const cx<float>* __restrict__ Hc,
                       int nblk, int step, int inputLen, int lastOut,
                       const cx<float>* __restrict__ twn,      // W_n^j, j < n
@@ -56,9 +62,10 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
                       unsigned* ctr, int nsig, size_t xstride, size_t ystride) {
     typedef float T;
     typedef cx<T> CX;
-    typedef SplitFir S;
-    typedef Tiled<S::Sub, FWD, 0> KF;
-    typedef Tiled<S::Sub, BWD, 0> KB;
+    typedef SplitFirT<W> S;
+    typedef Tiled<typename S::Sub, FWD, 0> KF;
+    typedef Tiled<typename S::Sub, BWD, 0> KB;
+    constexpr int T_ = S::WG, CPT = S::CPT;
     constexpr int n = S::n, ROW = S::ROW;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
@@ -71,20 +78,22 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     CX* row = rows + (size_t)wave * ROW;
     if (tid < 16) s_next[4 + tid] = 0u;
-    const bool paired = wave != 0 && wave != 4;              // 0 and 4 are their own partners
+    const bool paired = wave != 0 && wave != W / 2;          // 0 and W/2 are their own partners
 
     // ---- per-thread constants
     typename KF::Tw wf;
     typename KB::Tw wb;
     KF::load_tw(wf, lane, tw1024, nullptr);
     KB::load_tw(wb, lane, tw1024, nullptr);
-    const CX wa0 = twn[2 * tid], wa1 = twn[2 * tid + 1];   // W_n^j of this thread's two stage-A butterflies, j = 2 tid + u
+    CX wa[2 * CPT];                                          // W_n^j of this thread's stage-A butterflies, j = 2 (tid + T cc) + u
+#pragma unroll
+    for (int i = 0; i < 2 * CPT; ++i) wa[i] = twn[2 * (tid + T_ * (i >> 1)) + (i & 1)];
     // folded coefficients of this thread's 16 bins k = wave + 8 k2, k2 = 2 lane + u + 128 d (slot u * 8 + d): derivation in
     // fft_fir.h (fastconv_part_kernel); bin 0 = (DC, Nyquist) and bin n/2 are their own mirrors
     CX cA[16], cB[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int k = wave + 8 * (2 * lane + (i >> 3) + 128 * (i & 7));
+        const int k = wave + W * (2 * lane + (i >> 3) + 128 * (i & 7));
         const int km = (n - k) & (n - 1);
         const CX w = k <= n / 2 ? twr[k] : conj(twr[n - k]) * (T)-1;
         const CX Hk = Hc[k], Hm = Hc[km];
@@ -147,46 +156,49 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         const long off = (long)blk * step;
         const int numOut = (blk == nblk - 1) ? lastOut : step;
         float* ys = y + (size_t)sig * ystride;
-        // ================= A: radix 8 across the wavefronts, operands z[2 tid + u + 1024 q] = chunk tid + 512 q of the landed block
-        CX a0[8], a1[8];
+        // ================= A: radix W across the wavefronts, operands z[j + 1024 q], j = 2 c + u, c = tid + T cc: chunk c + 512 q of the landed block
+        // W_n^(j d), d = 1 .. W - 1, from W_n^j by products at most three deep (recomputed in A': the registers would stay pinned)
+        auto powers = [&](int cc, CX (&p0)[W], CX (&p1)[W]) {
+            p0[1] = wa[2 * cc]; p1[1] = wa[2 * cc + 1];
+            asm volatile("" : "+v"(p0[1].x), "+v"(p0[1].y), "+v"(p1[1].x), "+v"(p1[1].y));
+            p0[2] = cmul(p0[1], p0[1]); p0[3] = cmul(p0[2], p0[1]);
+            p1[2] = cmul(p1[1], p1[1]); p1[3] = cmul(p1[2], p1[1]);
+            if constexpr (W == 8) {
+                p0[4] = cmul(p0[2], p0[2]); p0[5] = cmul(p0[4], p0[1]); p0[6] = cmul(p0[3], p0[3]); p0[7] = cmul(p0[4], p0[3]);
+                p1[4] = cmul(p1[2], p1[2]); p1[5] = cmul(p1[4], p1[1]); p1[6] = cmul(p1[3], p1[3]); p1[7] = cmul(p1[4], p1[3]);
+            }
+        };
         {
             const long avail = (long)inputLen - off;         // samples of this block that exist
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int c = tid + 512 * q;
-                const int e0 = 4 * c;
-                const chunk16 cc = land16[c];
-                float f0 = cc.x, f1 = cc.y, f2 = cc.z, f3 = cc.w;
-                if (e0 + 3 >= avail) {     // clamped copy (issue): element k is sample avail - 4 + k of the block
-                    const long sh = (long)e0 - (avail - 4);      // >= 1
-                    f0 = sh == 1 ? cc.y : sh == 2 ? cc.z : sh == 3 ? cc.w : 0.f;
-                    f1 = sh == 1 ? cc.z : sh == 2 ? cc.w : 0.f;
-                    f2 = sh == 1 ? cc.w : 0.f;
-                    f3 = 0.f;
+            for (int cc = 0; cc < CPT; ++cc) {
+                CX a0[W], a1[W];
+#pragma unroll
+                for (int q = 0; q < W; ++q) {
+                    const int c = tid + T_ * cc + 512 * q;
+                    const int e0 = 4 * c;
+                    const chunk16 ck = land16[c];
+                    float f0 = ck.x, f1 = ck.y, f2 = ck.z, f3 = ck.w;
+                    if (e0 + 3 >= avail) {     // clamped copy (issue): element k is sample avail - 4 + k of the block
+                        const long sh = (long)e0 - (avail - 4);      // >= 1
+                        f0 = sh == 1 ? ck.y : sh == 2 ? ck.z : sh == 3 ? ck.w : 0.f;
+                        f1 = sh == 1 ? ck.z : sh == 2 ? ck.w : 0.f;
+                        f2 = sh == 1 ? ck.w : 0.f;
+                        f3 = 0.f;
+                    }
+                    a0[q] = mk<T>(f0, f1);
+                    a1[q] = mk<T>(f2, f3);
                 }
-                a0[q] = mk<T>(f0, f1);
-                a1[q] = mk<T>(f2, f3);
+                dftR<W, FWD>(a0);
+                dftR<W, FWD>(a1);
+                CX p0[W], p1[W];
+                powers(cc, p0, p1);
+#pragma unroll
+                for (int d = 1; d < W; ++d) { a0[d] = cmul(a0[d], p0[d]); a1[d] = cmul(a1[d], p1[d]); }
+#pragma unroll
+                for (int d = 0; d < W; ++d) lds_st2(rows + (size_t)d * ROW + 2 * (tid + T_ * cc), a0[d], a1[d]);
             }
         }
-        dft8<FWD>(a0);
-        dft8<FWD>(a1);
-        // W_n^(j d), d = 1 .. 7, from W_n^j by products at most three deep (recomputed in A': 28 registers would stay pinned)
-        auto powers = [&](CX (&p0)[8], CX (&p1)[8]) {
-            p0[1] = wa0; p1[1] = wa1;
-            asm volatile("" : "+v"(p0[1].x), "+v"(p0[1].y), "+v"(p1[1].x), "+v"(p1[1].y));
-            p0[2] = cmul(p0[1], p0[1]); p0[3] = cmul(p0[2], p0[1]); p0[4] = cmul(p0[2], p0[2]); p0[5] = cmul(p0[4], p0[1]);
-            p0[6] = cmul(p0[3], p0[3]); p0[7] = cmul(p0[4], p0[3]);
-            p1[2] = cmul(p1[1], p1[1]); p1[3] = cmul(p1[2], p1[1]); p1[4] = cmul(p1[2], p1[2]); p1[5] = cmul(p1[4], p1[1]);
-            p1[6] = cmul(p1[3], p1[3]); p1[7] = cmul(p1[4], p1[3]);
-        };
-        {
-            CX p0[8], p1[8];
-            powers(p0, p1);
-#pragma unroll
-            for (int d = 1; d < 8; ++d) { a0[d] = cmul(a0[d], p0[d]); a1[d] = cmul(a1[d], p1[d]); }
-        }
-#pragma unroll
-        for (int d = 0; d < 8; ++d) lds_st2(rows + (size_t)d * ROW + 2 * tid, a0[d], a1[d]);
         PF_DSTAMP(2);
         wg_sync_raw();                                       // (2) rows complete; the landing buffer is free
         PF_DSTAMP(3);
@@ -222,21 +234,21 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         KF::template butterflies<2>(v, lane, wf, tw1024);
         PF_SPLIT_PIECE(4);
         PF_DSTAMP(5);
-        // ================= M: Z[wave + 8 k2], k2 = 2 lane + u + 128 d -> row[k2]; mirrors conj Z[n - k] from row 8 - wave
+        // ================= M: Z[wave + W k2], k2 = 2 lane + u + 128 d -> row[k2]; mirrors conj Z[n - k] from row W - wave
 #pragma unroll
         for (int d = 0; d < 8; ++d) lds_st2(row + 2 * lane + 128 * d, v[d], v[8 + d]);
         const unsigned tag = it + 1;
         if constexpr (PSYNC) {
             if (lane == 0) lds_flag_set(flagZ + wave, tag);
-            if (paired) lds_flag_wait(flagZ + (8 - wave), tag);
+            if (paired) lds_flag_wait(flagZ + (W - wave), tag);
         } else {
             wg_sync_raw();                                   // (3) the whole packed spectrum sits in the rows
         }
         PF_DSTAMP(6);
         CX zm[16];
         if (wave != 0) {
-            // n - k = (8 - wave) + 8 (1023 - k2): the unit at point 1022 - 2 lane - 128 d holds the mirrors of u = 1, u = 0 in this order
-            const CX* mrow = rows + (size_t)(8 - wave) * ROW;
+            // n - k = (W - wave) + W (1023 - k2): the unit at point 1022 - 2 lane - 128 d holds the mirrors of u = 1, u = 0 in this order
+            const CX* mrow = rows + (size_t)(W - wave) * ROW;
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
                 const vec4<float> m = lds_ld2(mrow + 1022 - 2 * lane - 128 * d);
@@ -244,7 +256,7 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
                 zm[d] = mk<T>(m.z, m.w);
             }
         } else {
-            // wave 0: n - 8 k2 = 8 (1024 - k2): the same row, index (1024 - k2) mod 1024
+            // wave 0: n - W k2 = W (1024 - k2): the same row, index (1024 - k2) mod 1024
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
                 zm[d] = lds_ld(row + ((1024 - 2 * lane - 128 * d) & 1023));
@@ -265,7 +277,7 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         }
         // ================= B': inverse transform of Z'[wave + 8 k2] (first-stage operands are in place), wave-local
         KB::template butterflies<0>(v, lane, wb, tw1024);
-        if constexpr (PSYNC) { if (paired) lds_flag_wait(flagR + (8 - wave), tag); }   // the partner is done with this row
+        if constexpr (PSYNC) { if (paired) lds_flag_wait(flagR + (W - wave), tag); }   // the partner is done with this row
         PF_SPLIT_PIECE(5);
         KB::template xwrite<0>(v, lane, row); KB::xsync();
         KB::template xread<0>(v, lane, row); KB::xsync();
@@ -281,34 +293,36 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
         PF_DSTAMP(8);
         wg_sync_raw();                                       // (4)
         PF_DSTAMP(9);
-        // ================= A': z'[j + 1024 q] = sum_d W_8^(-q d) conj(W_n^(j d)) b_d[j], j = 2 tid + u
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            const vec4<float> c = lds_ld2(rows + (size_t)d * ROW + 2 * tid);
-            a0[d] = mk<T>(c.x, c.y);
-            a1[d] = mk<T>(c.z, c.w);
-        }
-        {
-            CX p0[8], p1[8];
-            powers(p0, p1);
-#pragma unroll
-            for (int d = 1; d < 8; ++d) { a0[d] = cmulc(a0[d], p0[d]); a1[d] = cmulc(a1[d], p1[d]); }
-        }
-        dft8<BWD>(a0);
-        dft8<BWD>(a1);
-        // ---- the first numOut samples (src/pffastconv.c:255)
+        // ================= A': z'[j + 1024 q] = sum_d W_W^(-q d) conj(W_n^(j d)) b_d[j], j = 2 (tid + T cc) + u: the block's output samples
         {
             float* dst = ys + off;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e0 = 4 * (tid + 512 * q);
-                if (e0 + 3 < numOut) {
-                    F4u q4; q4.a = a0[q].x; q4.b = a0[q].y; q4.c = a1[q].x; q4.d = a1[q].y;
-                    *reinterpret_cast<F4u*>(dst + e0) = q4;
-                } else {
-                    if (e0 < numOut) dst[e0] = a0[q].x;
-                    if (e0 + 1 < numOut) dst[e0 + 1] = a0[q].y;
-                    if (e0 + 2 < numOut) dst[e0 + 2] = a1[q].x;
+            for (int cc = 0; cc < CPT; ++cc) {
+                CX a0[W], a1[W];
+#pragma unroll
+                for (int d = 0; d < W; ++d) {
+                    const vec4<float> c = lds_ld2(rows + (size_t)d * ROW + 2 * (tid + T_ * cc));
+                    a0[d] = mk<T>(c.x, c.y);
+                    a1[d] = mk<T>(c.z, c.w);
+                }
+                CX p0[W], p1[W];
+                powers(cc, p0, p1);
+#pragma unroll
+                for (int d = 1; d < W; ++d) { a0[d] = cmulc(a0[d], p0[d]); a1[d] = cmulc(a1[d], p1[d]); }
+                dftR<W, BWD>(a0);
+                dftR<W, BWD>(a1);
+                // ---- the first numOut samples (src/pffastconv.c:255)
+#pragma unroll
+                for (int q = 0; q < W; ++q) {
+                    const int e0 = 4 * (tid + T_ * cc + 512 * q);
+                    if (e0 + 3 < numOut) {
+                        F4u q4; q4.a = a0[q].x; q4.b = a0[q].y; q4.c = a1[q].x; q4.d = a1[q].y;
+                        *reinterpret_cast<F4u*>(dst + e0) = q4;
+                    } else {
+                        if (e0 < numOut) dst[e0] = a0[q].x;
+                        if (e0 + 1 < numOut) dst[e0 + 1] = a0[q].y;
+                        if (e0 + 2 < numOut) dst[e0 + 2] = a1[q].x;
+                    }
                 }
             }
         }

@@ -50,24 +50,27 @@ static int run(const char* name, const float* x, float* y, const cx<float>* dH, 
     return 0;
 }
 
-template <int PSYNC, int SPREAD>
+template <int PSYNC, int SPREAD, int W = 8>
 static int run_split(const float* x, float* y, const cx<float>* dH, const cx<float>* dtw, const cx<float>* dtw1024, const cx<float>* dtwr,
                      unsigned* ctr, long L, int taps, int cus) {
-    const int n = 8192, Nfft = 2 * n, step = Nfft - taps + 1;
+    typedef SplitFirT<W> SF;
+    const int n = SF::n, Nfft = 2 * n, step = Nfft - taps + 1;
     const long nblk = (L - taps + 1 + step - 1) / step;
     const int lastOut = (int)(L - taps + 1 - (nblk - 1) * step);
-    auto k = fastconv_split_kernel<PSYNC, SPREAD>;
-    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitFir::LDS_BYTES));
+    auto k = fastconv_split_kernel<PSYNC, SPREAD, W>;
+    int per_cu = 1;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, SF::WG, SF::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF::LDS_BYTES));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipMemset(ctr, 0, 8));
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL(k, dim3(cus), dim3(SplitFir::WG), SplitFir::LDS_BYTES, 0, x, y, dH, (int)nblk, step, (int)L, lastOut, dtw, dtw1024, dtwr, ctr, 1, (size_t)0, (size_t)0);
+        hipLaunchKernelGGL(k, dim3(cus * per_cu), dim3(SF::WG), SF::LDS_BYTES, 0, x, y, dH, (int)nblk, step, (int)L, lastOut, dtw, dtw1024, dtwr, ctr, 1, (size_t)0, (size_t)0);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (rep == 3) {
-            printf("[lds %zu B, fraction of the 8 B / sample roofline %.3f] ", (size_t)SplitFir::LDS_BYTES, 8.0 * (L - taps + 1) / (ms * 1e-3) / 8e12);
-            report(PSYNC ? (SPREAD ? "split, pairwise flags, pieces spread" : "split, pairwise flags around the mirror exchange") : (SPREAD ? "split, pieces spread over B and B'" : "split: cross-wave radix 8 + wave-local 1024-point transforms"), ms * 1e3f, nblk, cus, 1);
+            printf("[lds %zu B, fraction of the 8 B / sample roofline %.3f] ", (size_t)SF::LDS_BYTES, 8.0 * (L - taps + 1) / (ms * 1e-3) / 8e12);
+            report(PSYNC ? (SPREAD ? "split, pairwise flags, pieces spread" : "split, pairwise flags around the mirror exchange") : (SPREAD ? "split, pieces spread over B and B'" : "split: cross-wave radix 8 + wave-local 1024-point transforms"), ms * 1e3f, nblk, cus, per_cu);
         }
     }
     return 0;
@@ -95,6 +98,18 @@ int main() {
     if (run_split<0, 0>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;
     if (run_split<0, 1>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;
     if (run_split<1, 1>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;
+    {   // four wavefronts, 8192-sample blocks, 2048 taps (the W_n table of n = 4096: every second entry of the 8192 one)
+        std::vector<cx<float>> t4(4096);
+        for (int j = 0; j < 4096; ++j) { double a = -2 * M_PI * j / 4096; t4[j].x = cos(a); t4[j].y = sin(a); }
+        std::vector<cx<float>> tr4(2049);
+        for (int k = 0; k <= 2048; ++k) { double a = -2 * M_PI * k / 8192; tr4[k].x = cos(a); tr4[k].y = sin(a); }
+        cx<float>*d4, *dr4; CK(hipMalloc(&d4, 4096 * 8)); CK(hipMalloc(&dr4, 2049 * 8));
+        CK(hipMemcpy(d4, t4.data(), 4096 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dr4, tr4.data(), 2049 * 8, hipMemcpyHostToDevice));
+        printf("(2048 taps:) ");
+        if (run_split<1, 1, 4>(x, y, dH, d4, dtw1024, dr4, ctr, L, 2048, cus)) return 1;
+        printf("(2048 taps, 16384-sample blocks:) ");
+        if (run_split<1, 1, 8>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, 2048, cus)) return 1;
+    }
     if (run<DmaCfgF32::D8192, false>("two images, 512 threads (D8192)", x, y, dH, dtw, dtwr, ctr, L, taps, cus)) return 1;
     if (run<DmaCfgF32::D8192, false, 1>("two images, 512 threads, pieces spread over the phases", x, y, dH, dtw, dtwr, ctr, L, taps, cus)) return 1;
     return 0;
