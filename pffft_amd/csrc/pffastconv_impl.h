@@ -199,6 +199,9 @@ static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, 
     return 0;
 }
 
+// filters of up to this many taps take the wave kernel (from g_fir_wave_min on, below): beyond, the 16384-sample split kernel (fft_split.h, round 4) is faster - 800 taps 0.44 / 0.465 (wave) against
+// 0.41 / 0.46 (split), 900 taps 0.40 / 0.43 against 0.41 / 0.46, 1024 taps 0.37 / 0.39 against 0.40 / 0.45 (tools/fir_shapes.py)
+static int g_fir_wave_max = [] { const char* e = getenv("PFFASTCONV_HIP_WAVE_MAX"); return e ? atoi(e) : 850; }();
 static int g_fir_dma = [] { const char* e = getenv("PFFASTCONV_HIP_DMA"); return e ? atoi(e) : -1; }();   // -1 = default
 
 // Internal block length for the throughput regime.  What a caller can observe of the reference's blocks is only HOW MANY
@@ -219,7 +222,7 @@ static int fc_big_nfft(const FastConv* s, long produced, int nsig) {
     //   4096 taps                                                 -             -        0.16 / 0.19   0.21 / 0.24
     // -> 16384 from 1024 taps on, 8192 below (the time-domain kernel wins up to ~128 taps).  All block kernels saturate
     // near 0.26-0.30: two 8192-point transforms per block cost ~33 k cycles per CU whatever the filter.
-    const int want = forced > 0 ? forced : (taps < 1024 ? 8192 : 16384);
+    const int want = forced > 0 ? forced : (taps <= g_fir_wave_max ? 8192 : 16384);
     if (want <= s->Nfft || want > 16384 || (want & (want - 1)) || want < 2 * taps) return 0;
     if (forced > 0) return want;
     if (taps <= 128) return 0;
@@ -396,7 +399,7 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     const int nblk = mode ? 2 * nbt : nbt;
     const int Nfft = s->Nfft;
     const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
-    if (mode == 0 && s->cplxFactor == 1 && g_variant == 0 && g_fir_part != 0 && s->filterLen >= g_fir_wave_min && s->filterLen <= PART_B && produced > 0) {
+    if (mode == 0 && s->cplxFactor == 1 && g_variant == 0 && g_fir_part != 0 && s->filterLen >= g_fir_wave_min && s->filterLen <= PART_B && s->filterLen <= g_fir_wave_max && produced > 0) {
         // many blocks of a filter of up to 1024 taps: one wavefront per 2048-sample block, step = 2048 - taps + 1 (round 3;
         // the partitioned kernel below advances 1024 samples per block whatever the filter)
         const int wstep = (2 * PART_B - s->filterLen + 1) & ~3;

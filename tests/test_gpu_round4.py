@@ -18,11 +18,11 @@ def ref():
 
 
 # ------------------------------------------------------------------ split FIR block kernel (fft_split.h)
-@pytest.mark.parametrize("taps,L,nsig", [(4096, (1 << 22) + 4321, 1), (1025, (1 << 22) + 17, 2), (2048, 3 * (1 << 20) + 3, 3),
+@pytest.mark.parametrize("taps,L,nsig", [(4096, (1 << 22) + 4321, 1), (851, (1 << 22) + 3, 2), (1025, (1 << 22) + 17, 2), (2048, 3 * (1 << 20) + 3, 3),
                                         (3001, 1 << 22, 2), (8192, (1 << 22) + 5, 1), (5000, 2500001, 2)])
 @pytest.mark.parametrize("flush", [1, 0])
 def test_fastconv_split_kernel(ref, taps, L, nsig, flush):
-    """fastconv_split_kernel - default for 16384-sample internal blocks (filters beyond 1024 taps on calls with many blocks) and
+    """fastconv_split_kernel - default for 16384-sample internal blocks (filters beyond 850 taps on calls with many blocks) and
     for reference-sized blocks of that length (4097 .. 8192 taps): cross-wave radix 8 + wave-local 1024-point transforms, mirror
     exchange by pairwise flags, LDS-DMA pieces spread over the wave-local phases.  Variant 116 = plain barriers / pieces at once,
     97 = the lock-step kernel it replaced.  Count = the reference's block schedule, values within the reference test's limit over
