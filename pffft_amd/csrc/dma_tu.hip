@@ -27,27 +27,66 @@ static int fir_dma_cfg(Setup* ps, const float* d_Hc, const float* d_x, float* d_
     return 0;
 }
 
-// W_1024^j for the wave-local sub-transforms of fastconv_split_kernel: one table per device, generated in extended precision
-static int split_sub_table(const cx<float>** out) {
+// W_m^j (m = 1024, 512) for the wave-local sub-transforms of the split kernels: one table per device and length, generated in
+// extended precision
+static int split_sub_table(const cx<float>** out, int m = 1024) {
     static std::mutex mu;
-    static std::map<int, cx<float>*> tabs;
+    static std::map<long long, cx<float>*> tabs;
     int dev = 0;
     PF_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    auto it = tabs.find(dev);
+    const long long key = (long long)dev * 65536 + m;
+    auto it = tabs.find(key);
     if (it == tabs.end()) {
-        std::vector<cx<float>> tw(SplitFir::M);
-        for (int j = 0; j < SplitFir::M; ++j) {
-            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)SplitFir::M;
+        std::vector<cx<float>> tw(m);
+        for (int j = 0; j < m; ++j) {
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)m;
             tw[j].x = (float)cosl(a); tw[j].y = (float)sinl(a);
         }
         cx<float>* d = nullptr;
-        PF_CHECK(hipMalloc((void**)&d, sizeof(cx<float>) * SplitFir::M));
-        PF_CHECK(hipMemcpy(d, tw.data(), sizeof(cx<float>) * SplitFir::M, hipMemcpyHostToDevice));
-        it = tabs.emplace(dev, d).first;
+        PF_CHECK(hipMalloc((void**)&d, sizeof(cx<float>) * m));
+        PF_CHECK(hipMemcpy(d, tw.data(), sizeof(cx<float>) * m, hipMemcpyHostToDevice));
+        it = tabs.emplace(key, d).first;
     }
     *out = it->second;
     return 0;
+}
+
+template <int W>
+static int fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
+                      hipStream_t st, const FcBatch& fb, void** ab_cache) {
+    typedef SplitOneT<W> S;
+    auto k = fastconv_split1_kernel<W>;
+    int rc = allow_big_lds(k, S::LDS_BYTES);
+    if (rc) return rc;
+    if (!*ab_cache) {    // the folded coefficients of this filter: once, on the caller's stream (ordered before the kernel below)
+        PF_CHECK(hipMalloc(ab_cache, sizeof(float) * 4 * (size_t)S::n));
+        hipLaunchKernelGGL(fastconv_split1_coef_kernel<W>, dim3(1), dim3(S::WG), 0, st, (const cx<float>*)d_Hc, (const cx<float>*)ps->d_twr,
+                           (vec4<float>*)*ab_cache);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(*ab_cache); *ab_cache = nullptr; return fail(hipErrorLaunchFailure, "fastconv_split1_coef_kernel"); }
+    }
+    const cx<float>* tw512 = nullptr;
+    if ((rc = split_sub_table(&tw512, S::M))) return rc;
+    int per_cu = 0;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), S::WG, S::LDS_BYTES, &per_cu))) return rc;
+    const size_t groups = (size_t)nblk * fb.nsig;
+    size_t grid = (size_t)num_cus() * per_cu;
+    if (grid > groups) grid = groups;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(S::WG), S::LDS_BYTES, st, d_x, d_y, (const vec4<float>*)*ab_cache, nblk, step, inputLen,
+                       lastOut, (const cx<float>*)ps->d_tw, tw512, fb.nsig, fb.xstride, fb.ystride);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
+// calls with few blocks on reference-sized blocks of 2 ps->n samples: W wavefronts x 512-point wave-local transforms (fft_split.h);
+// -1: no such kernel for this length
+int launch_fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
+                      hipStream_t st, const FcBatch& fb, void** ab_cache) {
+    switch (ps->n) {
+        case 4096: return fir_split1<8>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, ab_cache);
+        case 2048: return fir_split1<4>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, ab_cache);
+        default: return -1;
+    }
 }
 
 template <int PSYNC, int SPREAD, int W = 8>

@@ -337,4 +337,212 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same organisation for calls with FEW blocks (the stated C4 call: 2^20 samples, 4096 taps = 255 reference-sized blocks of
+// 8192 samples, one per CU): latency, not throughput.  n = W x 512: W wavefronts, EIGHT points per lane - A: radix W across the
+// wavefronts straight from HBM (no landing buffer: a workgroup has one block), B / B': wave-local 512-point transforms (8 x 8 x 8, two
+// wave-local exchanges), M: mirror exchange through the rows.  Against the lock-step kernel on 512 threads (fft_fir.h FirCfg::C4096m:
+// five stages, eight workgroup-wide exchanges, tools/fir_timeline.hip: 12 400 cycles from the first butterfly to the last store) the
+// dependent chain of a wavefront is two short transforms and four barriers.
+template <int W> struct SplitOneT {
+    typedef TiledCfg<float, 9, 64, 3, 8, 8, 8, 1, 4, 8, 3, 0, 512, 1> Sub;     // the wave-local 512-point transform, 8 points per lane
+    static constexpr int WAVES = W, M = 512, n = W * M, WG = 64 * W;
+    static constexpr int JPT = 8 / W;                                          // stage-A butterflies (points j) per thread
+    static constexpr int ROW = (Sub::IMG_NAT > Sub::IMG_TRN ? Sub::IMG_NAT : Sub::IMG_TRN) + 8;
+    static constexpr size_t LDS_BYTES = (size_t)WAVES * ROW * 8 + 16;
+    static_assert(W == 8 || W == 4, "cross-wave radix 8 or 4");
+};
+
+// Folded per-bin coefficients of fastconv_split1_kernel, once per filter (the reference transforms the filter once per setup too:
+// src/pffastconv.c:108): AB[d T + tid] = (A, B) of bin k = wave + W (lane + 64 d) - real finalize, x Hf / Nfft and real preprocess as
+// Z'[k] = A Z[k] + B conj Z[n - k] (derivation: fft_fir.h fastconv_part_kernel; bin 0 = (DC, Nyquist) and bin n/2 are their own
+// mirrors).  In the kernel's prologue this was 8 bins x 4 scattered table reads + 40 flops per thread, and 255 workgroups did it at
+// the same time: 6 000 of the 17 800 cycles of the stated C4 call (tools/dma_timeline.hip); now it is 8 coalesced 16-byte loads.
+template <int W>
+__global__ void __launch_bounds__(SplitOneT<W>::WG)
+fastconv_split1_coef_kernel(const cx<float>* __restrict__ Hc, const cx<float>* __restrict__ twr, vec4<float>* __restrict__ AB) {
+    typedef float T;
+    typedef cx<T> CX;
+    typedef SplitOneT<W> S;
+    constexpr int n = S::n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int d = 0; d < 8; ++d) {
+        const int k = wave + W * (lane + 64 * d);
+        const int km = (n - k) & (n - 1);
+        const CX w = k <= n / 2 ? twr[k] : conj(twr[n - k]) * (T)-1;
+        const CX Hk = Hc[k], Hm = Hc[km];
+        const CX iw = mk<T>(-w.y, w.x), iwc = mk<T>(w.y, w.x);   // i w, i conj(w)
+        const CX al = mk<T>(0.5f * (1.f - iw.x), -0.5f * iw.y), be = mk<T>(0.5f * (1.f + iw.x), 0.5f * iw.y);
+        const CX ga = mk<T>(1.f + iwc.x, iwc.y), de = mk<T>(1.f - iwc.x, -iwc.y);
+        const CX gH = cmul(ga, Hk), dHm = cmul(de, conj(Hm));
+        CX a = cmul(gH, al) + cmul(dHm, be), b = cmul(gH, be) + cmul(dHm, al);
+        if (k == 0) { a = mk<T>(Hk.x + Hk.y, 0.f); b = mk<T>(0.f, Hk.x - Hk.y); }
+        if (k == n / 2) { a = mk<T>(2.f * Hk.x, -2.f * Hk.y); b = mk<T>(0.f, 0.f); }
+        vec4<float> o; o.x = a.x; o.y = a.y; o.z = b.x; o.w = b.y;
+        AB[d * S::WG + tid] = o;
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(SplitOneT<W>::WG, 2)
+fastconv_split1_kernel(const float* __restrict__ x, float* __restrict__ y, const vec4<float>* __restrict__ AB,
+                       int nblk, int step, int inputLen, int lastOut,
+                       const cx<float>* __restrict__ twn,      // W_n^j, j < n
+                       const cx<float>* __restrict__ tw512,    // W_512^j
+                       int nsig, size_t xstride, size_t ystride) {
+    typedef float T;
+    typedef cx<T> CX;
+    typedef SplitOneT<W> S;
+    typedef Tiled<typename S::Sub, FWD, 0> KF;
+    typedef Tiled<typename S::Sub, BWD, 0> KB;
+    constexpr int n = S::n, ROW = S::ROW, T_ = S::WG, JPT = S::JPT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    CX* rows = reinterpret_cast<CX*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    CX* row = rows + (size_t)wave * ROW;
+    const long long nblk_all = (long long)nblk * nsig;
+    struct __attribute__((packed, aligned(4))) F2u { float a, b; };   // block offsets are multiples of 4 bytes only
+    typedef vec2<float> F2;
+    // ---- stage-A operands of block group grp: z[j + 512 q] = the float pair at 2 (j + 512 q), zero beyond the end of the signal
+    //      (src/pffastconv.c:231-233); requested before the tables (their misses overlap)
+    F2 raw[JPT][W];
+    auto gather = [&](long long ba) {
+        int sg, bk;
+        fc_split(ba, nblk, nsig, sg, bk);
+        const float* src = x + (size_t)sg * xstride + (long)bk * step;
+        const long avail = (long)inputLen - (long)bk * step;
+#pragma unroll
+        for (int jj = 0; jj < JPT; ++jj)
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const int e0 = 2 * (tid + T_ * jj + 512 * q);
+                F2 r;
+                if (e0 + 1 < avail) { const F2u q2 = *reinterpret_cast<const F2u*>(src + e0); r.x = q2.a; r.y = q2.b; }   // 8 bytes, 4-byte aligned
+                else { r.x = e0 < avail ? src[e0] : 0.f; r.y = 0.f; }
+                raw[jj][q] = r;
+            }
+    };
+    const unsigned it = 3; (void)it;      // (PF_DSTAMP's iteration filter: one-shot kernel)
+    PF_DSTAMP(0);
+    long long g = blockIdx.x;
+    if (g < nblk_all) gather(g);
+    PF_DSTAMP(1);
+    // ---- per-thread constants
+    typename KF::Tw wf;
+    typename KB::Tw wb;
+    KF::load_tw(wf, lane, tw512, nullptr);
+    KB::load_tw(wb, lane, tw512, nullptr);
+    CX wa[JPT];
+#pragma unroll
+    for (int jj = 0; jj < JPT; ++jj) wa[jj] = twn[tid + T_ * jj];
+    // folded coefficients of this thread's 8 bins k = wave + W k2, k2 = lane + 64 d: from the table of fastconv_split1_coef_kernel
+    CX cA[8], cB[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const vec4<float> ab = AB[d * T_ + tid];
+        cA[d] = mk<T>(ab.x, ab.y); cB[d] = mk<T>(ab.z, ab.w);
+    }
+    auto powers = [&](int jj, CX (&p)[W]) {                  // W_n^(j d), d = 1 .. W - 1
+        p[1] = wa[jj];
+        asm volatile("" : "+v"(p[1].x), "+v"(p[1].y));
+        p[2] = cmul(p[1], p[1]); p[3] = cmul(p[2], p[1]);
+        if constexpr (W == 8) { p[4] = cmul(p[2], p[2]); p[5] = cmul(p[4], p[1]); p[6] = cmul(p[3], p[3]); p[7] = cmul(p[4], p[3]); }
+    };
+    PF_DSTAMP(2);
+    for (; g < nblk_all; g += gridDim.x) {
+        int sig, blk;
+        fc_split(g, nblk, nsig, sig, blk);
+        const long off = (long)blk * step;
+        const int numOut = (blk == nblk - 1) ? lastOut : step;
+        float* dst = y + (size_t)sig * ystride + off;
+        // ================= A: radix W across the wavefronts, times W_n^(j d), into row d
+#pragma unroll
+        for (int jj = 0; jj < JPT; ++jj) {
+            CX a[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) a[q] = raw[jj][q];
+            dftR<W, FWD>(a);
+            CX p[W];
+            powers(jj, p);
+#pragma unroll
+            for (int d = 1; d < W; ++d) a[d] = cmul(a[d], p[d]);
+#pragma unroll
+            for (int d = 0; d < W; ++d) lds_st(rows + (size_t)d * ROW + tid + T_ * jj, a[d]);
+        }
+        PF_DSTAMP(3);
+        wg_sync_raw();                                       // (1) rows complete
+        PF_DSTAMP(4);
+        // ================= B: wavefront `wave` transforms row `wave` (512 points, operands lane + 64 q), wave-local
+        CX v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = lds_ld(row + lane + 64 * q);
+        KF::xsync();
+        KF::template butterflies<0>(v, lane, wf, tw512);
+        KF::template xwrite<0>(v, lane, row); KF::xsync();
+        KF::template xread<0>(v, lane, row); KF::xsync();
+        KF::template butterflies<1>(v, lane, wf, tw512);
+        KF::template xwrite<1>(v, lane, row); KF::xsync();
+        KF::template xread<1>(v, lane, row); KF::xsync();
+        KF::template butterflies<2>(v, lane, wf, tw512);
+        PF_DSTAMP(5);
+        // ================= M: Z[wave + W k2], k2 = lane + 64 d -> row[k2]; mirrors conj Z[n - k] from row W - wave, index 511 - k2
+#pragma unroll
+        for (int d = 0; d < 8; ++d) lds_st(row + lane + 64 * d, v[d]);
+        wg_sync_raw();                                       // (2) the whole packed spectrum sits in the rows
+        CX zm[8];
+        if (wave != 0) {
+            const CX* mrow = rows + (size_t)(W - wave) * ROW;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) zm[d] = lds_ld(mrow + 511 - lane - 64 * d);
+        } else {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) zm[d] = lds_ld(row + ((512 - lane - 64 * d) & 511));
+        }
+        wg_sync_raw();                                       // (3) every mirror is read: the rows are exchange buffers again
+        PF_DSTAMP(6);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const CX a = cA[i], bq = cB[i], zz = v[i], m = zm[i];
+            v[i] = mk<T>(fma_(a.x, zz.x, fma_(-a.y, zz.y, fma_(bq.x, m.x, bq.y * m.y))),
+                         fma_(a.x, zz.y, fma_(a.y, zz.x, fma_(bq.y, m.x, -(bq.x * m.y)))));
+        }
+        // ================= B': inverse transform of Z'[wave + W k2] (first-stage operands are in place), wave-local
+        KB::template butterflies<0>(v, lane, wb, tw512);
+        KB::template xwrite<0>(v, lane, row); KB::xsync();
+        KB::template xread<0>(v, lane, row); KB::xsync();
+        KB::template butterflies<1>(v, lane, wb, tw512);
+        KB::template xwrite<1>(v, lane, row); KB::xsync();
+        KB::template xread<1>(v, lane, row); KB::xsync();
+        KB::template butterflies<2>(v, lane, wb, tw512);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) lds_st(row + lane + 64 * d, v[d]);        // b_wave[j], j = lane + 64 d
+        PF_DSTAMP(7);
+        wg_sync_raw();                                       // (4)
+        PF_DSTAMP(8);
+        const long long gnext = g + gridDim.x;
+        // ================= A': z'[j + 512 q] = sum_d W_W^(-q d) conj(W_n^(j d)) b_d[j]: output samples 2 (j + 512 q), + 1
+#pragma unroll
+        for (int jj = 0; jj < JPT; ++jj) {
+            CX a[W];
+#pragma unroll
+            for (int d = 0; d < W; ++d) a[d] = lds_ld(rows + (size_t)d * ROW + tid + T_ * jj);
+            CX p[W];
+            powers(jj, p);
+#pragma unroll
+            for (int d = 1; d < W; ++d) a[d] = cmulc(a[d], p[d]);
+            dftR<W, BWD>(a);
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const int e0 = 2 * (tid + T_ * jj + 512 * q);
+                if (e0 + 1 < numOut) { F2u q2; q2.a = a[q].x; q2.b = a[q].y; *reinterpret_cast<F2u*>(dst + e0) = q2; }
+                else if (e0 < numOut) dst[e0] = a[q].x;
+            }
+        }
+        PF_DSTAMP(9);
+        if (gnext < nblk_all) gather(gnext);                 // (a call with more blocks than workgroups: the next block's operands; every
+                                                             //  thread re-writes exactly the row slots it has just read: no barrier)
+    }
+}
+
 }  // namespace pf

@@ -112,6 +112,11 @@ size_t tile_rfft_work_elems(long long N, bool is_double);
 // conv_tu.hip: forward -> x H (one filter spectrum, internal layout) -> backward in ONE kernel (fft_conv.h); -1: no fused kernel
 int launch_conv_fused(Setup* s, const void* in, const void* H, void* out, size_t batch, double scaling, int accumulate, hipStream_t st);
 
+// dma_tu.hip: few-block calls on reference-sized blocks (fft_split.h fastconv_split1_kernel); -1: no such kernel for this length
+// (ab_cache: the filter's folded coefficient table, built on first use and owned by the caller's pffastconv setup: hipFree)
+int launch_fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
+                      hipStream_t st, const FcBatch& fb, void** ab_cache);
+
 // tile_tu.hip: power-of-two sizes beyond LDS in two / three passes (fft_tile.h); canonical complex, in -> out through `work`
 // (same size, distinct from both; in may equal out).  -1 when the size has no tile plan.  layout 1 (forward only): the
 // spectrum is stored in the pffft-internal layout by the last pass; layout 2 (backward only): it is read from that layout

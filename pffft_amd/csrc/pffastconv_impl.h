@@ -30,6 +30,7 @@ struct FastConv {
     PFFFT_Setup* st_part = nullptr; float* d_Hp = nullptr; int part_P = 0;
     std::vector<float> h_td;  // y[m] = sum_i h_td[i] x[m + i]: the filter as the time-domain kernel applies it (zero padded to 8)
     float* d_td = nullptr;
+    void* d_split1_ab = nullptr;   // folded per-bin coefficients of the few-block split kernel (fft_split.h), built on first use
     // work image of the composed path: one per stream (two streams running one setup must not share scratch)
     struct Work { float* p = nullptr; size_t floats = 0; unsigned long long last_use = 0; };
     unsigned long long work_clock = 0;
@@ -478,6 +479,12 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         rc = launch_fir_dma(s->st, s->d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);   // many reference-sized blocks
         if (rc != -1) return rc;
     }
+    if (mode == 0 && g_variant != 30 && g_variant != 114 && g_variant != 115 && (Nfft == 8192 || Nfft == 4096)) {
+        // few blocks of 8192 / 4096 samples: cross-wave radix 8 / 4 + wave-local 512-point transforms (fft_split.h
+        // fastconv_split1_kernel, round 4); variant 115 = the lock-step kernel on 512 / 256 threads, 114 = on 256 / 128
+        rc = launch_fir_split1(s->st, s->d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, &s->d_split1_ab);
+        if (rc != -1) return rc;
+    }
     if (mode == 0 && g_variant != 30) {  // one real stream: the fused one-kernel path when Nfft/2 has a tiled kernel
         switch (Nfft / 2) {
             case 512: return fc_launch_fused<FirCfg::C512>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
@@ -569,6 +576,7 @@ PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
     for (float* p : {s->d_Hf, s->d_Hc, s->d_Hc_big, s->d_Hp, s->d_td, s->d_x, s->d_y}) if (p) (void)hipFree(p);
     if (s->st_part) pffft_destroy_setup(s->st_part);
     for (auto& kv : s->work) if (kv.second.p) (void)hipFree(kv.second.p);
+    if (s->d_split1_ab) (void)hipFree(s->d_split1_ab);
     for (float* p : {s->h_x, s->h_y}) if (p) (void)hipHostFree(p);
     s->magic = 0;
     delete s;

@@ -49,11 +49,13 @@ def test_fastconv_split_kernel(ref, taps, L, nsig, flush):
     fc.close()
 
 
-@pytest.mark.parametrize("taps,L", [(4096, 1 << 20), (2048, 1 << 19), (1500, 300001), (3000, 700003)])
+@pytest.mark.parametrize("taps,L", [(4096, 1 << 20), (2048, 1 << 19), (1500, 300001), (3000, 700003), (2049, 8192 * 3 + 5), (1025, 40001),
+                                    (4096, 5 * 4097 * 300 + 77)])
 def test_fastconv_few_blocks_512_thread_configurations(ref, taps, L):
     """Calls with few blocks (the stated C4 call: 2^20 samples, 4096 taps) run one workgroup per reference-sized block; round 4:
     512 / 256 threads per 8192- / 4096-sample block (FirCfg::C4096m / C2048m, eight points per thread), the first block's samples
-    requested before the tables.  Variant 114 = the 16-points-per-thread configurations."""
+    requested before the tables (variant 115), and - the default since - cross-wave radix 8 / 4 + wave-local 512-point transforms
+    (fastconv_split1_kernel).  Variant 114 = the 16-points-per-thread configurations."""
     rng = np.random.default_rng(taps)
     x = rng.uniform(-1, 1, L).astype(np.float32)
     h = rng.uniform(-1, 1, taps).astype(np.float32)
@@ -62,7 +64,7 @@ def test_fastconv_few_blocks_512_thread_configurations(ref, taps, L):
     try:
         for flush in (1, 0):
             yw, nw, _ = ref.fastconv(x, h, 0, 0, flush)
-            for var in (0, 114):
+            for var in (0, 115, 114):
                 pa.set_variant(var)
                 yd = torch.full_like(xd, 7.0)
                 y, n = fc.apply(xd, bool(flush), out=yd)

@@ -76,6 +76,33 @@ static int run_split(const float* x, float* y, const cx<float>* dH, const cx<flo
     return 0;
 }
 
+static int run_one(const float* x, float* y, int cus) {
+    // the stated C4 call: 2^20 samples, 4096 taps, 255 blocks of 8192 samples (n = 4096), one launch at a time
+    const int n = 4096, Nfft = 8192, taps = 4096; const long L = 1 << 20; const int step = Nfft - taps + 1;
+    const int nblk = (int)((L - taps + 1 + step - 1) / step), lastOut = (int)(L - taps + 1 - (long)(nblk - 1) * step);
+    std::vector<cx<float>> tw(n), twr(n / 2 + 1), H(n), t5(512);
+    for (int j = 0; j < n; ++j) { double a = -2 * M_PI * j / n; tw[j].x = cos(a); tw[j].y = sin(a); }
+    for (int k = 0; k <= n / 2; ++k) { double a = -2 * M_PI * k / Nfft; twr[k].x = cos(a); twr[k].y = sin(a); }
+    for (int k = 0; k < n; ++k) { H[k].x = 1.0f / Nfft; H[k].y = 0; }
+    for (int j = 0; j < 512; ++j) { double a = -2 * M_PI * j / 512; t5[j].x = cos(a); t5[j].y = sin(a); }
+    cx<float>*dtw, *dtwr, *dH, *d5;
+    CK(hipMalloc(&dtw, n * 8)); CK(hipMalloc(&dtwr, (n / 2 + 1) * 8)); CK(hipMalloc(&dH, n * 8)); CK(hipMalloc(&d5, 512 * 8));
+    CK(hipMemcpy(dtw, tw.data(), n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dtwr, twr.data(), (n / 2 + 1) * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dH, H.data(), n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d5, t5.data(), 512 * 8, hipMemcpyHostToDevice));
+    vec4<float>* dAB; CK(hipMalloc(&dAB, n * 16));
+    hipLaunchKernelGGL(fastconv_split1_coef_kernel<8>, dim3(1), dim3(512), 0, 0, dH, dtwr, dAB);
+    auto k = fastconv_split1_kernel<8>;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(512), SplitOneT<8>::LDS_BYTES, 0, x, y, dAB, nblk, step, (int)L, lastOut, dtw, d5, 1, (size_t)0, (size_t)0);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (rep == 3) report("one-shot split kernel, the stated C4 call (stamps: 1 gather issued, 2 constants, 3 A, 4 barrier, 5 B, 6 mirror, 7 B', 8 barrier, 9 A' + stores)", ms * 1e3f, nblk, cus, 1);
+    }
+    return 0;
+}
+
 int main() {
     const int n = 8192, Nfft = 2 * n, taps = 4096;
     const long L = 1L << 26;
@@ -95,6 +122,7 @@ int main() {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("clock rate %d kHz, %d CUs\n", prop.clockRate, cus);
+    if (run_one(x, y, cus)) return 1;
     if (run_split<0, 0>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;
     if (run_split<0, 1>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;
     if (run_split<1, 1>(x, y, dH, dtw, dtw1024, dtwr, ctr, L, taps, cus)) return 1;

@@ -75,12 +75,12 @@ if "fir" in what:
 if "single" in what:
     # the stated C4 call (2^20 samples, 4096 taps: 255 reference-sized blocks) and two neighbours, back-to-back launches
     rng = np.random.default_rng(4)
-    for taps, L in ((4096, 1 << 20), (2048, 1 << 19), (8192, 1 << 21)):
+    for taps, L in ((4096, 1 << 20), (3000, 1 << 20), (2048, 1 << 19), (1500, 300001), (8192, 1 << 21)):
         h = rng.uniform(-1, 1, taps).astype(np.float32)
         x = torch.rand(L, device="cuda") * 2 - 1
         y = torch.empty_like(x)
         yw, nw, _ = R.fastconv(x.cpu().numpy(), h, 0, 0, 1)
-        for var in (0, 114):
+        for var in (0, 115, 114):
             pa.set_variant(var)
             fc = pa.FastConv(h, 0, 0)
             ya, n = fc.apply(x, True, out=y)
