@@ -34,19 +34,22 @@ int launch_tiled_mw(Setup* s, const void* in, void* out, size_t batch, int dir, 
     if (s->is_double) return -1;
     const float* i = (const float*)in;
     float* o = (float*)out;
+    // measured slower than the adopted configurations everywhere: development build only, nothing routes here
+#ifdef PFFFT_HIP_VARIANTS
     if (s->n == 8192) {
         switch (which) {
             case 0: return mw_launch<float, TiledMwF32::M8192>(s, i, o, batch, dir, ordered, st);
-#ifndef PFFFT_HIP_NO_MW_ALTERNATIVES
             case 1: return mw_launch<float, TiledMwF32::M8192np>(s, i, o, batch, dir, ordered, st);
             case 2: return mw_launch<float, TiledMwF32::M8192x2>(s, i, o, batch, dir, ordered, st);
             case 3: return mw_launch<float, TiledMwF32::M8192x2g>(s, i, o, batch, dir, ordered, st);
             case 4: return mw_launch<float, TiledMwF32::M8192x2p>(s, i, o, batch, dir, ordered, st);
             case 7: return mw_launch<float, TiledMwF32::M8192l>(s, i, o, batch, dir, ordered, st);
-#endif
             default: return -1;
         }
     }
+#else
+    (void)i; (void)o; (void)batch; (void)dir; (void)ordered; (void)st; (void)which;
+#endif
     return -1;
 }
 

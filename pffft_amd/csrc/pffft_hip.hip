@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pffft_hip.h"
@@ -380,22 +381,33 @@ static int ensure_device(Setup* s) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// (both tables are per DEVICE: the attribute is a property of the function on one device, and one process may drive several)
 int allow_big_lds_impl(const void* kernel, size_t bytes) {
     static std::mutex mu;
-    static std::map<const void*, size_t> done;           // largest size already granted per kernel
+    static std::map<std::pair<int, const void*>, size_t> done;           // largest size already granted per (device, kernel)
+    int dev = 0;
+    PF_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    auto it = done.find(kernel);
+    const auto key = std::make_pair(dev, kernel);
+    auto it = done.find(key);
     if (it != done.end() && it->second >= bytes) return 0;
     PF_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    done[kernel] = bytes;
+    done[key] = bytes;
     return 0;
 }
 
 int cached_occupancy(const void* kernel, int threads, size_t lds, int* per_cu) {
-    struct Key { const void* k; int th; size_t lds; bool operator<(const Key& o) const { return k != o.k ? k < o.k : th != o.th ? th < o.th : lds < o.lds; } };
+    struct Key {
+        int dev; const void* k; int th; size_t lds;
+        bool operator<(const Key& o) const {
+            return dev != o.dev ? dev < o.dev : k != o.k ? k < o.k : th != o.th ? th < o.th : lds < o.lds;
+        }
+    };
     static std::mutex mu;
     static std::map<Key, int> tab;
-    const Key key{kernel, threads, lds};
+    int dev = 0;
+    PF_CHECK(hipGetDevice(&dev));
+    const Key key{dev, kernel, threads, lds};
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = tab.find(key);
