@@ -125,6 +125,7 @@ int launch_fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y
 // deep: the streaming route of this n would take five sweeps - three tile passes are allowed
 int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, long long n, int dir, hipStream_t st, int layout = 0, bool deep = false);
 bool tile_has_plan(long long n, bool is_double, bool deep = false);
-int tile_plan_lengths(long long n, bool is_double, bool deep, int lengths[3]);   // 0 / 2 / 3 passes (pffft_hip_tile_plan)
+int tile_plan_lengths(long long n, bool is_double, bool deep, int lengths[3]);
+int tile_plan_layouts(long long n, bool is_double, bool deep);   // bit 0: internal layout out of the last pass, bit 1: into the first   // 0 / 2 / 3 passes (pffft_hip_tile_plan)
 
 }  // namespace pf

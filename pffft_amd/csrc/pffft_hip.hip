@@ -312,8 +312,8 @@ static int alloc_counter_ring(Setup* s) {
     // launches later, i.e. at most CTR_RING launches of one setup may be in flight at once
     // (stated in include/pffft_hip.h; launches on one stream serialise, so this bounds concurrent streams x depth).
     if (s->d_ctr) return 0;
-    PF_CHECK(hipMalloc((void**)&s->d_ctr, sizeof(unsigned) * 2 * CTR_RING));
-    PF_CHECK(hipMemset(s->d_ctr, 0, sizeof(unsigned) * 2 * CTR_RING));
+    PF_CHECK(hipMalloc((void**)&s->d_ctr, sizeof(unsigned) * (2 * CTR_RING + 16)));   // (+ 16: a launch may take several consecutive pairs)
+    PF_CHECK(hipMemset(s->d_ctr, 0, sizeof(unsigned) * (2 * CTR_RING + 16)));
     return 0;
 }
 
@@ -924,9 +924,15 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     // two (three beyond 2^20) tile passes: power-of-two n and the n whose odd part splits over two tile lengths (tile_tu.hip)
     // (deep: the row length of the streaming route is itself beyond LDS, or there is no streaming plan - five sweeps)
     const bool deep = !s->bigR || !s->sub || s->sub->kernel == K_BIG;
-    const bool tiled = g_variant != 80 && g_variant != 82 && tile_has_plan(s->n, s->is_double, deep);
+    bool tiled = g_variant != 80 && g_variant != 82 && tile_has_plan(s->n, s->is_double, deep);
     // complex backward from the internal layout on the tile passes: the first one reads the layout itself (variant 86 = off)
-    const bool fuse_in = !fwd && !ordered && !real && tiled && g_variant != 86;
+    const int tlay = tiled ? tile_plan_layouts(s->n, s->is_double, deep) : 0;
+    // a complex plan with a run-time tile pass (fft_tileg.h) cannot fuse the internal layout on that side: two passes + a reorder sweep
+    // against the three streaming passes, which fuse it (measured 0.13-0.15 against 0.18-0.24) - and ordered / unordered must run the SAME
+    // arithmetic (ordered == zreorder(unordered) bit for bit): such a plan is used for both layouts or for none.  It stays where the
+    // streaming route would take five sweeps (deep)
+    if (tiled && !real && !deep && s->bigR && tlay != 3) tiled = false;
+    const bool fuse_in = !fwd && !ordered && !real && tiled && (tlay & 2) && g_variant != 86;
     // ... and so does the column pass of the three-pass route when R is a multiple of 4
     const bool col_in = !fwd && !ordered && !real && !tiled && s->bigR && s->bigR % 4 == 0 && g_variant != 80 && g_variant != 86;
     if (fuse_in || col_in) {
@@ -953,7 +959,7 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
         // power-of-two sizes: two passes over HBM up to n = 2^20, three beyond; sizes with an odd part that splits over two tile
         // lengths: two passes (fft_tile.h); variant 82 = the three-to-five-pass composition below, 83 = that only for the latter (A/B)
         // complex forward into the internal layout: the last tile pass stores the layout itself (variant 86 = separate reorder sweep, A/B)
-        const bool fuse_int = fwd && !ordered && !real && g_variant != 86;
+        const bool fuse_int = fwd && !ordered && !real && (tlay & 1) && g_variant != 86;
         const int trc = launch_tile_fft(s, cur, bufB, fuse_int ? (cx<T>*)out : dest, batch, (long long)s->n, dir, st, fuse_int ? 1 : fuse_in ? 2 : 0, deep);
         if (trc > 0) return trc;
         if (trc < 0 && fuse_in) { g_last_error = "pffft_hip: no tile plan for this size beyond LDS"; return (int)hipErrorInvalidValue; }

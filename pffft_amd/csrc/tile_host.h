@@ -102,6 +102,11 @@ static int tile_dispatch_mr(int logl, const cx<T>* in, cx<T>* out, unsigned long
     return (int)hipErrorInvalidValue;
 }
 
+// tileg_tu.hip: tile lengths on a run-time mixed-radix plan (fft_tileg.h), canonical layouts
+int tile_gen_pass(bool is_double, int L, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
+                  bool out_int, bool in_int);
+bool tile_gen_length_ok(int L, bool is_double);
+
 // one entry per odd radix, each in its own translation unit (tile_mr<R0>_tu.hip)
 int tile_mr_pass_3(bool is_double, int logl, const void* in, void* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
                    Setup* s, bool out_int, bool in_int);

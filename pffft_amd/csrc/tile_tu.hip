@@ -53,14 +53,17 @@ template <typename T> static int pick_pp(int logl) {
 // W_len^(k col); same layout out (in place allowed)
 // in_int (backward only, the first pass of a transform): the columns are read from the pffft-internal layout (tile_fft_kernel IINT)
 // one tile length L = r0 2^logl (r0 = 1: power of two)
+// (gen: a length of fft_tileg.h - run-time mixed-radix plan, r0 = L, logl = 0)
 struct TileLen {
     int r0, logl;
+    bool gen = false;
     unsigned long long len() const { return (unsigned long long)r0 << logl; }
 };
 
 template <typename T>
 static int tile_any(const TileLen& tl, int pp, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st,
                     Setup* s, bool out_int, bool in_int) {
+    if (tl.gen) return tile_gen_pass(sizeof(T) == 8, (int)tl.len(), in, out, ntiles, D, dir, st, s, out_int, in_int);
     switch (tl.r0) {
         case 1: return pp == 8 ? tile_dispatch<T, 8>(tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int)
                                : tile_dispatch<T, 4>(tl.logl, in, out, ntiles, D, dir, st, s, out_int, in_int);
@@ -77,7 +80,7 @@ static int tile_any(const TileLen& tl, int pp, const cx<T>* in, cx<T>* out, unsi
     return (int)hipErrorInvalidValue;
 }
 
-template <typename T> static int pick_pp(const TileLen& tl) { return tl.r0 == 1 ? pick_pp<T>(tl.logl) : 8; }
+template <typename T> static int pick_pp(const TileLen& tl) { return (tl.r0 == 1 && !tl.gen) ? pick_pp<T>(tl.logl) : 8; }
 
 template <typename T>
 static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, TileLen tl, unsigned long long cols, int dir, hipStream_t st,
@@ -126,8 +129,23 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
 // odd stages (25, 27, 45): columns 118-128 (L = 720: 176-192), rows 102-138 (L = 720: 165-169).  false: no plan - the three streaming passes of fft_big.h.
 static int g_mr_min = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMIN"); return e ? atoi(e) : 48; }();    // A/B: shortest / longest
 static int g_mr_max = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMAX"); return e ? atoi(e) : 768; }();   // tile length of a plan
-static int tile_cost(const TileLen& t, bool columns) {
+static int g_gen_cost = [] { const char* e = getenv("PFFFT_HIP_TILE_GENCOST"); return e ? atoi(e) : 1; }();   // A/B: 0 = no run-time plans
+// `stride`: the element stride between the points of the pass's strided side - the column count of a column pass (loads and stores), the
+// row count (outer) of a row pass (stores).  Costs in the unit of the table above (~ us per 0.5 GiB of float vectors / 2.1), round 4,
+// N = 10800 / 11664 / 250000 / 600000 on forced plans (tools/r4_gen_force.sh):
+//   run-time plans (fft_tileg.h): rows 230 us where the stride is whole 128-byte lines, 250-275 on half lines, 250-290 else (L > 432: 280-310);
+//   columns 285-318 on half lines, 320-340 else, 414 for L = 60 (L > 432: 330-365);
+//   register-tiled kernels on strides that are not half lines (float, the other length = 2, 4, 6 mod 8): 475-550 for either pass
+static int tile_cost(const TileLen& t, bool columns, unsigned long long stride, bool is_double) {
     const long long L = t.len();
+    const unsigned long long line = is_double ? 8 : 16;
+    if (t.gen) {
+        // (+ 10: a plan that ties with a register-tiled one on this model measured 1-9 % slower - N = 144000 .. 307200, tools/r4_gen_scan2.sh)
+        const int dbl = (is_double ? 8 : 0) + 10;         // (double: 233-324 / 292-390 on the same plans)
+        if (columns) return (L > 432 ? 165 : stride % (line / 2) == 0 ? 143 : 158) + (L < 80 ? 40 : 0) + dbl;
+        return (L > 432 ? 140 : stride % line == 0 ? 110 : stride % (line / 2) == 0 ? 125 : 132) + (L < 80 ? 20 : 0) + dbl;
+    }
+    if (stride % (line / 2)) return 240;
     if (t.r0 == 1) return columns ? 103 : 97;
     if (t.r0 >= 25) {                                    // two odd stages: one more exchange
         if (columns) return L >= 600 ? 185 : 125;
@@ -152,12 +170,22 @@ static const std::vector<TileLen>& tile_lengths(bool is_double) {
             for (int r0 : {3, 5, 9, 15, 25, 27, 45})
                 for (int l = mr_min_logl(r0, dbl != 0); l <= mr_max_logl(r0); ++l)
                     if ((r0 << l) >= 48) v.push_back(TileLen{r0, l});
+            // every other length 2^a 3^b 5^c (float: even) up to 864 on the run-time plans of fft_tileg.h
+            if (g_gen_cost > 0) {
+                const size_t fixed = v.size();
+                for (int L = 32; L <= 864; ++L) {
+                    if (!tile_gen_length_ok(L, dbl != 0)) continue;
+                    bool have = false;
+                    for (size_t i = 0; i < fixed; ++i) have = have || (long long)v[i].len() == L;
+                    if (!have) v.push_back(TileLen{L, 0, true});
+                }
+            }
             std::sort(v.begin(), v.end(), [](const TileLen& x, const TileLen& y) { return x.len() < y.len(); });
         }
     });
     return is_double ? f64 : f32;
 }
-static bool tile_len_ok(const TileLen& t) { return (long long)t.len() >= g_mr_min && (long long)t.len() <= g_mr_max; }
+static bool tile_len_ok(const TileLen& t) { return t.gen || ((long long)t.len() >= g_mr_min && (long long)t.len() <= g_mr_max); }
 
 // PFFFT_HIP_TILE_MRPLAN="R1,l1,R2,l2" forces the two tile lengths of the sizes they multiply to (A/B): read ONCE, and only
 // lengths that are instantiated are accepted (an arbitrary pair used to surface as "tile pass length out of range" after the
@@ -182,7 +210,28 @@ static const ForcedPlan& forced_plan() {
     return f;
 }
 
+// PFFFT_HIP_TILE_FORCE="L1[g],L2[g]" (A/B): the two tile lengths by value, g = the run-time plan even where a register-tiled kernel exists
+static bool forced_lengths(long long n, bool is_double, TileLen& a, TileLen& b) {
+    static const char* e = getenv("PFFFT_HIP_TILE_FORCE");
+    if (!e) return false;
+    int l1 = 0, l2 = 0;
+    char g1 = 0, g2 = 0;
+    if (sscanf(e, "%d%c%d%c", &l1, &g1, &l2, &g2) < 3) return false;
+    const bool gen1 = g1 == 'g', gen2 = g2 == 'g';
+    if (gen1 && sscanf(e, "%dg,%d%c", &l1, &l2, &g2) < 2) return false;
+    if ((long long)l1 * l2 != n) return false;
+    auto pick = [&](int L, bool gen, TileLen& t) {
+        if (!gen)
+            for (const TileLen& v : tile_lengths(is_double)) if ((long long)v.len() == L && !v.gen) { t = v; return true; }
+        if (!tile_gen_length_ok(L, is_double)) return false;
+        t = TileLen{L, 0, true};
+        return true;
+    };
+    return pick(l1, gen1, a) && pick(l2, gen2 || g2 == 'g', b);
+}
+
 static bool tile_plan_search(long long n, bool is_double, bool deep, TileLen& a, TileLen& b) {
+    if (forced_lengths(n, is_double, a, b)) return true;
     {
         const ForcedPlan& f = forced_plan();
         if (f.ok && (long long)f.a.len() * (long long)f.b.len() == n) { a = f.a; b = f.b; return true; }
@@ -195,8 +244,12 @@ static bool tile_plan_search(long long n, bool is_double, bool deep, TileLen& a,
         const long long L2 = n / (long long)ta.len();
         for (const TileLen& tb : V) {
             if ((long long)tb.len() != L2 || !tile_len_ok(tb)) continue;
+            // (double: the register-tiled kernels are built without the ragged last tile - the OTHER length must be a multiple of 8)
+            if (is_double && ((!ta.gen && tb.len() % 8) || (!tb.gen && ta.len() % 8))) continue;
             // (float: a length that is 8 mod 16 leaves the OTHER pass a half-empty last tile of 8 sequences)
-            const int c = tile_cost(ta, true) * ragged_pct(tb.len(), is_double) / 100 + tile_cost(tb, false) * ragged_pct(ta.len(), is_double) / 100;
+            int c = tile_cost(ta, true, tb.len(), is_double) * ragged_pct(tb.len(), is_double) / 100 + tile_cost(tb, false, ta.len(), is_double) * ragged_pct(ta.len(), is_double) / 100;
+            // (lengths that are not multiples of 4 cannot carry the internal layout: a reorder sweep, ~130, on the unordered half of the calls)
+            if (ta.len() % 4 || tb.len() % 4) c += 40;
             if (c < best) { best = c; a = ta; b = tb; found = true; }
         }
     }
@@ -216,8 +269,10 @@ static bool tile_plan3_search(long long n, bool is_double, TileLen& a, TileLen& 
             const long long L3 = rem / (long long)tb.len();
             for (const TileLen& tc : V) {
                 if ((long long)tc.len() != L3 || !tile_len_ok(tc)) continue;
-                const int cst = tile_cost(ta, true) * ragged_pct(tb.len() * tc.len(), is_double) / 100 + tile_cost(tb, true) * ragged_pct(tc.len(), is_double) / 100 +
-                                tile_cost(tc, false) * ragged_pct(ta.len(), is_double) / 100;
+                if (is_double && ((!ta.gen && (tb.len() * tc.len()) % 8) || (!tb.gen && tc.len() % 8) || (!tc.gen && ta.len() % 8))) continue;
+                const int cst = tile_cost(ta, true, tb.len() * tc.len(), is_double) * ragged_pct(tb.len() * tc.len(), is_double) / 100 +
+                                tile_cost(tb, true, tc.len(), is_double) * ragged_pct(tc.len(), is_double) / 100 +
+                                tile_cost(tc, false, ta.len(), is_double) * ragged_pct(ta.len(), is_double) / 100;
                 if (cst < best) { best = cst; a = ta; b = tb; c = tc; }
             }
         }
@@ -260,6 +315,20 @@ bool tile_has_plan(long long n, bool is_double, bool deep) {
     if (g_variant == 83) return false;                   // variant 83: the streaming passes for these sizes (A/B)
     TileLen a, b, c;
     return tile_plan(n, is_double, deep, a, b) || (deep && n <= (1ll << 27) && tile_plan3(n, is_double, a, b, c));
+}
+
+// bit 0: the last pass can store the internal layout, bit 1: the first pass can read it.  The layout is blocks of four adjacent bins of
+// the four quarters of the spectrum: the pass's tile length (the quarters) and its sequence count (the other lengths) are multiples of 4
+int tile_plan_layouts(long long n, bool is_double, bool deep) {
+    if (n > 0 && (n & (n - 1)) == 0) return 3;
+    const PlanEntry& e = plan_of(n, is_double, deep);
+    if (e.passes == 2) return ((e.t[1].len() % 4 || e.t[0].len() % 4) ? 0 : 1) | ((e.t[0].len() % 4 || e.t[1].len() % 4) ? 0 : 2);
+    if (deep) {
+        const PlanEntry& e3 = plan_of(n, is_double, true);
+        if (e3.passes == 3)
+            return ((e3.t[2].len() % 4 || e3.t[0].len() % 4 || e3.t[1].len() % 4) ? 0 : 1) | ((e3.t[0].len() % 4 || (e3.t[1].len() * e3.t[2].len()) % 4) ? 0 : 2);
+    }
+    return 0;
 }
 
 int tile_plan_lengths(long long n, bool is_double, bool deep, int lengths[3]) {

@@ -200,13 +200,16 @@ def test_legal_size_enumeration_matches_the_library():
 def test_tile_planner_over_every_legal_size():
     """The planner of the tile passes beyond LDS (tile_tu.hip, reached through pffft_hip_tile_plan: host arithmetic, no GPU): for
     EVERY legal core size n = 16 2^a 3^b 5^c up to 2^24, both precisions, with and without `deep`, a plan is 2 or 3 tile lengths
-    whose product is n, each one an instantiated length (power of two 64 .. 1024, or R0 2^b with R0 in {3, 5, 9, 15, 25, 27, 45},
-    48 .. 768) and a multiple of 8 (a tile is 16 float / 8 double sequences; a float length that is 8 mod 16 leaves the other pass a
-    ragged last tile) - a plan that names a length without a kernel would only fail at launch time, beyond the sizes the GPU walk of tests/test_gpu_round3.py covers."""
+    whose product is n, each one an instantiated length: power of two 64 .. 1024, R0 2^b with R0 in {3, 5, 9, 15, 25, 27, 45}, 48 .. 768
+    (register-tiled, fft_tile.h), or - round 4 - any 2^a 3^b 5^c from 32 to 864 on the run-time plans of fft_tileg.h (float: even, a 16-byte
+    unit is two sequences of the other pass; double next to a register-tiled pass: a multiple of 8, those kernels are built without the
+    ragged last tile).  A plan that names a length without a kernel would only fail at launch time, beyond the sizes the GPU walk of
+    tests/test_gpu_round3.py covers.  With the run-time lengths EVERY legal size beyond LDS up to 2^21 has a plan when the streaming route
+    would take five sweeps (deep)."""
     import pffft_amd as pa
     from conftest import legal_sizes
 
-    def instantiated(L, is_double):
+    def register_tiled(L):
         r0 = L
         b = 0
         while r0 % 2 == 0:
@@ -216,6 +219,13 @@ def test_tile_planner_over_every_legal_size():
         if r0 not in (3, 5, 9, 15, 25, 27, 45) or not 48 <= L <= 768:
             return False
         return b >= (3 if r0 >= 9 else 4)
+
+    def run_time(L, is_double):
+        m = L
+        for q in (2, 3, 5):
+            while m % q == 0:
+                m //= q
+        return m == 1 and 32 <= L <= 864 and (is_double or L % 2 == 0)
 
     covered = {False: 0, True: 0}
     sizes = [n for n in legal_sizes(pa.COMPLEX, 16, 1 << 24)]
@@ -230,19 +240,26 @@ def test_tile_planner_over_every_legal_size():
                 prod = 1
                 for L in plan:
                     prod *= L
-                    assert instantiated(L, is_double), (n, is_double, deep, plan)
-                    assert L % 8 == 0, (n, plan)       # (float: 8 mod 16 = a ragged last tile in the other pass, TileDesc::last_units)
+                    assert register_tiled(L) or run_time(L, is_double), (n, is_double, deep, plan)
                 assert prod == n, (n, plan)
+                if is_double and len(plan) == 2:       # a register-tiled double pass sees whole tiles of 8 sequences
+                    for L, other in ((plan[0], plan[1]), (plan[1], plan[0])):
+                        assert not register_tiled(L) or other % 8 == 0, (n, plan)
                 if n & (n - 1):
-                    assert all(L <= 768 for L in plan) and (len(plan) == 2 or deep), (n, deep, plan)
+                    assert all(L <= 864 for L in plan) and (len(plan) == 2 or deep), (n, deep, plan)
                 if deep and n & (n - 1):
                     covered[is_double] += 1
             # without `deep` a plan is never costlier than with it: whatever is planned shallow is planned deep as well
             if pa.tile_plan(n, is_double, False):
                 assert pa.tile_plan(n, is_double, True), n
+            if n <= (1 << 21) and n * (16 if is_double else 8) > 80000 and n & (n - 1):
+                assert pa.tile_plan(n, is_double, True), (n, is_double)
     # the sizes DESIGN.md §3.5 names
     assert pa.tile_plan(61440) == [256, 240] and pa.tile_plan(115200) == [480, 240] and pa.tile_plan(9216, True) == [64, 144]
     assert pa.tile_plan(12000) == [] and pa.tile_plan(1024000) == [] and len(pa.tile_plan(1024000, False, True)) == 3
-    assert pa.tile_plan(288000) == [] and pa.tile_plan(288000, False, True) == [400, 720]      # two costly passes beat five sweeps
+    assert pa.tile_plan(288000) == [480, 600]                    # (round 3: [] / [400, 720] - 600 = 75 x 8 is a run-time length)
+    assert pa.tile_plan(518400) == [] and pa.tile_plan(518400, False, True) == [600, 864]      # two costly passes beat five sweeps
+    assert pa.tile_plan(600000) == [] and pa.tile_plan(600000, False, True) == [750, 800] and pa.tile_plan(314928, True, True) == [486, 648]
     assert pa.tile_plan(1 << 16) == [256, 256] and pa.tile_plan(1 << 22) == [128, 128, 256] and pa.tile_plan(2048) == []
     assert covered[False] > 100 and covered[True] > 150, covered
+

@@ -238,3 +238,81 @@ def test_real_forward_two_sweeps(ref, dt, tol, lg):
     finally:
         pa.set_variant(0)
     s.close(); rs.close()
+
+
+# ------------------------------------------------------------------ tile passes on a run-time mixed-radix plan (fft_tileg.h)
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("N", [291600, 314928, 500000, 524880, 600000])
+def test_runtime_tile_plans(ref, dt, N):
+    """Sizes with few factors of two and a large odd part (2^4 3^6 5^2 ... 2^6 3 5^5) had no two-pass plan on the register-tiled tile
+    lengths (R0 2^b, b >= 3) and ran the five streaming sweeps; the tile passes of fft_tileg.h take any length 2^a 3^b 5^c up to 864
+    (486 x 648, 750 x 800 ...).  Complex N and real 2N, four direction x layout combinations against oracle/_ref on a batch that takes
+    the tiles in order from the per-XCD counters (more tiles than workgroups), and on two vectors (static XCD-contiguous map, a grid
+    rounded up to whole eights); ordered == zreorder(unordered) bit for bit; in place == out of place."""
+    from conftest import relerr, tol_for
+    from test_gpu_round3 import _check_size
+    dtype = np.float32 if dt == "f32" else np.float64
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    L = pa.lib()
+    import ctypes
+    lens = (ctypes.c_int * 3)()
+    L.pffft_hip_tile_plan.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int * 3]
+    assert L.pffft_hip_tile_plan(N, int(dt == "f64"), 1, lens) >= 2, "no tile plan"
+    for tr, NN in ((pa.COMPLEX, N), (pa.REAL, 2 * N)):
+        _check_size(ref, NN, tr, dt, batch=2)
+        s = pa.Setup(NN, tr, dtype)
+        rs = ref.setup(NN, tr, dtype)
+        B = 24 if dt == "f32" else 12
+        x = _uniform((B, s.vec_scalars), 4242 + N % 1000, tdt)
+        xh = x[[0, B // 2, B - 1]].cpu().numpy()
+        for d in (pa.FORWARD, pa.BACKWARD):
+            got_o = s.transform_batch(x, None, d, True)
+            e = relerr(got_o[[0, B // 2, B - 1]].cpu().numpy(), rs.batch(xh, d, True))
+            assert e <= tol_for(dt, NN), (dt, tr, NN, d, e)
+            xi = x.clone()
+            assert torch.equal(s.transform_batch(xi, xi, d, True), got_o), "in place != out of place"
+        fu = s.transform_batch(x, None, pa.FORWARD, False)
+        assert torch.equal(s.zreorder_batch(fu, None, pa.FORWARD), s.transform_batch(x, None, pa.FORWARD, True))
+        s.close(); rs.close()
+
+
+_FORCED = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import pffft_amd as pa
+from oracle import ref as oref
+R = oref.get()
+dt = {dt!r}
+dtype = np.float32 if dt == "f32" else np.float64
+tol = 1e-5 if dt == "f32" else 2e-7            # (double with factors 3 / 5: the reference's own float-suffixed constants, conftest.tol_for)
+N = {N}
+s = pa.Setup(N, pa.COMPLEX, dtype); rs = R.setup(N, pa.COMPLEX, dtype)
+g = torch.Generator(device="cuda"); g.manual_seed(7)
+x = torch.empty((5, 2 * N), device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64).uniform_(-1, 1, generator=g)
+xh = x.cpu().numpy()
+for d in (pa.FORWARD, pa.BACKWARD):
+    for o in (True, False):
+        got = s.transform_batch(x, None, d, o).cpu().numpy()
+        want = rs.batch(xh, d, o)
+        e = max(float(np.abs(got[i].astype(np.float64) - want[i]).max() / np.abs(want[i]).max()) for i in range(5))
+        assert e <= tol, (d, o, e)
+X = np.fft.fft(xh[:, 0::2].astype(np.float64) + 1j * xh[:, 1::2].astype(np.float64))
+got = s.transform_batch(x, None, pa.FORWARD, True).cpu().numpy()
+e = float(np.abs((got[:, 0::2] + 1j * got[:, 1::2]) - X).max() / np.abs(X).max())
+assert e <= (1e-5 if dt == "f32" else 1e-12), e
+print("FORCED-OK")
+"""
+
+
+@pytest.mark.parametrize("dt,N,plan", [("f32", 10800, "108,100"), ("f32", 10800, "60,180"), ("f32", 10800, "270,40"), ("f32", 10800, "120,90"),
+                                       ("f32", 11664, "162g,72g"), ("f64", 10800, "135,80"), ("f64", 10800, "40,270"), ("f64", 50000, "125,400"),
+                                       ("f64", 18000, "225,80g")])
+def test_runtime_tile_plans_forced_lengths(dt, N, plan):
+    """The short tile lengths (128 / 256 / 512-thread workgroups, radices 2 .. 12, ragged last tiles of 2 .. 14 sequences, odd lengths in
+    double, a register-tiled pass next to a run-time one) on sizes whose production route is the streaming passes: the plan is forced by
+    PFFFT_HIP_TILE_FORCE (read once per process: a child process), values against oracle/_ref and against a float64 DFT."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PFFFT_HIP_TILE_FORCE=plan)
+    r = subprocess.run([sys.executable, "-c", _FORCED.format(root=root, dt=dt, N=N)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FORCED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
