@@ -49,6 +49,11 @@ struct TileDesc {
     // column length N1 of the real four-step split (rows k1 <= N1 / 2 exist)
     unsigned long long ovstride;
     unsigned rn1;
+    // round 4, which tiles a workgroup takes (workgroup b runs on XCD b mod 8): bit 0 - static stride: XCD x takes a CONTIGUOUS eighth of
+    // every sweep of the grid (the grid is a whole number of eights); bit 1 - in order: one work counter per XCD over a contiguous eighth
+    // of the tiles (ctr[0 .. 7] next, ctr[8] done).  Tiles that share 128-byte lines then meet in one L2, and eight counter addresses
+    // serve the start-up burst of three grabs per workgroup (fft_tileg.h has the measurements)
+    unsigned xmode;
 };
 
 template <typename T> struct TileUnit;                // one 16-byte LDS / global unit
@@ -231,17 +236,23 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     const bool dyn = ctr != nullptr;
     // ids of the counter / the static stride are GROUPS of K consecutive tiles: gcur = the group in work, gnext = the one after
     const unsigned K = D.group > 1 ? D.group : 1u;
-    unsigned long long gcur = blockIdx.x, gnext = (unsigned long long)blockIdx.x + gridDim.x;
+    const bool xmap = !dyn && (D.xmode & 1u), xctr = dyn && (D.xmode & 2u);
+    const unsigned long long gstride = xmap ? 8ull * ((gridDim.x + 7) / 8) : gridDim.x;
+    unsigned long long gcur = xmap ? (unsigned long long)(blockIdx.x % 8) * ((gridDim.x + 7) / 8) + blockIdx.x / 8 : blockIdx.x, gnext = gcur + gstride;
+    const unsigned long long ngroups = (ntiles + K - 1) / K, xper = (ngroups + 7) / 8, xbase = xctr ? (blockIdx.x % 8) * xper : 0;
+    const unsigned long long xend = xctr ? (xbase + xper < ngroups ? xbase + xper : ngroups) : ngroups;
+    unsigned* cnext = ctr + (xctr ? blockIdx.x % 8 : 0);
+    // The first TWO groups of a workgroup are static (its index among the workgroups of its counter, and that plus their number): the counter
+    // hands out what follows.  (Round 3 took all three start-up grabs from the counter: on a short launch - 512 tiles on 256 workgroups - the
+    // first 170 workgroups to arrive took three tiles each and the rest none: 34 us per pass against 10 us for 256 tiles; and the start-up
+    // burst of three atomics per workgroup on one address is off the critical path now.)
+    const unsigned long long g0 = xctr ? gridDim.x / 8 : gridDim.x, lid = xctr ? blockIdx.x / 8 : blockIdx.x;
+    auto ranged = [&](unsigned long long local) -> unsigned long long { const unsigned long long g = xbase + local; return g < xend ? g : ngroups; };
+    auto grabbed = [&](unsigned v) -> unsigned long long { return ranged(2 * g0 + v); };
     unsigned pend = 0;
     if (dyn) {
-        if (tid == 0) {
-            s_next[0] = atomicAdd(&ctr[0], 1u);
-            s_next[1] = atomicAdd(&ctr[0], 1u);
-            pend = atomicAdd(&ctr[0], 1u);
-        }
-        __syncthreads();
-        gcur = s_next[0]; gnext = s_next[1];
-        __syncthreads();
+        gcur = ranged(lid); gnext = ranged(lid + g0);
+        if (tid == 0) pend = atomicAdd(cnext, 1u);
     }
     unsigned sub = 0;                                 // tile of the group in work
     unsigned long long tile = gcur * K, tile1 = K > 1 ? tile + 1 : gnext * K;
@@ -253,7 +264,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     for (unsigned it = 0; tile < ntiles; ++it) {
         if (dyn && tid == 0 && sub == 0) {
             s_next[gi & 1] = pend;                   // the group after the next one, read by everyone after the first barrier below
-            pend = atomicAdd(&ctr[0], 1u);
+            pend = atomicAdd(cnext, 1u);
         }
         const CX* src; CX* dst; unsigned col0; unsigned long long ebase = 0;
         int pv;
@@ -593,7 +604,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
         }
         // next tile: the group's next one, or the first of the next group (whose successor was published at this group's start)
         unsigned long long gnn = gnext;
-        if (sub + 1 == K) gnn = dyn ? (unsigned long long)s_next[gi & 1] : gnext + gridDim.x;
+        if (sub + 1 == K) gnn = dyn ? grabbed(s_next[gi & 1]) : gnext + gstride;
         __syncthreads();
         tile = tile1;
         if (++sub == K) { sub = 0; gcur = gnext; gnext = gnn; ++gi; }
@@ -601,8 +612,11 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     }
     if (dyn && tid == 0) {
         __threadfence();
-        const unsigned dn = atomicAdd(&ctr[1], 1u);
-        if (dn == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+        const unsigned dn = atomicAdd(&ctr[xctr ? 8 : 1], 1u);
+        if (dn == gridDim.x - 1) {
+            if (xctr) { for (int i = 0; i < 9; ++i) atomicExch(&ctr[i], 0u); }
+            else { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+        }
     }
 }
 

@@ -198,11 +198,14 @@ tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned lon
     const unsigned long long xper = (ntiles + 7) / 8, xbase = xctr ? (blockIdx.x % 8) * xper : 0;
     const unsigned long long xend = xctr ? (xbase + xper < ntiles ? xbase + xper : ntiles) : ntiles;
     unsigned* cnext = ctr + (xctr ? blockIdx.x % 8 : 0);
-    auto grabbed = [&](unsigned v) -> unsigned long long { const unsigned long long t = xbase + v; return t < xend ? t : ntiles; };
+    // the first two tiles of a workgroup are static (its index among the workgroups of its counter, and that plus their number); the counter
+    // hands out what follows (fft_tile.h: three start-up grabs per workgroup left a short launch unbalanced)
+    const unsigned long long g0 = xctr ? gridDim.x / 8 : gridDim.x, lid = xctr ? blockIdx.x / 8 : blockIdx.x;
+    auto ranged = [&](unsigned long long local) -> unsigned long long { const unsigned long long t = xbase + local; return t < xend ? t : ntiles; };
+    auto grabbed = [&](unsigned v) -> unsigned long long { return ranged(2 * g0 + v); };
     if (dyn) {
-        if (tid == 0) { s_next[0] = atomicAdd(cnext, 1u); s_next[1] = atomicAdd(cnext, 1u); pend = atomicAdd(cnext, 1u); }
-        __syncthreads();
-        tile = grabbed(s_next[0]); tile1 = grabbed(s_next[1]);
+        tile = ranged(lid); tile1 = ranged(lid + g0);
+        if (tid == 0) pend = atomicAdd(cnext, 1u);
     }
     __syncthreads();
     LD nxt[NLD];

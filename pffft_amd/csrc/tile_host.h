@@ -55,8 +55,19 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     // order).  PFFFT_HIP_TILE_DYN=0/1 forces it (A/B).
     static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_TILE_DYN"); return e ? atoi(e) : -1; }();
     const bool want_dyn = dyn_env >= 0 ? dyn_env != 0 : (size_t)G::L * G::C * sizeof(cx<T>) >= 60 * 1024;   // (L = 480: 60 KiB)
-    unsigned* ctr = (ngroups <= grid || !want_dyn || ntiles >= 0xfffffff0ull) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D, ctr);
+    // XCD-aware tile order (TileDesc::xmode, round 4): PFFFT_HIP_TILE_XMODE = 0 off, 1 static map only, 2 per-XCD counters only, 3 both (A/B).
+    // OFF for these kernels: their strides are whole or half lines, and measured (tools/r4_xmode.sh) the static map costs 0-4 %, the per-XCD
+    // counters N = 2^20 0.20-0.23 -> 0.17-0.19 (one in-order sweep over the whole batch is what HBM rewards there); they pay only on the
+    // strides of fft_tileg.h that are neither
+    static const int xmode_env = [] { const char* e = getenv("PFFFT_HIP_TILE_XMODE"); return e ? atoi(e) : 0; }();
+    const bool dynm = !(ngroups <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
+    const bool xctr = dynm && (xmode_env & 2) && grid % 8 == 0 && ngroups >= 64 && D.group <= 1;
+    // (per-XCD counters: nine words = five {next, done} pairs of the ring, which is allocated with that much room past its end)
+    unsigned* ctr = !dynm ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(xctr ? 5 : 1) % CTR_RING);
+    TileDesc D2 = D;
+    D2.xmode = (xctr ? 2u : 0u) | ((!dynm && (xmode_env & 1) && D.group <= 1) ? 1u : 0u);
+    if (D2.xmode & 1u) grid = (grid + 7) / 8 * 8;      // (the static map is a bijection on a grid of whole eights; the surplus workgroups retire at once)
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D2, ctr);
     PF_CHECK(hipGetLastError());
     return 0;
 }
