@@ -202,9 +202,17 @@ big_block_kernel(const T* __restrict__ in, T* __restrict__ out, long long batch,
         const int nunits = nblk * (32 / G::CH);
         const long long ubase = (vec * 2 * n + 8 * t0) / G::CH;                   // first 16-byte unit of the tile in the internal layout
         CX q[4];                                                                  // the four quarters' values at position t
-        if constexpr (MODE == 0 || MODE == 2) {
+        if constexpr (MODE == 0 || MODE == 2 || MODE == 5) {
             // ---- canonical side in: dense runs of 64 bins per quarter
-            if constexpr (MODE == 0) {
+            if constexpr (MODE == 5) {
+                // the canonical half-complex spectrum of a real transform: the four bins of position t (the mirror image of MODE 4) - a pure
+                // permutation, for the real forward transforms whose spectrum is computed canonically (two tile sweeps, tile_real_tu.hip)
+                const long long ta = act ? t : 0;
+                q[0] = __builtin_nontemporal_load(cin + ta);
+                q[1] = __builtin_nontemporal_load(cin + (ta ? half - ta : n4));
+                q[2] = __builtin_nontemporal_load(cin + half + ta);
+                q[3] = __builtin_nontemporal_load(cin + (ta ? n - ta : n - n4));
+            } else if constexpr (MODE == 0) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) q[m] = act ? __builtin_nontemporal_load(cin + m * n4 + t) : mk<T>((T)0, (T)0);
             } else {

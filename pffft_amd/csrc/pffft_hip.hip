@@ -840,7 +840,7 @@ static int big_small_factor(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, 
 
 // one-sweep layout / pair kernels of the beyond-LDS path (fft_big.h big_block_kernel): mode 0 complex canonical -> internal,
 // 1 complex internal -> canonical, 2 real forward Z -> X (internal), 3 real backward X (internal) -> Z', 4 real backward
-// X (canonical) -> Z'.  in != out.
+// X (canonical) -> Z', 5 real X (canonical) -> X (internal), a pure permutation.  in != out.
 template <typename T>
 static int launch_block(Setup* s, int mode, const T* in, T* out, size_t batch, hipStream_t st) {
     const long long n = s->n, tiles = (long long)batch * ((n / 4 + 63) / 64);
@@ -859,7 +859,8 @@ static int launch_block(Setup* s, int mode, const T* in, T* out, size_t batch, h
         case 1: hipLaunchKernelGGL((big_block_kernel<T, 1>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
         case 2: hipLaunchKernelGGL((big_block_kernel<T, 2>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
         case 3: hipLaunchKernelGGL((big_block_kernel<T, 3>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
-        default: hipLaunchKernelGGL((big_block_kernel<T, 4>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
+        case 4: hipLaunchKernelGGL((big_block_kernel<T, 4>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
+        default: hipLaunchKernelGGL((big_block_kernel<T, 5>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
     }
     PF_CHECK(hipGetLastError());
     return 0;
@@ -873,7 +874,9 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     // real forward into the canonical spectrum, power-of-two N = 2^16 .. 2^20: two sweeps where they measured faster
     // (tile_real_tu.hip; variant 121 = always the three sweeps - complex transform + pair sweep -, 122 = two sweeps wherever the
     // length splits, A/B and tests).  Its work rows (k1 <= N1/2, whole row tiles) need a little more than n.
-    const bool rfft2 = s->transform == PFFFT_REAL && dir == PFFFT_FORWARD && ordered && g_variant != 121 && g_variant != 80 &&
+    // (ordered and unordered take the SAME route: pffft_transform_ordered == pffft_zreorder(pffft_transform) bit for bit - the unordered
+    //  spectrum is the canonical one of the two sweeps through the one-sweep permutation big_block_kernel<5>)
+    const bool rfft2 = s->transform == PFFFT_REAL && dir == PFFFT_FORWARD && g_variant != 121 && g_variant != 80 &&
                        g_variant != 82 && tile_rfft_has_plan(2LL * s->n, s->is_double != 0, g_variant != 122);
     if (rfft2) bytes = std::max(bytes, batch * tile_rfft_work_elems(2LL * s->n, s->is_double != 0) * sizeof(cx<T>));
     cx<T>*bufA, *bufB;
@@ -909,8 +912,9 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     const bool real = s->transform == PFFFT_REAL;
     const bool fwd = dir == PFFFT_FORWARD;
     if (rfft2) {
-        const int r2 = launch_tile_rfft(s, in, bufB, out, batch, 2LL * s->n, dir, st);
-        if (r2 != -1) return r2;
+        const int r2 = launch_tile_rfft(s, in, bufB, ordered ? (void*)out : (void*)bufA, batch, 2LL * s->n, dir, st);
+        if (r2 > 0) return r2;
+        if (r2 == 0) return ordered ? 0 : launch_block<T>(s, 5, (const T*)bufA, out, batch, st);
     }
     // (pair pass in place: one pair per thread, every workgroup once, in dispatch order - PFFFT_HIP_PAIR_CAP=1: the persistent
     //  grid-stride launch it replaces, A/B)

@@ -61,7 +61,8 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     // strides of fft_tileg.h that are neither
     static const int xmode_env = [] { const char* e = getenv("PFFFT_HIP_TILE_XMODE"); return e ? atoi(e) : 0; }();
     const bool dynm = !(ngroups <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
-    const bool xctr = dynm && (xmode_env & 2) && grid % 8 == 0 && ngroups >= 64 && D.group <= 1;
+    // (bit 2: per-XCD counters for the column passes with 64-byte runs only - adjacent tiles share every line there)
+    const bool xctr = dynm && ((xmode_env & 2) || ((xmode_env & 4) && PP == 4 && D.seq_contig)) && grid % 8 == 0 && ngroups >= 64 && D.group <= 1;
     // (per-XCD counters: nine words = five {next, done} pairs of the ring, which is allocated with that much room past its end)
     unsigned* ctr = !dynm ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(xctr ? 5 : 1) % CTR_RING);
     TileDesc D2 = D;

@@ -233,6 +233,13 @@ def test_real_forward_two_sweeps(ref, dt, tol, lg):
             z = x.clone()
             s.transform_batch(z, z, pa.FORWARD, True)
             assert torch.equal(z, y), (var, lg)
+            # ordered == zreorder(unordered) bit for bit on every route (the unordered transform of the two-sweep route is its canonical
+            # spectrum through a one-sweep permutation: src/pffft_priv_impl.h:1497-1498 runs the same passes for both layouts)
+            fu = s.transform_batch(x, None, pa.FORWARD, False)
+            assert torch.equal(s.zreorder_batch(fu, None, pa.FORWARD), y), (var, lg)
+            want_u = rs.batch(xh, FORWARD, False)
+            erru = (np.abs(fu.cpu().numpy().astype(np.float64) - want_u).max(axis=1) / np.abs(want_u).max(axis=1)).max()
+            assert erru <= tol, (var, lg, erru)
         den = outs[121].abs().amax(dim=1, keepdim=True)
         assert float(((outs[122] - outs[121]).abs() / den).max()) <= tol
     finally:
