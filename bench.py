@@ -27,7 +27,7 @@ At N = 1 the default line also carries `configs`: every other BASELINE config at
 its own `roofline` and `cpu_baseline` (no warm-up beyond --warmup; the first launches of each are reported as
 `first_launches_ms` next to the timed region), and `sizes`: the reference's benchmark table
 (benchmarks/bench_pffft.c:445,547-550,1140-1150: every size of its lists, real and complex, float and double, ordered and
-unordered, forward and backward; plus six legal sizes with factors 3 and 5 beyond LDS, which that list does not hold).  All GPU work runs back to back, the CPU baselines afterwards (an idle gap between
+unordered, forward and backward; plus eight legal sizes with factors 3 and 5 beyond LDS, which that list does not hold).  All GPU work runs back to back, the CPU baselines afterwards (an idle gap between
 configs lets the clocks drop and the next config starts cold).  At N > 1 the line carries the C5 sharded config, weak and
 strong, `ranks_seen` from the RCCL all-reduce and the fastest / slowest rank's ms_per_step.
 Inputs are a counter hash of (seed, GLOBAL element index) (pffft_amd/sharding.py): a shard holds the same data whatever
@@ -338,9 +338,9 @@ REF_SIZES = [64, 96, 128, 160, 192, 256, 384, 480, 512, 640, 768, 800, 1024, 204
 
 # Sizes with factors 3 and 5 beyond LDS (legal sizes of tests/test_fft_factors.c the reference's benchmark list does not hold):
 # two tile passes (15360 = 64 x 240, 61440 = 256 x 240, 102400 = 400 x 256, 368640 = 480 x 768: pffft_hip_tile_plan), three where the
-# streaming route needs five sweeps (1024000 = 80 x 160 x 80), and one size without a tile plan (12000 = 2^5 x 375: three streaming
-# passes) - DESIGN.md §3.5
-BEYOND_LDS_35 = [12000, 15360, 61440, 102400, 368640, 1024000]
+# streaming route needs five sweeps (1024000 = 64 x 200 x 80), one size that stays on three streaming passes (12000 = 2^5 x 375), and -
+# round 4 - two sizes on the run-time tile lengths of fft_tileg.h (384000 = 480 x 800, 600000 = 750 x 800; real N: half of it) - DESIGN.md §3.5
+BEYOND_LDS_35 = [12000, 15360, 61440, 102400, 368640, 384000, 600000, 1024000]
 
 
 def sizes_table(torch, pa, dev, timer, R=None):

@@ -92,11 +92,12 @@ __device__ __forceinline__ void tg_stage(typename TileUnit<T>::U* img, const cx<
 }
 
 // SEQC = 1: pass A (adjacent columns, four-step twiddle)   SEQC = 0: pass B (rows in, transposing store); canonical layouts only
-// NT = 1: streaming (nontemporal) global accesses - only where every 128-byte run of a tile is a whole line (strides that are multiples of
-// 16 float / 8 double elements); elsewhere adjacent tiles share lines, and the half a tile does not use must stay in L2 for its neighbour
+// No streaming (nontemporal) hint on the global accesses: where a stride is not whole 128-byte lines adjacent tiles share lines, and the half
+// a tile does not use must stay in L2 for its neighbour (N = 10800 on 108 x 100: 350 / 307 -> 332 / 277 us per pass); where the runs ARE whole
+// lines the hint measured no difference (N = 384000, 409600), so there is one kind of kernel
 // OINT (row pass of a forward transform) / IINT (column pass of a backward one): the spectrum leaves / arrives in the pffft-internal layout,
 // as in fft_tile.h (the layout: SURVEY.md appendix A, src/pffft_priv_impl.h:1195-1237): L and the sequence count of the pass multiples of 4
-template <typename T, int WG, int DIR, int SEQC, int NT, int OINT = 0, int IINT = 0>
+template <typename T, int WG, int DIR, int SEQC, int OINT = 0, int IINT = 0>
 __global__ void __launch_bounds__(WG, 4)
 tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned long long ntiles, TileDesc D, TileGenPlan P, unsigned* ctr) {
     typedef cx<T> CX;
@@ -157,7 +158,7 @@ tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned lon
                 const int g = tid_l + k * WG, ptq = g >> 5, rr = g & 31, bb = rr / UPB;
                 if (g < units && bb * 4 < t.pv * S) {
                     const U* gp = reinterpret_cast<const U*>(t.src + 4 * (t.eb + (unsigned long long)ptq * D.ips + 4 * bb)) + rr % UPB;
-                    r[k] = NT ? __builtin_nontemporal_load(gp) : *gp;
+                    r[k] = *gp;
                 }
             }
         } else if constexpr (SEQC) {
@@ -166,7 +167,7 @@ tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned lon
                 const int i = tid_l + k * WG, pt = i >> 3, pu = i & 7;
                 if (i < units && pu < t.pv) {
                     const U* gp = reinterpret_cast<const U*>(t.src + (unsigned long long)pt * D.ips + S * pu);
-                    r[k] = NT ? __builtin_nontemporal_load(gp) : *gp;
+                    r[k] = *gp;
                 }
             }
         } else {
@@ -175,7 +176,7 @@ tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned lon
                 const int g = tid_l + k * WG, seq = (int)__umulhi((unsigned)g, P.m_L), pt = g - seq * L;
                 if (g < C * L && seq < t.pv * S) {
                     const CX* gp = t.src + (unsigned long long)seq * D.iss + pt;
-                    r[k] = NT ? __builtin_nontemporal_load(gp) : *gp;
+                    r[k] = *gp;
                 }
             }
         }
@@ -308,7 +309,7 @@ tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned lon
                         if (sub >> 1) { o.x = u0.y; o.y = u1.y; }
                         else { o.x = u0.x; o.y = u1.x; }
                     }
-                    if constexpr (NT) __builtin_nontemporal_store(o, gp); else *gp = o;
+                    *gp = o;
                 }
             }
         } else {
@@ -326,7 +327,7 @@ tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned lon
                 }
                 if (pu < pv) {
                     U* gp = reinterpret_cast<U*>(dst + (unsigned long long)pt * D.ops + S * pu);
-                    if constexpr (NT) __builtin_nontemporal_store(x, gp); else *gp = x;
+                    *gp = x;
                 }
             }
         }

@@ -245,30 +245,33 @@ static void lanes4_run(const char* entry, complexf* in_out, int n, D* d) {
     }
 }
 
+// The float phase accumulator of the reference's table builders: one increment, then wrapped into (-pi, pi] by whole turns.  The tables
+// must carry the reference's float rounding (they are compared bit for bit), so the accumulation stays in float, step by step.
+static inline float phase_step(float phase, float inc) {
+    phase += inc;
+    for (; phase > PI_F; phase -= 2 * PI_F) {}
+    for (; phase < -PI_F; phase += 2 * PI_F) {}
+    return phase;
+}
+
 template <typename D>
 static void lanes4_init_state(D* out, float relative_freq, float phase_start_rad) {   // :519-557 (and :637, :750)
     out->phase_increment = 2 * relative_freq * PI_F;
     out->dcos_blk = 0.0F; out->dsin_blk = 0.0F;
-    float myphase = phase_start_rad;
-    for (int i = 0; i < 4; ++i) {
-        out->phase_state_i[i] = cosf(myphase);
-        out->phase_state_q[i] = sinf(myphase);
-        myphase += out->phase_increment;
-        while (myphase > PI_F) myphase -= 2 * PI_F;
-        while (myphase < -PI_F) myphase += 2 * PI_F;
+    float ph = phase_start_rad;                       // lane i starts i increments ahead
+    for (int lane = 0; lane < 4; ++lane, ph = phase_step(ph, out->phase_increment)) {
+        out->phase_state_i[lane] = cosf(ph);
+        out->phase_state_q[lane] = sinf(ph);
     }
 }
 // table entry g (g = 0..32) of F/G/H: phasor of 4*(g+1) increments, the phase accumulated in float as there
 template <typename F>
 static void lanes4_tables(float inc, F&& put) {
-    float myphase = 0.0F;
-    for (int g = 0; g < (PF_SHIFT_LIMITED_UNROLL_SIZE + PF_SHIFT_LIMITED_SIMD_SZ) / PF_SHIFT_LIMITED_SIMD_SZ; ++g) {
-        for (int k = 0; k < PF_SHIFT_LIMITED_SIMD_SZ; ++k) {
-            myphase += inc;
-            while (myphase > PI_F) myphase -= 2 * PI_F;
-            while (myphase < -PI_F) myphase += 2 * PI_F;
-        }
-        put(g, cosf(myphase), sinf(myphase));
+    constexpr int LANES = PF_SHIFT_LIMITED_SIMD_SZ, ENTRIES = (PF_SHIFT_LIMITED_UNROLL_SIZE + LANES) / LANES;
+    float ph = 0.0F;
+    for (int g = 0; g < ENTRIES; ++g) {
+        for (int k = 0; k < LANES; ++k) ph = phase_step(ph, inc);
+        put(g, cosf(ph), sinf(ph));
     }
 }
 

@@ -62,17 +62,17 @@ static const TileGenPlan* tg_plan(int L) {
     return &it->second;
 }
 
-template <typename T, int WG, int NT>
+template <typename T, int WG>
 static int tile_gen_launch(const TileGenPlan& P, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
                            bool out_int, bool in_int) {
     typedef TileGenGeom<T, WG> G;
     const size_t lds = G::lds_bytes(P.L, D.M > (1ull << (2 * G::WB)) ? 3 : 2);
     void (*k)(const cx<T>*, cx<T>*, unsigned long long, TileDesc, TileGenPlan, unsigned*);
     const bool fw = dir == PFFFT_FORWARD;
-    if (D.seq_contig && in_int && !fw) k = tileg_kernel<T, WG, BWD, 1, NT, 0, 1>;
-    else if (D.seq_contig) k = fw ? tileg_kernel<T, WG, FWD, 1, NT> : tileg_kernel<T, WG, BWD, 1, NT>;
-    else if (out_int && fw) k = tileg_kernel<T, WG, FWD, 0, NT, 1, 0>;
-    else k = fw ? tileg_kernel<T, WG, FWD, 0, NT> : tileg_kernel<T, WG, BWD, 0, NT>;
+    if (D.seq_contig && in_int && !fw) k = tileg_kernel<T, WG, BWD, 1, 0, 1>;
+    else if (D.seq_contig) k = fw ? tileg_kernel<T, WG, FWD, 1> : tileg_kernel<T, WG, BWD, 1>;
+    else if (out_int && fw) k = tileg_kernel<T, WG, FWD, 0, 1, 0>;
+    else k = fw ? tileg_kernel<T, WG, FWD, 0> : tileg_kernel<T, WG, BWD, 0>;
     int rc = allow_big_lds(k, lds);
     if (rc) return rc;
     int per_cu = 0;
@@ -113,16 +113,9 @@ int tile_gen_pass(bool is_double, int L, const void* in, void* out, unsigned lon
     }
     static const int wg128 = [] { const char* e = getenv("PFFFT_HIP_TILE_WG128"); return e ? atoi(e) : 1; }();
     const int wg = (wg128 && L <= TileGenGeom<float, 128>::LMAX) ? 128 : L <= TileGenGeom<float, 256>::LMAX ? 256 : L <= TileGenGeom<float, 512>::LMAX ? 512 : 1024;
-    // streaming accesses only where the strided 128-byte runs are whole lines (pass A: both sides at stride ips = ops; pass B: the store side)
-    const unsigned long long line = is_double ? 8 : 16;
-    static const int nt_env = [] { const char* e = getenv("PFFFT_HIP_TILE_NT"); return e ? atoi(e) : -1; }();
-    const bool nt = nt_env >= 0 ? nt_env != 0 : (D.ops % line == 0 && (!D.seq_contig || D.ips % line == 0));
-#define PF_TG2(T, WG) (nt ? tile_gen_launch<T, WG, 1>(*P, (const cx<T>*)in, (cx<T>*)out, ntiles, D, dir, st, s, out_int, in_int) \
-                          : tile_gen_launch<T, WG, 0>(*P, (const cx<T>*)in, (cx<T>*)out, ntiles, D, dir, st, s, out_int, in_int))
-#define PF_TG(T, WG) PF_TG2(T, WG)
+#define PF_TG(T, WG) tile_gen_launch<T, WG>(*P, (const cx<T>*)in, (cx<T>*)out, ntiles, D, dir, st, s, out_int, in_int)
     if (is_double) return wg == 128 ? PF_TG(double, 128) : wg == 256 ? PF_TG(double, 256) : wg == 512 ? PF_TG(double, 512) : PF_TG(double, 1024);
     return wg == 128 ? PF_TG(float, 128) : wg == 256 ? PF_TG(float, 256) : wg == 512 ? PF_TG(float, 512) : PF_TG(float, 1024);
-#undef PF_TG2
 #undef PF_TG
 }
 
