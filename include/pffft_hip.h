@@ -183,9 +183,11 @@ int pffastconv_hip_apply_batch(PFFASTCONV_Setup *, const float *d_input, int inp
 const char *pffft_hip_kernel_name(const void *setup);
 /* The tile plan of a complex core transform of n points beyond LDS (n = N for complex setups, N / 2 for real ones): returns the
  * number of tile passes over HBM — 2 or 3 — and their tile lengths in `lengths` (column pass(es) first, the row pass last), or 0
- * when the size runs on the streaming passes (or is LDS-resident: the planner is not consulted then).  `deep` != 0: the size's
- * streaming route would take five sweeps (its row length is itself beyond LDS), which admits costlier tile plans.  Pure host
- * arithmetic, no device needed: for tests and for callers that want to know what a size costs. */
+ * when the size runs on the streaming passes (or is LDS-resident: the planner is not consulted then).  `deep` = 1: the size's
+ * streaming route would take five sweeps (its row length is itself beyond LDS), which admits costlier tile plans; 0: it takes three
+ * and n is a complex transform; 2: it takes three and n is the core of a real transform of 2n points (the plans of 0 minus those
+ * that pay only for complex transforms).  Pure host arithmetic, no device needed: for tests and for callers that want to know what
+ * a size costs. */
 int pffft_hip_tile_plan(long long n, int is_double, int deep, int lengths[3]);
 const char *pffft_hip_last_error(void);
 /* Number of legacy (void) entries that failed in this process so far.  The legacy entries have no error channel

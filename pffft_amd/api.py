@@ -156,7 +156,7 @@ def tile_plan(n, is_double=False, deep=False):
     """Tile lengths of the passes over HBM of a complex core transform of n points beyond LDS ([] = streaming passes / not planned
     by the tile planner): include/pffft_hip.h pffft_hip_tile_plan.  Host arithmetic only."""
     buf = (C.c_int * 3)()
-    k = lib().pffft_hip_tile_plan(int(n), int(bool(is_double)), int(bool(deep)), buf)
+    k = lib().pffft_hip_tile_plan(int(n), int(bool(is_double)), int(deep), buf)
     return [int(buf[i]) for i in range(k)]
 
 

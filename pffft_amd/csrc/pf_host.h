@@ -123,9 +123,9 @@ int launch_fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y
 // by the first pass.
 // (n complex points; -1 = no tile plan for n.  tile_has_plan: the same answer without launching)
 // deep: the streaming route of this n would take five sweeps - three tile passes are allowed
-int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, long long n, int dir, hipStream_t st, int layout = 0, bool deep = false);
-bool tile_has_plan(long long n, bool is_double, bool deep = false);
-int tile_plan_lengths(long long n, bool is_double, bool deep, int lengths[3]);
-int tile_plan_layouts(long long n, bool is_double, bool deep);   // bit 0: internal layout out of the last pass, bit 1: into the first   // 0 / 2 / 3 passes (pffft_hip_tile_plan)
+int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, long long n, int dir, hipStream_t st, int layout = 0, int mode = 0);
+bool tile_has_plan(long long n, bool is_double, int mode = 0);   // mode: 0 complex / three streaming sweeps, 1 five (deep), 2 real core / three
+int tile_plan_lengths(long long n, bool is_double, int mode, int lengths[3]);
+int tile_plan_layouts(long long n, bool is_double, int mode);   // bit 0: internal layout out of the last pass, bit 1: into the first   // 0 / 2 / 3 passes (pffft_hip_tile_plan)
 
 }  // namespace pf

@@ -928,9 +928,10 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     // two (three beyond 2^20) tile passes: power-of-two n and the n whose odd part splits over two tile lengths (tile_tu.hip)
     // (deep: the row length of the streaming route is itself beyond LDS, or there is no streaming plan - five sweeps)
     const bool deep = !s->bigR || !s->sub || s->sub->kernel == K_BIG;
-    bool tiled = g_variant != 80 && g_variant != 82 && tile_has_plan(s->n, s->is_double, deep);
+    const int tmode = deep ? 1 : real ? 2 : 0;
+    bool tiled = g_variant != 80 && g_variant != 82 && tile_has_plan(s->n, s->is_double, tmode);
     // complex backward from the internal layout on the tile passes: the first one reads the layout itself (variant 86 = off)
-    const int tlay = tiled ? tile_plan_layouts(s->n, s->is_double, deep) : 0;
+    const int tlay = tiled ? tile_plan_layouts(s->n, s->is_double, tmode) : 0;
     // a complex plan with a run-time tile pass (fft_tileg.h) cannot fuse the internal layout on that side: two passes + a reorder sweep
     // against the three streaming passes, which fuse it (measured 0.13-0.15 against 0.18-0.24) - and ordered / unordered must run the SAME
     // arithmetic (ordered == zreorder(unordered) bit for bit): such a plan is used for both layouts or for none.  It stays where the
@@ -964,7 +965,7 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
         // lengths: two passes (fft_tile.h); variant 82 = the three-to-five-pass composition below, 83 = that only for the latter (A/B)
         // complex forward into the internal layout: the last tile pass stores the layout itself (variant 86 = separate reorder sweep, A/B)
         const bool fuse_int = fwd && !ordered && !real && (tlay & 1) && g_variant != 86;
-        const int trc = launch_tile_fft(s, cur, bufB, fuse_int ? (cx<T>*)out : dest, batch, (long long)s->n, dir, st, fuse_int ? 1 : fuse_in ? 2 : 0, deep);
+        const int trc = launch_tile_fft(s, cur, bufB, fuse_int ? (cx<T>*)out : dest, batch, (long long)s->n, dir, st, fuse_int ? 1 : fuse_in ? 2 : 0, tmode);
         if (trc > 0) return trc;
         if (trc < 0 && fuse_in) { g_last_error = "pffft_hip: no tile plan for this size beyond LDS"; return (int)hipErrorInvalidValue; }
         done = trc == 0;
@@ -1560,7 +1561,7 @@ PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
 }
 PF_EXPORT int pffft_hip_tile_plan(long long n, int is_double, int deep, int lengths[3]) {
     if (!lengths) return 0;
-    return pf::tile_plan_lengths(n, is_double != 0, deep != 0, lengths);
+    return pf::tile_plan_lengths(n, is_double != 0, deep < 0 || deep > 2 ? 1 : deep, lengths);
 }
 PF_EXPORT const char* pffft_hip_last_error(void) { return pf::g_last_error.c_str(); }
 PF_EXPORT unsigned pffft_hip_error_count(void) { return pf::g_error_count.load(); }

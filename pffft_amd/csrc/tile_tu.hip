@@ -129,6 +129,7 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
 // odd stages (25, 27, 45): columns 118-128 (L = 720: 176-192), rows 102-138 (L = 720: 165-169).  false: no plan - the three streaming passes of fft_big.h.
 static int g_mr_min = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMIN"); return e ? atoi(e) : 48; }();    // A/B: shortest / longest
 static int g_mr_max = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMAX"); return e ? atoi(e) : 768; }();   // tile length of a plan
+static int g_wide_cost = [] { const char* e = getenv("PFFFT_HIP_TILE_WIDECOST"); return e ? atoi(e) : 340; }();   // A/B: 0 = off
 static int g_gen_cost = [] { const char* e = getenv("PFFFT_HIP_TILE_GENCOST"); return e ? atoi(e) : 1; }();   // A/B: 0 = no run-time plans
 // `stride`: the element stride between the points of the pass's strided side - the column count of a column pass (loads and stores), the
 // row count (outer) of a row pass (stores).  Costs in the unit of the table above (~ us per 0.5 GiB of float vectors / 2.1), round 4,
@@ -230,15 +231,21 @@ static bool forced_lengths(long long n, bool is_double, TileLen& a, TileLen& b) 
     return pick(l1, gen1, a) && pick(l2, gen2 || g2 == 'g', b);
 }
 
-static bool tile_plan_search(long long n, bool is_double, bool deep, TileLen& a, TileLen& b) {
+// mode: 0 = the streaming route of this size is three sweeps, complex transform; 1 = it is five (deep); 2 = three sweeps, the core of a REAL
+// transform (no wide threshold: real N = 2n measured 1-4 % slower on those plans - the pair sweep dominates either way)
+static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, TileLen& b) {
+    const bool deep = mode == 1;
     if (forced_lengths(n, is_double, a, b)) return true;
     {
         const ForcedPlan& f = forced_plan();
         if (f.ok && (long long)f.a.len() * (long long)f.b.len() == n) { a = f.a; b = f.b; return true; }
     }
     const std::vector<TileLen>& V = tile_lengths(is_double);
-    int best = deep ? 460 : 286;                         // (deep: the streaming route takes five sweeps, ~480)
-    bool found = false;
+    static const int maxcost_env = [] { const char* e = getenv("PFFFT_HIP_TILE_MAXCOST"); return e ? atoi(e) : 286; }();   // A/B
+    int best = deep ? 460 : maxcost_env;                 // (deep: the streaming route takes five sweeps, ~480)
+    bool found = false, have_wide = false;
+    int wide_best = g_wide_cost;
+    TileLen wa{1, 0}, wb{1, 0};
     for (const TileLen& ta : V) {
         if (!tile_len_ok(ta) || n % (long long)ta.len()) continue;
         const long long L2 = n / (long long)ta.len();
@@ -250,9 +257,15 @@ static bool tile_plan_search(long long n, bool is_double, bool deep, TileLen& a,
             int c = tile_cost(ta, true, tb.len(), is_double) * ragged_pct(tb.len(), is_double) / 100 + tile_cost(tb, false, ta.len(), is_double) * ragged_pct(ta.len(), is_double) / 100;
             // (lengths that are not multiples of 4 cannot carry the internal layout: a reorder sweep, ~130, on the unordered half of the calls)
             if (ta.len() % 4 || tb.len() % 4) c += 40;
-            if (c < best) { best = c; a = ta; b = tb; found = true; }
+            // (float, not deep: a plan with a run-time length that carries the internal layout is taken up to 340 - the sizes with 2^4 / 2^5
+            //  and a large odd part, whose streaming route cannot read the internal layout in its column pass (R odd): four combinations
+            //  0.23 / 0.24 / 0.25 / 0.18 -> 0.21 / 0.24 / 0.24 / 0.24, tools/r4_gen_scan4.sh; double: the run-time passes are 5-17 % behind)
+            const bool wide = mode == 0 && !is_double && (ta.gen || tb.gen) && ta.len() % 4 == 0 && tb.len() % 4 == 0;
+            if (c < best) { best = c; found = true; a = ta; b = tb; }
+            else if (wide && c < wide_best) { wide_best = c; wa = ta; wb = tb; have_wide = true; }
         }
     }
+    if (!found && have_wide) { a = wa; b = wb; found = true; }
     return found;
 }
 
@@ -283,55 +296,59 @@ static bool tile_plan3_search(long long n, bool is_double, TileLen& a, TileLen& 
 // The plan of a size is a pure function of (n, precision, deep): searched once, then served from a table (launch_big asked
 // twice per transform, under the setup's lock; the three-pass search walks ~26^3 length triples)
 struct PlanEntry { int passes = 0; TileLen t[3] = {{1, 0}, {1, 0}, {1, 0}}; };
-static const PlanEntry& plan_of(long long n, bool is_double, bool deep) {
+static const PlanEntry& plan_of(long long n, bool is_double, int mode) {
+    const bool deep = mode == 1;
     static std::mutex mu;
     static std::map<long long, PlanEntry> tab;
-    const long long key = n * 4 + (is_double ? 2 : 0) + (deep ? 1 : 0);
+    const long long key = n * 8 + (is_double ? 4 : 0) + mode;
     std::lock_guard<std::mutex> lk(mu);
     auto it = tab.find(key);
     if (it == tab.end()) {
         PlanEntry e;
-        if (tile_plan_search(n, is_double, deep, e.t[0], e.t[1])) e.passes = 2;
+        if (tile_plan_search(n, is_double, mode, e.t[0], e.t[1])) e.passes = 2;
         else if (deep && n <= (1ll << 27) && tile_plan3_search(n, is_double, e.t[0], e.t[1], e.t[2])) e.passes = 3;
         it = tab.emplace(key, e).first;
     }
     return it->second;
 }
-static bool tile_plan(long long n, bool is_double, bool deep, TileLen& a, TileLen& b) {
-    const PlanEntry& e = plan_of(n, is_double, deep);
+static bool tile_plan(long long n, bool is_double, int mode, TileLen& a, TileLen& b) {
+    const PlanEntry& e = plan_of(n, is_double, mode);
     if (e.passes != 2) return false;
     a = e.t[0]; b = e.t[1];
     return true;
 }
 static bool tile_plan3(long long n, bool is_double, TileLen& a, TileLen& b, TileLen& c) {
-    const PlanEntry& e = plan_of(n, is_double, true);
+    const PlanEntry& e = plan_of(n, is_double, 1);
     if (e.passes != 3) return false;
     a = e.t[0]; b = e.t[1]; c = e.t[2];
     return true;
 }
 
-bool tile_has_plan(long long n, bool is_double, bool deep) {
+bool tile_has_plan(long long n, bool is_double, int mode) {
+    const bool deep = mode == 1;
     if (n > 0 && (n & (n - 1)) == 0) return n >= (1 << 12) && n <= (1ll << 27);
     if (g_variant == 83) return false;                   // variant 83: the streaming passes for these sizes (A/B)
     TileLen a, b, c;
-    return tile_plan(n, is_double, deep, a, b) || (deep && n <= (1ll << 27) && tile_plan3(n, is_double, a, b, c));
+    return tile_plan(n, is_double, mode, a, b) || (deep && n <= (1ll << 27) && tile_plan3(n, is_double, a, b, c));
 }
 
 // bit 0: the last pass can store the internal layout, bit 1: the first pass can read it.  The layout is blocks of four adjacent bins of
 // the four quarters of the spectrum: the pass's tile length (the quarters) and its sequence count (the other lengths) are multiples of 4
-int tile_plan_layouts(long long n, bool is_double, bool deep) {
+int tile_plan_layouts(long long n, bool is_double, int mode) {
+    const bool deep = mode == 1;
     if (n > 0 && (n & (n - 1)) == 0) return 3;
-    const PlanEntry& e = plan_of(n, is_double, deep);
+    const PlanEntry& e = plan_of(n, is_double, mode);
     if (e.passes == 2) return ((e.t[1].len() % 4 || e.t[0].len() % 4) ? 0 : 1) | ((e.t[0].len() % 4 || e.t[1].len() % 4) ? 0 : 2);
     if (deep) {
-        const PlanEntry& e3 = plan_of(n, is_double, true);
+        const PlanEntry& e3 = plan_of(n, is_double, 1);
         if (e3.passes == 3)
             return ((e3.t[2].len() % 4 || e3.t[0].len() % 4 || e3.t[1].len() % 4) ? 0 : 1) | ((e3.t[0].len() % 4 || (e3.t[1].len() * e3.t[2].len()) % 4) ? 0 : 2);
     }
     return 0;
 }
 
-int tile_plan_lengths(long long n, bool is_double, bool deep, int lengths[3]) {
+int tile_plan_lengths(long long n, bool is_double, int mode, int lengths[3]) {
+    const bool deep = mode == 1;
     lengths[0] = lengths[1] = lengths[2] = 0;
     if (n <= 0) return 0;
     TileLen a, b, c;
@@ -345,7 +362,7 @@ int tile_plan_lengths(long long n, bool is_double, bool deep, int lengths[3]) {
         return 3;
     }
     if (g_variant == 83) return 0;
-    if (tile_plan(n, is_double, deep, a, b)) { lengths[0] = (int)a.len(); lengths[1] = (int)b.len(); return 2; }
+    if (tile_plan(n, is_double, mode, a, b)) { lengths[0] = (int)a.len(); lengths[1] = (int)b.len(); return 2; }
     if (deep && n <= (1ll << 27) && tile_plan3(n, is_double, a, b, c)) {
         lengths[0] = (int)a.len(); lengths[1] = (int)b.len(); lengths[2] = (int)c.len();
         return 3;
@@ -358,12 +375,13 @@ int tile_plan_lengths(long long n, bool is_double, bool deep, int lengths[3]) {
 // out_int: forward transform straight into the internal layout (the last pass stores it: no reorder sweep)
 template <typename T>
 static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, long long n, int dir, hipStream_t st, bool out_int, bool in_int,
-                    bool deep) {
+                    int mode) {
+    const bool deep = mode == 1;
     int rc;
     if (n & (n - 1)) {
         TileLen a, b, c;
         if (g_variant == 83) return -1;
-        if (tile_plan(n, sizeof(T) == 8, deep, a, b)) {
+        if (tile_plan(n, sizeof(T) == 8, mode, a, b)) {
             if ((rc = pass_columns<T>(s, in, work, batch, a, b.len(), dir, st, in_int))) return rc;
             return pass_rows<T>(s, work, out, batch, b, a.len(), 1, dir, st, out_int);
         }
@@ -390,11 +408,11 @@ static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t b
 }
 
 // layout: 1 = forward, spectrum out in the internal layout; 2 = backward, spectrum in from the internal layout
-int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, long long n, int dir, hipStream_t st, int layout, bool deep) {
+int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, long long n, int dir, hipStream_t st, int layout, int mode) {
     const bool out_int = layout == 1, in_int = layout == 2;
     if ((out_int && dir != PFFFT_FORWARD) || (in_int && dir != PFFFT_BACKWARD)) return -1;
-    if (s->is_double) return tile_fft<double>(s, (const cx<double>*)in, (cx<double>*)work, (cx<double>*)out, batch, n, dir, st, out_int, in_int, deep);
-    return tile_fft<float>(s, (const cx<float>*)in, (cx<float>*)work, (cx<float>*)out, batch, n, dir, st, out_int, in_int, deep);
+    if (s->is_double) return tile_fft<double>(s, (const cx<double>*)in, (cx<double>*)work, (cx<double>*)out, batch, n, dir, st, out_int, in_int, mode);
+    return tile_fft<float>(s, (const cx<float>*)in, (cx<float>*)work, (cx<float>*)out, batch, n, dir, st, out_int, in_int, mode);
 }
 
 }  // namespace pf

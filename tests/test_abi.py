@@ -258,7 +258,10 @@ def test_tile_planner_over_every_legal_size():
     assert pa.tile_plan(61440) == [256, 240] and pa.tile_plan(115200) == [480, 240] and pa.tile_plan(9216, True) == [64, 144]
     assert pa.tile_plan(12000) == [] and pa.tile_plan(1024000) == [] and len(pa.tile_plan(1024000, False, True)) == 3
     assert pa.tile_plan(288000) == [480, 600]                    # (round 3: [] / [400, 720] - 600 = 75 x 8 is a run-time length)
-    assert pa.tile_plan(518400) == [] and pa.tile_plan(518400, False, True) == [600, 864]      # two costly passes beat five sweeps
+    assert pa.tile_plan(518400, False, 2) == [] and pa.tile_plan(518400, False, True) == [600, 864]      # two costly passes beat five sweeps
+    # float complex, three streaming sweeps: run-time lengths that carry the internal layout are taken up to a wider bar (mode 0), not for
+    # the core of a real transform (mode 2) and not in double
+    assert pa.tile_plan(10800) == [100, 108] and pa.tile_plan(10800, False, 2) == [] and pa.tile_plan(10800, True) == []
     assert pa.tile_plan(600000) == [] and pa.tile_plan(600000, False, True) == [750, 800] and pa.tile_plan(314928, True, True) == [486, 648]
     assert pa.tile_plan(1 << 16) == [256, 256] and pa.tile_plan(1 << 22) == [128, 128, 256] and pa.tile_plan(2048) == []
     assert covered[False] > 100 and covered[True] > 150, covered
