@@ -44,8 +44,12 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     // what the static-stride Stockham kernels showed, tools/tune_stock_grid.py, holds here too - N = 2^15 complex float 0.31-0.33 ->
     // 0.33-0.37, N = 15360 0.31 -> 0.36, 61440 0.33 -> 0.36, double 2^15 0.31-0.33 -> 0.34-0.36 at 2 .. 4 tiles per workgroup, back
     // to the old figures from 16 on).  PFFFT_HIP_TILE_ITS=<k> sets the count, 0 = the resident set (A/B)
+    // ... but only for tiles up to 32 KiB: steady scans over every size (profiles/r04_scan_beyond_lds_*.txt against r03's) showed the plans with
+    // a 36-54 KiB column tile (L = 288 ... 432) 9-15 % SLOWER at three tiles per workgroup than on the resident set - their prefetch pipeline
+    // wants a long run of tiles - and the L = 144 tiles (radix 9 first, 144 threads: columns -11 ... -15 %, rows -4 %) likewise; L = 64 ... 256 gain 7-18 %
     static const int its_env = [] { const char* e = getenv("PFFFT_HIP_TILE_ITS"); return e ? atoi(e) : 3; }();
-    if (its_env > 0 && (size_t)G::L * G::C * sizeof(cx<T>) < 60 * 1024) {
+    const bool its_ok = (size_t)G::L * G::C * sizeof(cx<T>) <= 32 * 1024 && !(R0 == 9 && LOGL == 4);
+    if (its_env > 0 && its_ok) {
         const unsigned long long want = (ntiles + its_env - 1) / its_env;
         if (want > grid) grid = want;
     }

@@ -40,6 +40,8 @@ CASES = [
     ("stock4000", "SKP_f_4000_c_0", 2 * (1 << 15) * 4000 * 8, "N=4000 cplx f32 forward unordered (Stockham workgroup kernel), batch 2^15"),
     ("big20_A", "tile_fft_kernel<float, 10, 4, 0, 1", 2 * (1 << 30), "N=2^20 cplx f32, pass A"),
     ("big20_B", "tile_fft_kernel<float, 10, 4, 0, 0", 2 * (1 << 30), "N=2^20 cplx f32, pass B"),
+    ("gen600k_A", "tileg_kernel<float, 1024, 0, 1", 2 * 223 * 600000 * 8, "N=600000 cplx f32 = 750 x 800, column pass on a run-time plan (fft_tileg.h, round 4)"),
+    ("gen600k_B", "tileg_kernel<float, 1024, 0, 0", 2 * 223 * 600000 * 8, "N=600000 cplx f32, row pass on a run-time plan"),
 ]
 # c4_long / c4_batch share one kernel: told apart by the grid (both 256 workgroups) - by their position in the run instead:
 # tools/prof_configs.py launches the long signal first, then the batch

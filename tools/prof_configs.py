@@ -1,6 +1,6 @@
 """Launches the dominant kernel of every BASELINE config at its stated size a few times (for rocprofv3 passes):
 c2 N=1024 cplx f32 2^20, c3 N=16384 real f32 2^16, c5 N=1024 cplx f64 2^20, c4 FIR 2^26 samples / 4096 taps,
-beyond-LDS N=2^16 and 2^20 cplx f32 (1 GiB of vectors), N = 115200 = 480 x 240 on the odd-stage tile passes."""
+beyond-LDS N=2^16 and 2^20 cplx f32 (1 GiB of vectors), N = 600000 = 750 x 800 on the run-time tile passes."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -52,3 +52,4 @@ fft(1 << 16, pa.COMPLEX, np.float32, 2048, ordered=False)     # round 3: the las
 fft(1 << 20, pa.COMPLEX, np.float32, 128, ordered=True)
 fft(1 << 18, pa.REAL, np.float32, 1024, ordered=False)        # round 3: pair pass + internal layout as one block-kernel sweep
 fft(4000, pa.COMPLEX, np.float32, 1 << 15, ordered=False)     # a mixed-radix Stockham plan (workgroup kernel)
+fft(600000, pa.COMPLEX, np.float32, 223, ordered=True)        # round 4: 750 x 800 on the run-time tile passes (fft_tileg.h), 1 GiB of vectors
