@@ -141,7 +141,7 @@ static int tile_cost(const TileLen& t, bool columns, unsigned long long stride, 
     const long long L = t.len();
     const unsigned long long line = is_double ? 8 : 16;
     if (t.gen) {
-        // (+ 10: a plan that ties with a register-tiled one on this model measured 1-9 % slower - N = 144000 .. 307200, tools/r4_gen_scan2.sh)
+        // (+ 10: a plan that ties with a register-tiled one on this model measured 1-9 % slower - N = 144000 .. 307200, tools/r4_gen_scan.sh changed)
         const int dbl = (is_double ? 8 : 0) + 10;         // (double: 233-324 / 292-390 on the same plans)
         if (columns) return (L > 432 ? 165 : stride % (line / 2) == 0 ? 143 : 158) + (L < 80 ? 40 : 0) + dbl;
         return (L > 432 ? 140 : stride % line == 0 ? 110 : stride % (line / 2) == 0 ? 125 : 132) + (L < 80 ? 20 : 0) + dbl;
@@ -259,7 +259,7 @@ static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, 
             if (ta.len() % 4 || tb.len() % 4) c += 40;
             // (float, not deep: a plan with a run-time length that carries the internal layout is taken up to 340 - the sizes with 2^4 / 2^5
             //  and a large odd part, whose streaming route cannot read the internal layout in its column pass (R odd): four combinations
-            //  0.23 / 0.24 / 0.25 / 0.18 -> 0.21 / 0.24 / 0.24 / 0.24, tools/r4_gen_scan4.sh; double: the run-time passes are 5-17 % behind)
+            //  0.23 / 0.24 / 0.25 / 0.18 -> 0.21 / 0.24 / 0.24 / 0.24, tools/r4_gen_scan.sh wide; double: the run-time passes are 5-17 % behind)
             const bool wide = mode == 0 && !is_double && (ta.gen || tb.gen) && ta.len() % 4 == 0 && tb.len() % 4 == 0;
             if (c < best) { best = c; found = true; a = ta; b = tb; }
             else if (wide && c < wide_best) { wide_best = c; wa = ta; wb = tb; have_wide = true; }
