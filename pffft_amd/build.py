@@ -32,11 +32,16 @@ def needs_build() -> bool:
     return any(os.path.getmtime(f) > t for f in _deps())
 
 
+# The device code of ~2 500 kernels is 90 % of the library: compressed offload bundles (the HIP runtime inflates a bundle when it loads the
+# module) take libpffft_hip.so from 27 MB to a few MB.  PFFFT_HIP_NO_COMPRESS=1 builds without (A/B of the load time).
+COMPRESS = [] if os.environ.get("PFFFT_HIP_NO_COMPRESS") == "1" else ["--offload-compress"]
+
+
 def _build_dsp(force: bool, verbose: bool) -> None:
     if not force and os.path.exists(DSP_LIB) and all(os.path.getmtime(f) <= os.path.getmtime(DSP_LIB) for f in DSP_DEPS):
         return
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off"] + COMPRESS + [
            "-shared", "-Wl,--version-script=" + os.path.join(CSRC, "exports_dsp.map"), "-o", DSP_LIB, DSP_SRC]
     if verbose:
         print(" ".join(cmd))
@@ -61,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
              "-Wno-pass-failed",   # "loop not unrolled" remarks of fully unrollable radix loops hid real diagnostics
-             "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+             "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + COMPRESS
     # PFFFT_HIP_VARIANTS=1: development build - BOTH variants (deposit / direct first stage) of every Stockham plan are
     # instantiated so that the A/B selectors 54 / 55 and tools/tune_stock_df.py can compare them (twice the generated kernels,
     # 10 instead of 5 minutes).  The product build instantiates the adopted one only (tools/gen_stock_plans.hip).
