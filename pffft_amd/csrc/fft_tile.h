@@ -140,7 +140,12 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     typedef TileGeom<T, LOGL, PP, R0> G;
     typedef TileUnit<T> TU;
     typedef typename TU::U U;
-    constexpr int L = G::L, TPT = G::TPT, WG = G::WG, S = G::S, C = G::C, PITCH = G::PITCH, NS = G::NS;
+    constexpr int L = G::L, TPT = G::TPT, WG = G::WG, S = G::S, C = G::C, NS = G::NS;
+    // 16-byte units per point row of the image.  The padding unit is for the TRANSPOSING write of a row pass (and the quarter rows of the
+    // internal-layout input); a plain column pass touches the image only in whole unit rows - lanes (t, p), p fastest - and those are
+    // conflict-free exactly WITHOUT it: ds_read_b128 of four consecutive rows at a pitch of 9 units costs 8 cycles against 4 (tools/lds_sim.py;
+    // rocprofv3 had 0.56 conflict cycles per active cycle on pass A of N = 2^20).  The LDS size stays that of the padded image.
+    constexpr int PITCH = (SEQC && !IINT) ? PP : G::PITCH;
     // odd first stage on a pass-A tile (not from the internal layout): the loads ARE its operands, point j + q 2^LOGL of butterfly
     // j = t + TPT u (u < UB0, predicated on j < 2^LOGL)
     constexpr int RA = G::RA, RB = G::RB, NODD = G::NODD;

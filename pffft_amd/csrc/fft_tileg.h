@@ -38,13 +38,13 @@ template <typename T, int WG> struct TileGenGeom {
 };
 
 // one stage: radix R, every thread up to K work items
-template <typename T, int WG, int R, int DIR>
+template <typename T, int WG, int R, int DIR, int PITCH>
 __device__ __forceinline__ void tg_stage(typename TileUnit<T>::U* img, const cx<T>* wl, int nb, int Ns, unsigned mNs, int tws, int tid) {
     typedef cx<T> CX;
     typedef TileGenGeom<T, WG> G;
     typedef TileUnit<T> TU;
     typedef typename TU::U U;
-    constexpr int K = (G::KU + R - 1) / R, S = G::S, PITCH = G::PITCH;
+    constexpr int K = (G::KU + R - 1) / R, S = G::S;
     const int items = nb * G::PP;
     U op[K][R];
 #pragma unroll
@@ -104,7 +104,8 @@ tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned lon
     typedef TileGenGeom<T, WG> G;
     typedef TileUnit<T> TU;
     typedef typename TU::U U;
-    constexpr int PP = G::PP, S = G::S, C = G::C, PITCH = G::PITCH, WB = G::WB, KU = G::KU, KE = G::KE;
+    constexpr int PP = G::PP, S = G::S, C = G::C, WB = G::WB, KU = G::KU, KE = G::KE;
+    constexpr int PITCH = (SEQC && !IINT) ? PP : G::PITCH;        // (a plain column pass is conflict-free without the padding unit: fft_tile.h)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int L = P.L, tid = threadIdx.x;
     U* img = reinterpret_cast<U*>(smem);
@@ -265,15 +266,15 @@ tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned lon
             const int nb = P.nb[s], Ns = P.Ns[s], tws = P.tws[s];
             const unsigned mNs = P.m_Ns[s];
             switch (P.R[s]) {
-                case 2: tg_stage<T, WG, 2, DIR>(img, wl, nb, Ns, mNs, tws, tid); break;
-                case 3: tg_stage<T, WG, 3, DIR>(img, wl, nb, Ns, mNs, tws, tid); break;
-                case 4: tg_stage<T, WG, 4, DIR>(img, wl, nb, Ns, mNs, tws, tid); break;
-                case 5: tg_stage<T, WG, 5, DIR>(img, wl, nb, Ns, mNs, tws, tid); break;
-                case 6: tg_stage<T, WG, 6, DIR>(img, wl, nb, Ns, mNs, tws, tid); break;
-                case 8: tg_stage<T, WG, 8, DIR>(img, wl, nb, Ns, mNs, tws, tid); break;
-                case 9: tg_stage<T, WG, 9, DIR>(img, wl, nb, Ns, mNs, tws, tid); break;
-                case 10: tg_stage<T, WG, 10, DIR>(img, wl, nb, Ns, mNs, tws, tid); break;
-                case 12: tg_stage<T, WG, 12, DIR>(img, wl, nb, Ns, mNs, tws, tid); break;
+                case 2: tg_stage<T, WG, 2, DIR, PITCH>(img, wl, nb, Ns, mNs, tws, tid); break;
+                case 3: tg_stage<T, WG, 3, DIR, PITCH>(img, wl, nb, Ns, mNs, tws, tid); break;
+                case 4: tg_stage<T, WG, 4, DIR, PITCH>(img, wl, nb, Ns, mNs, tws, tid); break;
+                case 5: tg_stage<T, WG, 5, DIR, PITCH>(img, wl, nb, Ns, mNs, tws, tid); break;
+                case 6: tg_stage<T, WG, 6, DIR, PITCH>(img, wl, nb, Ns, mNs, tws, tid); break;
+                case 8: tg_stage<T, WG, 8, DIR, PITCH>(img, wl, nb, Ns, mNs, tws, tid); break;
+                case 9: tg_stage<T, WG, 9, DIR, PITCH>(img, wl, nb, Ns, mNs, tws, tid); break;
+                case 10: tg_stage<T, WG, 10, DIR, PITCH>(img, wl, nb, Ns, mNs, tws, tid); break;
+                case 12: tg_stage<T, WG, 12, DIR, PITCH>(img, wl, nb, Ns, mNs, tws, tid); break;
                 default: break;
             }
         }
