@@ -142,12 +142,12 @@ zconvolve_dyn_kernel(const T* a, const T* b, T* ab, unsigned long long Q, unsign
     const unsigned long long nchunks = (Q + ZD_CHUNK - 1) / ZD_CHUNK;
     const bool need_rem = BCAST || is_real;
     unsigned pend = 0;
-    if (threadIdx.x == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
+    // the first TWO groups of a workgroup are static (its index, and that plus the grid); the counter hands out what follows: value v =
+    // group 2 grid + v.  (Every workgroup used to open with two grabs: ~2 000 atomics on one address, served at ~80 M/s, stood between the
+    // launch and the last workgroup's first load - 25-35 us of every launch, tools/r4_small_batch.py.)
+    pend = blockIdx.x + gridDim.x;
     __syncthreads();
-    unsigned g = s_next[0];
+    unsigned g = blockIdx.x;
     V xa[ZD_ROWS], xb[ZD_ROWS], xc[ZD_ROWS];
     unsigned rem[ZD_ROWS];
     // all loads of one chunk; indices clamped to the last unit so that they are unconditional
@@ -172,7 +172,7 @@ zconvolve_dyn_kernel(const T* a, const T* b, T* ab, unsigned long long Q, unsign
     for (unsigned it = 0; (unsigned long long)g * ZD_WAVES < nchunks; ++it) {
         if (threadIdx.x == 0) {
             s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
+            pend = 2u * gridDim.x + atomicAdd(&ctr[0], 1u);
         }
         __syncthreads();
         const unsigned gn = s_next[(it + 1) & 1];
@@ -341,12 +341,12 @@ zreorder_dyn_kernel(const T* in, T* out, size_t batch, int n, int is_real, int G
     const size_t last_chunk = batch * (size_t)nchk - 1;
     const size_t gchunks = (size_t)G * nchk;
     unsigned pend = 0;
-    if (tid == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
+    // the first TWO groups of a workgroup are static (its index, and that plus the grid); the counter hands out what follows: value v =
+    // group 2 grid + v.  (Every workgroup used to open with two grabs: ~2 000 atomics on one address, served at ~80 M/s, stood between the
+    // launch and the last workgroup's first load - 25-35 us of every launch, tools/r4_small_batch.py.)
+    pend = blockIdx.x + gridDim.x;
     __syncthreads();
-    unsigned g = s_next[0];
+    unsigned g = blockIdx.x;
     chunk16 v[ZRD_U];
     auto load_group = [&](size_t grp) {           // clamped: unconditional loads
         if (grp >= ngroups) grp = ngroups - 1;
@@ -361,7 +361,7 @@ zreorder_dyn_kernel(const T* in, T* out, size_t batch, int n, int is_real, int G
     for (unsigned it = 0; g < ngroups; ++it) {
         if (tid == 0) {
             s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
+            pend = 2u * gridDim.x + atomicAdd(&ctr[0], 1u);
         }
         const size_t t0 = (size_t)g * G;
         const int cnt = (int)((batch - t0) < (size_t)G ? (batch - t0) : (size_t)G);

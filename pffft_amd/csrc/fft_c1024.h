@@ -260,12 +260,12 @@ __device__ __forceinline__ void c1024_dyn_body(const float* in, float* out, unsi
         }
     }
     unsigned pend = 0;
-    if (threadIdx.x == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
+    // the first TWO groups of a workgroup are static (its index, and that plus the grid); the counter hands out what follows: value v =
+    // group 2 grid + v.  (Every workgroup used to open with two grabs: ~2 000 atomics on one address, served at ~80 M/s, stood between the
+    // launch and the last workgroup's first load - 25-35 us of every launch, tools/r4_small_batch.py.)
+    pend = blockIdx.x + gridDim.x;
     __syncthreads();
-    unsigned g = s_next[0];
+    unsigned g = blockIdx.x;
     const size_t last = (size_t)batch - 1;
     C1024V4 raw[8];
     {   // clamped: always a valid address, so the loads are unconditional (no phi copies, no early waits)
@@ -275,7 +275,7 @@ __device__ __forceinline__ void c1024_dyn_body(const float* in, float* out, unsi
     for (unsigned it = 0; (size_t)g * C1024_WAVES < batch; ++it) {
         if (threadIdx.x == 0) {  // publish the index of iteration it+1, grab the one of it+2
             s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
+            pend = 2u * gridDim.x + atomicAdd(&ctr[0], 1u);
         }
         const size_t t = (size_t)g * C1024_WAVES + wave;
         const bool active = t < batch;  // wave-uniform

@@ -74,12 +74,11 @@ fft_conv_kernel(const typename C::real_t* in, const typename C::real_t* __restri
     const bool dyn = ctr != nullptr;
     unsigned pend = 0;
     unsigned g = blockIdx.x;
-    if (dyn && threadIdx.x == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
+    // the first TWO groups of a workgroup are static (its index, and that plus the grid); the counter hands out what follows: value v =
+    // group 2 grid + v.  (Every workgroup used to open with two grabs: ~2 000 atomics on one address, served at ~80 M/s, stood between the
+    // launch and the last workgroup's first load - 25-35 us of every launch, tools/r4_small_batch.py.)
+    pend = blockIdx.x + gridDim.x;
     __syncthreads();
-    if (dyn) g = s_next[0];
     const size_t last = (size_t)batch - 1;
     chunk16 raw[NCH];
     {
@@ -89,7 +88,7 @@ fft_conv_kernel(const typename C::real_t* in, const typename C::real_t* __restri
     for (unsigned it = 0; (size_t)g * C::T_PER_WG < batch; ++it) {
         if (dyn && threadIdx.x == 0) {
             s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
+            pend = 2u * gridDim.x + atomicAdd(&ctr[0], 1u);
         }
         const size_t tr = (size_t)g * C::T_PER_WG + slot;
         const bool active = tr < batch;  // inactive slots recompute the last vector and never store

@@ -64,14 +64,8 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     const bool dyn = ctr != nullptr;
     unsigned pend = 0;
     unsigned g = blockIdx.x;
-    if (dyn) {
-        if (threadIdx.x == 0) {
-            s_next[0] = atomicAdd(&ctr[0], 1u);
-            pend = atomicAdd(&ctr[0], 1u);
-        }
-        __syncthreads();
-        g = s_next[0];
-    }
+    // (the first two groups of a workgroup are static - its index, and that plus the grid -, the counter hands out what follows: fft_tiled.h)
+    pend = blockIdx.x + gridDim.x;
     const long long nblk_all = (long long)nblk * nsig;
     // ---- gather of block group grp: stage-0 operand order, zero beyond the end of the signal (src/pffastconv.c:231-233).
     //      The FIRST block's samples are requested before anything else: the twiddle / filter tables below are cold on a call
@@ -113,7 +107,7 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     for (unsigned it = 0; (long long)g * C::T_PER_WG < nblk_all; ++it) {
         if (dyn && threadIdx.x == 0) {
             s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
+            pend = 2u * gridDim.x + atomicAdd(&ctr[0], 1u);
         }
         const long long blk_all = (long long)g * C::T_PER_WG + slot;
         const bool active = blk_all < nblk_all;

@@ -110,12 +110,11 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     const bool dyn = ctr != nullptr;
     unsigned pend = 0;
     unsigned g = blockIdx.x;
-    if (dyn && tid == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
+    // the first TWO groups of a workgroup are static (its index, and that plus the grid); the counter hands out what follows: value v =
+    // group 2 grid + v.  (Every workgroup used to open with two grabs: ~2 000 atomics on one address, served at ~80 M/s, stood between the
+    // launch and the last workgroup's first load - 25-35 us of every launch, tools/r4_small_batch.py.)
+    pend = blockIdx.x + gridDim.x;
     __syncthreads();
-    if (dyn) g = s_next[0];
     const long long nblk_all = (long long)nblk * nsig;
     // copies that would run past the signal are clamped to its last 16 bytes (their samples are replaced by the zero padding of
     // src/pffastconv.c:231-233 when the operands are picked up)
@@ -144,7 +143,7 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     for (unsigned it = 0; (long long)g < nblk_all; ++it) {
         if (dyn && tid == 0) {
             s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
+            pend = 2u * gridDim.x + atomicAdd(&ctr[0], 1u);
         }
         PF_DSTAMP(0);
         wait_vmcnt<0>();

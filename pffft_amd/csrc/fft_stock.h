@@ -700,10 +700,12 @@ struct SkSched {
     unsigned* ctr;
     unsigned* s_next;
     __device__ __forceinline__ void grab(bool owner) {   // before the first barrier
+        // the first THREE chunks of a workgroup are static (its index, + grid, + 2 grid), the counter hands out what follows (value v = chunk
+        // 3 grid + v): no atomic stands between the launch and a workgroup's first load (fft_tiled.h has the measurement)
         if (dyn && owner) {
-            s_next[0] = atomicAdd(&ctr[0], 1u);
-            s_next[1] = atomicAdd(&ctr[0], 1u);
-            pend = atomicAdd(&ctr[0], 1u);
+            s_next[0] = blockIdx.x;
+            s_next[1] = blockIdx.x + gridDim.x;
+            pend = blockIdx.x + 2u * gridDim.x;
         }
     }
     __device__ __forceinline__ void start() {            // after it
@@ -715,7 +717,7 @@ struct SkSched {
     }
     __device__ __forceinline__ void top(bool owner) {    // top of an iteration
         if (dyn && sub + 1 >= K) {
-            if (owner) { s_next[wslot] = pend; pend = atomicAdd(&ctr[0], 1u); }
+            if (owner) { s_next[wslot] = pend; pend = 3u * gridDim.x + atomicAdd(&ctr[0], 1u); }
             wslot = wslot == 2 ? 0 : wslot + 1;
         }
     }

@@ -119,12 +119,12 @@ mix_dyn_kernel(const f32x4* in, f32x4* out, unsigned nchunks, MixArgs a, unsigne
     const int l0 = (2 * lane) % LANES;
     const float2 s0 = a.S[l0], s1 = a.S[LANES == 1 ? 0 : l0 + 1];
     unsigned pend = 0;
-    if (threadIdx.x == 0) {
-        s_next[0] = atomicAdd(&ctr[0], 1u);
-        pend = atomicAdd(&ctr[0], 1u);
-    }
+    // the first TWO groups of a workgroup are static (its index, and that plus the grid); the counter hands out what follows: value v =
+    // group 2 grid + v.  (Every workgroup used to open with two grabs: ~2 000 atomics on one address, served at ~80 M/s, stood between the
+    // launch and the last workgroup's first load - 25-35 us of every launch, tools/r4_small_batch.py.)
+    pend = blockIdx.x + gridDim.x;
     __syncthreads();
-    unsigned g = s_next[0];
+    unsigned g = blockIdx.x;
     const unsigned long long lastc = (unsigned long long)nchunks - 1;
     f32x4 x[MIX_DYN_ROWS];
     {   // clamped: always a valid address, so the loads are unconditional
@@ -136,7 +136,7 @@ mix_dyn_kernel(const f32x4* in, f32x4* out, unsigned nchunks, MixArgs a, unsigne
     for (unsigned it = 0; (unsigned long long)g * MIX_DYN_WAVES < nchunks; ++it) {
         if (threadIdx.x == 0) {   // publish the group of iteration it+1, grab the one of it+2 (latency never exposed)
             s_next[(it + 1) & 1] = pend;
-            pend = atomicAdd(&ctr[0], 1u);
+            pend = 2u * gridDim.x + atomicAdd(&ctr[0], 1u);
         }
         __syncthreads();
         const unsigned gn = s_next[(it + 1) & 1];

@@ -632,6 +632,13 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
     if (g_variant >= 10 && g_variant < 20 && per_cu > g_variant - 10 && g_variant > 10) per_cu = g_variant - 10;  // A/B: cap WGs per CU
     size_t groups = (batch + e.t_per_wg - 1) / e.t_per_wg;
     size_t grid = (size_t)num_cus() * per_cu;
+    // Launches of up to FOUR groups per resident workgroup run as ONE group per workgroup in hardware dispatch order instead of the
+    // persistent in-order loop: that loop pays for itself only over a long run of groups (tools/r4_small_batch.py, us per call, persistent ->
+    // one-shot: C3's kernel at 64 / 128 MiB of vectors 46 / 72 -> 30 / 60, N = 4096 complex 44 / 69 -> 24 / 49, N = 256 at 32 MiB 25 -> 14,
+    // N = 1024 double at 64 MiB 34 -> 27; from 8 groups per workgroup on the loop wins: N = 1024 double at 256 MiB 98 against 110, C3 at 512
+    // MiB 197 against 206; 1 GiB: 0.71-0.82 against 0.62-0.76).  PFFFT_HIP_TILED_ONESHOT=<k> sets the bound, 0 = always the loop (A/B)
+    static const size_t oneshot_env = [] { const char* e = getenv("PFFFT_HIP_TILED_ONESHOT"); return e ? (size_t)atol(e) : (size_t)4; }();
+    if (oneshot_env && groups <= oneshot_env * grid && groups < 0x7fffffffull) grid = groups;
     if (grid > groups) grid = groups;
     const int flags = (((dir == PFFFT_BACKWARD) && !ordered) ? 1 : 0) | (((dir == PFFFT_FORWARD) && !ordered) ? 2 : 0);
     unsigned* ctr = groups <= grid ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
