@@ -739,6 +739,10 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
             else if (tab_its > 0 && g_variant != 208) by_its(tab_its);
             else if ((size_t)sp.n * sizeof(cx<T>) <= 4096) grid *= 16;
             else if ((size_t)sp.n * sizeof(cx<T>) <= 20480) grid *= 8;
+            // (in-order plans: launches of up to four groups per resident workgroup as one group per workgroup - n = 8192 complex float at 32 MiB
+            //  of vectors 25 -> 16 us, launch_tiled has the rule's measurements; PFFFT_HIP_STOCK_ONESHOT=<k>, 0 = off)
+            static const size_t oneshot_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_ONESHOT"); return e ? (size_t)atol(e) : (size_t)4; }();
+            if (want_dyn && oneshot_env && groups <= oneshot_env * grid) grid = groups;
             if (grid > groups) grid = groups;
             if (grid > 0x7fffffffu) grid = 0x7fffffffu;
             unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);

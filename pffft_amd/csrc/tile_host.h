@@ -59,6 +59,10 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     // order).  PFFFT_HIP_TILE_DYN=0/1 forces it (A/B).
     static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_TILE_DYN"); return e ? atoi(e) : -1; }();
     const bool want_dyn = dyn_env >= 0 ? dyn_env != 0 : (size_t)G::L * G::C * sizeof(cx<T>) >= 60 * 1024;   // (L = 480: 60 KiB)
+    // (in-order tiles: a launch of up to four tiles per resident workgroup runs one tile per workgroup in dispatch order - N = 2^18 complex at 32 MiB
+    //  of vectors 56 -> 38 us per transform, tools/r4_small_batch.py; launch_tiled has the rule's measurements.  PFFFT_HIP_TILE_ONESHOT=<k>, 0 = off)
+    static const unsigned long long oneshot_env = [] { const char* e = getenv("PFFFT_HIP_TILE_ONESHOT"); return e ? (unsigned long long)atol(e) : 4ull; }();
+    if (want_dyn && oneshot_env && ngroups <= oneshot_env * grid) grid = ngroups;
     // XCD-aware tile order (TileDesc::xmode, round 4): PFFFT_HIP_TILE_XMODE = 0 off, 1 static map only, 2 per-XCD counters only, 3 both (A/B).
     // OFF for these kernels: their strides are whole or half lines, and measured (tools/r4_xmode.sh) the static map costs 0-4 %, the per-XCD
     // counters N = 2^20 0.20-0.23 -> 0.17-0.19 (one in-order sweep over the whole batch is what HBM rewards there); they pay only on the

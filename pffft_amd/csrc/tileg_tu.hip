@@ -87,6 +87,7 @@ static int tile_gen_launch(const TileGenPlan& P, const cx<T>* in, cx<T>* out, un
     }
     if (grid > ntiles) grid = ntiles;
     const bool want_dyn = tile_bytes >= 60 * 1024;
+    if (want_dyn && ntiles <= 4 * grid) grid = ntiles;     // (short launches of in-order tiles: one tile per workgroup, the rule of tile_host.h)
     static const int xctr_env = [] { const char* e = getenv("PFFFT_HIP_TILE_XCTR"); return e ? atoi(e) : 1; }();
     const bool dynm = !(ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
     const bool xctr = dynm && xctr_env && grid % 8 == 0 && ntiles >= 64;

@@ -6,7 +6,11 @@ import pffft_amd as pa
 from r4_graph import per_call
 VAR = int(os.environ.get("R4_VARIANT", "0"))
 pa.set_variant(VAR)
-for N, tr, dt in ((1024, pa.COMPLEX, np.float32), (1024, pa.COMPLEX, np.float64), (16384, pa.REAL, np.float32), (4096, pa.COMPLEX, np.float32), (2048, pa.COMPLEX, np.float32), (256, pa.COMPLEX, np.float32), (512, pa.REAL, np.float32), (2048, pa.COMPLEX, np.float64)):
+SIZES = os.environ.get('R4_SIZES')
+DEFAULT = ((1024, pa.COMPLEX, np.float32), (1024, pa.COMPLEX, np.float64), (16384, pa.REAL, np.float32), (4096, pa.COMPLEX, np.float32), (2048, pa.COMPLEX, np.float32), (256, pa.COMPLEX, np.float32), (512, pa.REAL, np.float32), (2048, pa.COMPLEX, np.float64))
+if SIZES:
+    DEFAULT = tuple((int(a.split(':')[0]), pa.REAL if a.split(':')[1] == 'r' else pa.COMPLEX, np.float64 if a.split(':')[2] == 'd' else np.float32) for a in SIZES.split(','))
+for N, tr, dt in DEFAULT:
     s = pa.Setup(N, tr, dt)
     vb = s.vec_scalars * np.dtype(dt).itemsize
     row = []
