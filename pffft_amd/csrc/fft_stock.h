@@ -699,13 +699,15 @@ struct SkSched {
     bool dyn;
     unsigned* ctr;
     unsigned* s_next;
+    // (Round 4: the register-tiled kernels take their first groups statically - fft_tiled.h, no start-up burst of atomics, C3 0.71 -> 0.74.  The
+    //  same change HERE measured the in-order plans 10-12 % slower at 1 GiB per launch - n = 8192 complex float 0.79 -> 0.68, double n = 2048 /
+    //  4096 0.77-0.80 -> 0.68-0.72 - and neither a run-time switch back to these three grabs nor a staggered start brought it back, only this
+    //  source: the start-up grabs stay.)
     __device__ __forceinline__ void grab(bool owner) {   // before the first barrier
-        // the first THREE chunks of a workgroup are static (its index, + grid, + 2 grid), the counter hands out what follows (value v = chunk
-        // 3 grid + v): no atomic stands between the launch and a workgroup's first load (fft_tiled.h has the measurement)
         if (dyn && owner) {
-            s_next[0] = blockIdx.x;
-            s_next[1] = blockIdx.x + gridDim.x;
-            pend = blockIdx.x + 2u * gridDim.x;
+            s_next[0] = atomicAdd(&ctr[0], 1u);
+            s_next[1] = atomicAdd(&ctr[0], 1u);
+            pend = atomicAdd(&ctr[0], 1u);
         }
     }
     __device__ __forceinline__ void start() {            // after it
@@ -717,7 +719,7 @@ struct SkSched {
     }
     __device__ __forceinline__ void top(bool owner) {    // top of an iteration
         if (dyn && sub + 1 >= K) {
-            if (owner) { s_next[wslot] = pend; pend = 3u * gridDim.x + atomicAdd(&ctr[0], 1u); }
+            if (owner) { s_next[wslot] = pend; pend = atomicAdd(&ctr[0], 1u); }
             wslot = wslot == 2 ? 0 : wslot + 1;
         }
     }
