@@ -323,3 +323,48 @@ def test_runtime_tile_plans_forced_lengths(dt, N, plan):
     env = dict(os.environ, PFFFT_HIP_TILE_FORCE=plan)
     r = subprocess.run([sys.executable, "-c", _FORCED.format(root=root, dt=dt, N=N)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FORCED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ HIP graph capture of the device entries
+def test_device_entries_replay_from_a_hip_graph(ref):
+    """after one call on the setup and stream (lazily built tables, per-stream work buffers) the launch path neither
+    allocates nor synchronises, so the device entries can be captured and replayed - an LDS-resident transform, a transform beyond LDS (two
+    tile passes through the stream's work buffer), the fused convolution and a few-block pffastconv call; the replay writes the same values
+    as the direct calls, and those meet the reference."""
+    st = torch.cuda.Stream()
+    rng = np.random.default_rng(11)
+    h = rng.uniform(-1, 1, 1500).astype(np.float32)
+    with torch.cuda.stream(st):
+        s1 = pa.Setup(1024, pa.COMPLEX)
+        s2 = pa.Setup(1 << 16, pa.COMPLEX)
+        fc = pa.FastConv(h, 0, 0)
+        x1 = _uniform((300, 2048), 1, torch.float32); y1 = torch.empty_like(x1); c1 = torch.empty_like(x1)
+        x2 = _uniform((5, 2 << 16), 2, torch.float32); y2 = torch.empty_like(x2)
+        xs = _uniform((300001,), 3, torch.float32); ys = torch.zeros_like(xs)
+        H = s1.transform_batch(x1[:1].contiguous(), None, pa.FORWARD, False).reshape(-1).contiguous()
+
+        def work():
+            s1.transform_batch(x1, y1, pa.FORWARD, False)
+            s2.transform_batch(x2, y2, pa.FORWARD, True)
+            s1.convolve_batch(x1, H, out=c1, scaling=1.0 / 1024)
+            return fc.apply(xs, True, out=ys)[1]
+
+        n = work()
+        torch.cuda.synchronize()
+        want = [t.clone() for t in (y1, y2, c1, ys)]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            work()
+        for t in (y1, y2, c1, ys):
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for got, w in zip((y1, y2, c1, ys), want):
+            assert torch.equal(got, w)
+    yw, nw, _ = ref.fastconv(xs.cpu().numpy(), h, 0, 0, 1)
+    assert n == nw and np.abs(ys[:n].cpu().numpy() - yw).max() <= (yw.max() - yw.min()) / 1e5
+    rs = ref.setup(1 << 16, pa.COMPLEX, np.float32)
+    from oracle.ref import FORWARD
+    wantf = rs.batch(x2.cpu().numpy(), FORWARD, True)
+    assert (np.abs(y2.cpu().numpy().astype(np.float64) - wantf).max(axis=1) / np.abs(wantf).max(axis=1)).max() <= 1e-5
+    rs.close(); s1.close(); s2.close(); fc.close()
