@@ -30,7 +30,7 @@ CASES = [
     ("c5", "TiledCfg<double, 10, 64, 3, 8, 16, 8", (1 << 20) * 32768, "C5 N=1024 cplx f64 fwd, batch 2^20"),
     ("c4_long", "fastconv_split_kernel", 8 * N26, "C4 FIR 2^26 samples, 4096 taps (8 B per output sample): split block kernel (round 4)"),
     ("c4_batch", "fastconv_split_kernel", 8 * N20B, "C4 FIR 256 signals of 2^20 samples, 4096 taps: split block kernel"),
-    ("c4_single", "fastconv_fused_kernel<pf::TiledCfg<float, 12, 512, 5", 8 * ((1 << 20) - 4095), "C4 stated call: 2^20 samples, 4096 taps, 255 blocks, fused kernel on 512 threads per block (round 4)"),
+    ("c4_single", "fastconv_split1_kernel<", 8 * ((1 << 20) - 4095), "C4 stated call: 2^20 samples, 4096 taps, 255 reference-sized blocks, one-shot split kernel (fastconv_split1_kernel, round 4)"),
     ("fir_wave200", "fastconv_wave_kernel", 8 * ((1 << 26) - 199), "FIR 200 taps on 2^26 samples: one wavefront per 2048-sample block (round 3)"),
     ("conv1024", "fft_conv_kernel<pf::TiledCfg<float, 10, 64", (1 << 20) * 16384, "pffft_hip_convolve_batch N=1024 cplx f32, batch 2^20: forward x H backward in one kernel (round 4)"),
     ("stock3888", "SKP_f_3888_c_0", 2 * 34521 * 3888 * 8, "N=3888 cplx f32 forward unordered: Stockham plan 3 x 9 x 9 x 16 (round 4), 1 GiB of vectors"),
