@@ -253,9 +253,16 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     // burst of three atomics per workgroup on one address is off the critical path now.)
     const unsigned long long g0 = xctr ? gridDim.x / 8 : gridDim.x, lid = xctr ? blockIdx.x / 8 : blockIdx.x;
     auto ranged = [&](unsigned long long local) -> unsigned long long { const unsigned long long g = xbase + local; return g < xend ? g : ngroups; };
-    auto grabbed = [&](unsigned v) -> unsigned long long { return ranged(2 * g0 + v); };
     unsigned pend = 0;
-    if (dyn) {
+    const bool cstart = dyn && (D.xmode & 8u);       // (A/B, PFFFT_HIP_TILE_CSTART=1: the three start-up grabs of round 3 - 1-3 % slower at 1 GiB, N = 2^18 .. 393216)
+    const unsigned long long goff = cstart ? 0 : 2 * g0;
+    auto grabbed = [&](unsigned v) -> unsigned long long { return ranged(goff + v); };
+    if (cstart) {
+        if (tid == 0) { s_next[0] = atomicAdd(cnext, 1u); s_next[1] = atomicAdd(cnext, 1u); pend = atomicAdd(cnext, 1u); }
+        __syncthreads();
+        gcur = ranged(s_next[0]); gnext = ranged(s_next[1]);
+        __syncthreads();
+    } else if (dyn) {
         gcur = ranged(lid); gnext = ranged(lid + g0);
         if (tid == 0) pend = atomicAdd(cnext, 1u);
     }

@@ -74,7 +74,8 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     // (per-XCD counters: nine words = five {next, done} pairs of the ring, which is allocated with that much room past its end)
     unsigned* ctr = !dynm ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(xctr ? 5 : 1) % CTR_RING);
     TileDesc D2 = D;
-    D2.xmode = (xctr ? 2u : 0u) | ((!dynm && (xmode_env & 1) && D.group <= 1) ? 1u : 0u);
+    static const int cstart_env = [] { const char* e = getenv("PFFFT_HIP_TILE_CSTART"); return e ? atoi(e) : 0; }();   // A/B: start-up grabs from the counter
+    D2.xmode = (xctr ? 2u : 0u) | ((!dynm && (xmode_env & 1) && D.group <= 1) ? 1u : 0u) | (cstart_env ? 8u : 0u);
     if (D2.xmode & 1u) grid = (grid + 7) / 8 * 8;      // (the static map is a bijection on a grid of whole eights; the surplus workgroups retire at once)
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D2, ctr);
     PF_CHECK(hipGetLastError());
