@@ -368,3 +368,29 @@ def test_device_entries_replay_from_a_hip_graph(ref):
     wantf = rs.batch(x2.cpu().numpy(), FORWARD, True)
     assert (np.abs(y2.cpu().numpy().astype(np.float64) - wantf).max(axis=1) / np.abs(wantf).max(axis=1)).max() <= 1e-5
     rs.close(); s1.close(); s2.close(); fc.close()
+
+
+# ------------------------------------------------------------------ one value per vector, whatever the launch shape
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("tr,N", [(pa.COMPLEX, 256), (pa.COMPLEX, 1024), (pa.COMPLEX, 4096), (pa.REAL, 16384), (pa.COMPLEX, 8192), (pa.COMPLEX, 2400),
+                                  (pa.COMPLEX, 1 << 16), (pa.COMPLEX, 10800)])
+def test_values_do_not_depend_on_the_launch_shape(dt, tr, N):
+    """Round 4 chooses between three launch shapes by the number of groups per resident workgroup - one group per workgroup without a counter,
+    the same in dispatch order for up to four groups per workgroup, the persistent in-order loop beyond (first groups static, the counter for
+    the rest).  A vector's spectrum must not depend on which one ran: the first vectors of a long batch equal, bit for bit, the same vectors
+    transformed as a short batch, for the four direction x layout combinations."""
+    dtype = np.float32 if dt == "f32" else np.float64
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    s = pa.Setup(N, tr, dtype)
+    vb = s.vec_scalars * np.dtype(dtype).itemsize
+    big = max(64, min((160 << 20) // vb, 40000))          # many groups per workgroup for the LDS-resident sizes
+    x = _uniform((big, s.vec_scalars), 31 + N % 97, tdt)
+    for d in (pa.FORWARD, pa.BACKWARD):
+        for o in (True, False):
+            full = s.transform_batch(x, None, d, o)
+            for k in (1, 7, min(big, 1500)):
+                part = s.transform_batch(x[:k].contiguous(), None, d, o)
+                assert torch.equal(part, full[:k]), (dt, tr, N, d, o, k)
+            tail = s.transform_batch(x[big - 5:].contiguous(), None, d, o)
+            assert torch.equal(tail, full[big - 5:]), (dt, tr, N, d, o, "tail")
+    s.close()
