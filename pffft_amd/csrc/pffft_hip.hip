@@ -638,7 +638,10 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
     // N = 1024 double at 64 MiB 34 -> 27; from 8 groups per workgroup on the loop wins: N = 1024 double at 256 MiB 98 against 110, C3 at 512
     // MiB 197 against 206; 1 GiB: 0.71-0.82 against 0.62-0.76).  PFFFT_HIP_TILED_ONESHOT=<k> sets the bound, 0 = always the loop (A/B)
     static const size_t oneshot_env = [] { const char* e = getenv("PFFFT_HIP_TILED_ONESHOT"); return e ? (size_t)atol(e) : (size_t)4; }();
-    if (oneshot_env && groups <= oneshot_env * grid && groups < 0x7fffffffull) grid = groups;
+    // (N = 4096 complex float alone prefers the dispatch order up to SIXTEEN groups per workgroup: 256 / 512 MiB 111 / 193 -> 91 / 178 us; every
+    //  other size measured loses there - 4096 real 104 -> 154 us at 256 MiB, 16384 complex 217 -> 283 at 512 MiB)
+    const size_t oneshot = (oneshot_env == 4 && sizeof(T) == 4 && s->n == 4096 && !real) ? (size_t)16 : oneshot_env;
+    if (oneshot && groups <= oneshot * grid && groups < 0x7fffffffull) grid = groups;
     if (grid > groups) grid = groups;
     const int flags = (((dir == PFFFT_BACKWARD) && !ordered) ? 1 : 0) | (((dir == PFFFT_FORWARD) && !ordered) ? 2 : 0);
     unsigned* ctr = groups <= grid ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
