@@ -338,7 +338,7 @@ REF_SIZES = [64, 96, 128, 160, 192, 256, 384, 480, 512, 640, 768, 800, 1024, 204
 
 # Sizes with factors 3 and 5 beyond LDS (legal sizes of tests/test_fft_factors.c the reference's benchmark list does not hold):
 # two tile passes (15360 = 64 x 240, 61440 = 256 x 240, 102400 = 400 x 256, 368640 = 480 x 768: pffft_hip_tile_plan), three where the
-# streaming route needs five sweeps (1024000 = 64 x 200 x 80), one size that stays on three streaming passes (12000 = 2^5 x 375), and -
+# streaming route needs five sweeps (1024000 = 64 x 200 x 80), one size with 2^5 only (12000 = 100 x 120 float complex on run-time plans, three streaming passes otherwise), and -
 # round 4 - two sizes on the run-time tile lengths of fft_tileg.h (384000 = 480 x 800, 600000 = 750 x 800; real N: half of it) - DESIGN.md §3.5
 BEYOND_LDS_35 = [12000, 15360, 61440, 102400, 368640, 384000, 600000, 1024000]
 

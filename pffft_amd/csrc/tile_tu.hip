@@ -57,6 +57,7 @@ template <typename T> static int pick_pp(int logl) {
 struct TileLen {
     int r0, logl;
     bool gen = false;
+    bool alt = false;      // a run-time plan for a length that also has a register-tiled kernel: considered only where that kernel's stride is misaligned
     unsigned long long len() const { return (unsigned long long)r0 << logl; }
 };
 
@@ -178,7 +179,8 @@ static const std::vector<TileLen>& tile_lengths(bool is_double) {
                     if (!tile_gen_length_ok(L, dbl != 0)) continue;
                     bool have = false;
                     for (size_t i = 0; i < fixed; ++i) have = have || (long long)v[i].len() == L;
-                    if (!have) v.push_back(TileLen{L, 0, true});
+                    static const int alt_env = [] { const char* e = getenv("PFFFT_HIP_TILE_ALT"); return e ? atoi(e) : 1; }();   // A/B: 0 = off
+                    if (!have || alt_env) v.push_back(TileLen{L, 0, true, have});
                 }
             }
             std::sort(v.begin(), v.end(), [](const TileLen& x, const TileLen& y) { return x.len() < y.len(); });
@@ -241,9 +243,13 @@ static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, 
         if (f.ok && (long long)f.a.len() * (long long)f.b.len() == n) { a = f.a; b = f.b; return true; }
     }
     const std::vector<TileLen>& V = tile_lengths(is_double);
+    // two rounds: the plans without `alt` lengths first; those with them only where that finds nothing (N = 12000 = 100 x 120 ... 200000: the
+    // minimum over the four combinations 0.18 -> 0.25, mean +10 ... +17 %; as equal competitors they displaced better plans: N = 108000 -7 %)
+    bool found = false;
+    for (int round = 0; round < 2 && !found; ++round) {
     static const int maxcost_env = [] { const char* e = getenv("PFFFT_HIP_TILE_MAXCOST"); return e ? atoi(e) : 286; }();   // A/B
     int best = deep ? 460 : maxcost_env;                 // (deep: the streaming route takes five sweeps, ~480)
-    bool found = false, have_wide = false;
+    bool have_wide = false;
     int wide_best = g_wide_cost;
     TileLen wa{1, 0}, wb{1, 0};
     for (const TileLen& ta : V) {
@@ -253,6 +259,13 @@ static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, 
             if ((long long)tb.len() != L2 || !tile_len_ok(tb)) continue;
             // (double: the register-tiled kernels are built without the ragged last tile - the OTHER length must be a multiple of 8)
             if (is_double && ((!ta.gen && tb.len() % 8) || (!tb.gen && ta.len() % 8))) continue;
+            // (a length with a register-tiled kernel runs on the run-time plan only where the strided 128-byte runs of that kernel would not be
+            //  half lines - 475-550 us per pass against 250-330, tools/r4_gen_force.sh: N = 12000 = 100 x 120, 21600 = 180 x 120 ...)
+            {
+                const unsigned long long half = is_double ? 4 : 8;
+                if ((ta.alt || tb.alt) && round == 0) continue;
+                if ((ta.alt && tb.len() % half == 0) || (tb.alt && ta.len() % half == 0)) continue;
+            }
             // (float: a length that is 8 mod 16 leaves the OTHER pass a half-empty last tile of 8 sequences)
             int c = tile_cost(ta, true, tb.len(), is_double) * ragged_pct(tb.len(), is_double) / 100 + tile_cost(tb, false, ta.len(), is_double) * ragged_pct(ta.len(), is_double) / 100;
             // (lengths that are not multiples of 4 cannot carry the internal layout: a reorder sweep, ~130, on the unordered half of the calls)
@@ -266,6 +279,7 @@ static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, 
         }
     }
     if (!found && have_wide) { a = wa; b = wb; found = true; }
+    }
     return found;
 }
 
@@ -283,6 +297,7 @@ static bool tile_plan3_search(long long n, bool is_double, TileLen& a, TileLen& 
             for (const TileLen& tc : V) {
                 if ((long long)tc.len() != L3 || !tile_len_ok(tc)) continue;
                 if (is_double && ((!ta.gen && (tb.len() * tc.len()) % 8) || (!tb.gen && tc.len() % 8) || (!tc.gen && ta.len() % 8))) continue;
+                if (ta.alt || tb.alt || tc.alt) continue;       // (three passes: the register-tiled kernel of a length where there is one)
                 const int cst = tile_cost(ta, true, tb.len() * tc.len(), is_double) * ragged_pct(tb.len() * tc.len(), is_double) / 100 +
                                 tile_cost(tb, true, tc.len(), is_double) * ragged_pct(tc.len(), is_double) / 100 +
                                 tile_cost(tc, false, ta.len(), is_double) * ragged_pct(ta.len(), is_double) / 100;

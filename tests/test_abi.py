@@ -256,7 +256,10 @@ def test_tile_planner_over_every_legal_size():
                 assert pa.tile_plan(n, is_double, True), (n, is_double)
     # the sizes DESIGN.md §3.5 names
     assert pa.tile_plan(61440) == [256, 240] and pa.tile_plan(115200) == [480, 240] and pa.tile_plan(9216, True) == [64, 144]
-    assert pa.tile_plan(12000) == [] and pa.tile_plan(1024000) == [] and len(pa.tile_plan(1024000, False, True)) == 3
+    assert pa.tile_plan(1024000) == [] and len(pa.tile_plan(1024000, False, True)) == 3
+    # 120 has a register-tiled kernel, but next to 100 its strided runs would not be half lines: the run-time plan of the same length (float
+    # complex only: the wide bar of mode 0)
+    assert pa.tile_plan(12000) == [100, 120] and pa.tile_plan(12000, False, 2) == [] and pa.tile_plan(12000, True) == []
     assert pa.tile_plan(288000) == [480, 600]                    # (round 3: [] / [400, 720] - 600 = 75 x 8 is a run-time length)
     assert pa.tile_plan(518400, False, 2) == [] and pa.tile_plan(518400, False, True) == [600, 864]      # two costly passes beat five sweeps
     # float complex, three streaming sweeps: run-time lengths that carry the internal layout are taken up to a wider bar (mode 0), not for
