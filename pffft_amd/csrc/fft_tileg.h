@@ -10,7 +10,7 @@
 // one unit; the same pass descriptor (TileDesc), the same four-step twiddle tables, so that a plan may mix the two families (tile_tu.hip).
 // What differs is the stage engine: radices 2 .. 12 (cxmath.h dftR; 15 and 16 would hold 64 registers of operands next to the 28 of the prefetch) in up to five Stockham stages taken from the plan, a stage's work items
 // (butterfly j, unit p) dealt to the threads round robin; all operands of a thread are read before the barrier, all results written after
-// it (one image: L = 864 is 122 KiB).  One thread per 6.75 image units: 256 threads up to L = 216, 512 up to 432, 1024 beyond - a stage then
+// it (one image: L = 864 is 122 KiB).  One thread per 6.75 image units: 128 threads up to L = 108, 256 up to 216, 512 up to 432, 1024 beyond - a stage then
 // holds at most 16 units per thread and the kernels stay within 128 registers.
 #pragma once
 #include <type_traits>

@@ -243,44 +243,44 @@ static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, 
         if (f.ok && (long long)f.a.len() * (long long)f.b.len() == n) { a = f.a; b = f.b; return true; }
     }
     const std::vector<TileLen>& V = tile_lengths(is_double);
-    // two rounds: the plans without `alt` lengths first; those with them only where that finds nothing (N = 12000 = 100 x 120 ... 200000: the
-    // minimum over the four combinations 0.18 -> 0.25, mean +10 ... +17 %; as equal competitors they displaced better plans: N = 108000 -7 %)
-    bool found = false;
-    for (int round = 0; round < 2 && !found; ++round) {
     static const int maxcost_env = [] { const char* e = getenv("PFFFT_HIP_TILE_MAXCOST"); return e ? atoi(e) : 286; }();   // A/B
-    int best = deep ? 460 : maxcost_env;                 // (deep: the streaming route takes five sweeps, ~480)
-    bool have_wide = false;
-    int wide_best = g_wide_cost;
-    TileLen wa{1, 0}, wb{1, 0};
-    for (const TileLen& ta : V) {
-        if (!tile_len_ok(ta) || n % (long long)ta.len()) continue;
-        const long long L2 = n / (long long)ta.len();
-        for (const TileLen& tb : V) {
-            if ((long long)tb.len() != L2 || !tile_len_ok(tb)) continue;
-            // (double: the register-tiled kernels are built without the ragged last tile - the OTHER length must be a multiple of 8)
-            if (is_double && ((!ta.gen && tb.len() % 8) || (!tb.gen && ta.len() % 8))) continue;
-            // (a length with a register-tiled kernel runs on the run-time plan only where the strided 128-byte runs of that kernel would not be
-            //  half lines - 475-550 us per pass against 250-330, tools/r4_gen_force.sh: N = 12000 = 100 x 120, 21600 = 180 x 120 ...)
-            {
+    // one round over the pairs of tile lengths; with_alt: lengths that have a register-tiled kernel also on their run-time plan
+    auto search = [&](bool with_alt) -> bool {
+        int best = deep ? 460 : maxcost_env;             // (deep: the streaming route takes five sweeps, ~480)
+        int wide_best = g_wide_cost;
+        bool found = false, have_wide = false;
+        TileLen wa{1, 0}, wb{1, 0};
+        for (const TileLen& ta : V) {
+            if (!tile_len_ok(ta) || n % (long long)ta.len()) continue;
+            const long long L2 = n / (long long)ta.len();
+            for (const TileLen& tb : V) {
+                if ((long long)tb.len() != L2 || !tile_len_ok(tb)) continue;
+                // (double: the register-tiled kernels are built without the ragged last tile - the OTHER length must be a multiple of 8)
+                if (is_double && ((!ta.gen && tb.len() % 8) || (!tb.gen && ta.len() % 8))) continue;
+                // (a length with a register-tiled kernel runs on the run-time plan only where the strided 128-byte runs of that kernel would
+                //  not be half lines - 475-550 us per pass against 250-330, tools/r4_gen_force.sh: N = 12000 = 100 x 120, 21600 = 108 x 200 ...)
                 const unsigned long long half = is_double ? 4 : 8;
-                if ((ta.alt || tb.alt) && round == 0) continue;
+                if ((ta.alt || tb.alt) && !with_alt) continue;
                 if ((ta.alt && tb.len() % half == 0) || (tb.alt && ta.len() % half == 0)) continue;
+                // (float: a length that is 8 mod 16 leaves the OTHER pass a half-empty last tile of 8 sequences)
+                int c = tile_cost(ta, true, tb.len(), is_double) * ragged_pct(tb.len(), is_double) / 100 +
+                        tile_cost(tb, false, ta.len(), is_double) * ragged_pct(ta.len(), is_double) / 100;
+                // (lengths that are not multiples of 4 cannot carry the internal layout: a reorder sweep, ~130, on the unordered half of the calls)
+                if (ta.len() % 4 || tb.len() % 4) c += 40;
+                // (float, not deep: a plan with a run-time length that carries the internal layout is taken up to 340 - the sizes with 2^4 / 2^5
+                //  and a large odd part, whose streaming route cannot read the internal layout in its column pass (R odd): four combinations
+                //  0.23 / 0.24 / 0.25 / 0.18 -> 0.21 / 0.24 / 0.24 / 0.24, tools/r4_gen_scan.sh wide; double: the run-time passes are 5-17 % behind)
+                const bool wide = mode == 0 && !is_double && (ta.gen || tb.gen) && ta.len() % 4 == 0 && tb.len() % 4 == 0;
+                if (c < best) { best = c; found = true; a = ta; b = tb; }
+                else if (wide && c < wide_best) { wide_best = c; wa = ta; wb = tb; have_wide = true; }
             }
-            // (float: a length that is 8 mod 16 leaves the OTHER pass a half-empty last tile of 8 sequences)
-            int c = tile_cost(ta, true, tb.len(), is_double) * ragged_pct(tb.len(), is_double) / 100 + tile_cost(tb, false, ta.len(), is_double) * ragged_pct(ta.len(), is_double) / 100;
-            // (lengths that are not multiples of 4 cannot carry the internal layout: a reorder sweep, ~130, on the unordered half of the calls)
-            if (ta.len() % 4 || tb.len() % 4) c += 40;
-            // (float, not deep: a plan with a run-time length that carries the internal layout is taken up to 340 - the sizes with 2^4 / 2^5
-            //  and a large odd part, whose streaming route cannot read the internal layout in its column pass (R odd): four combinations
-            //  0.23 / 0.24 / 0.25 / 0.18 -> 0.21 / 0.24 / 0.24 / 0.24, tools/r4_gen_scan.sh wide; double: the run-time passes are 5-17 % behind)
-            const bool wide = mode == 0 && !is_double && (ta.gen || tb.gen) && ta.len() % 4 == 0 && tb.len() % 4 == 0;
-            if (c < best) { best = c; found = true; a = ta; b = tb; }
-            else if (wide && c < wide_best) { wide_best = c; wa = ta; wb = tb; have_wide = true; }
         }
-    }
-    if (!found && have_wide) { a = wa; b = wb; found = true; }
-    }
-    return found;
+        if (!found && have_wide) { a = wa; b = wb; found = true; }
+        return found;
+    };
+    // the plans without `alt` lengths first; those with them only where that finds nothing (N = 12000 = 100 x 120 ... 200000: the minimum
+    // over the four combinations 0.18 -> 0.25, mean +10 ... +17 %; as equal competitors they displaced better plans: N = 108000 -7 %)
+    return search(false) || search(true);
 }
 
 // Three tile passes n = L1 (L2 L3) (the shape of the power-of-two sizes beyond 2^20) for the sizes without a two-pass plan whose
