@@ -20,7 +20,7 @@ static int conv_launch(Setup* s, const T* in, const T* H, T* out, size_t batch, 
     size_t grid = (size_t)num_cus() * per_cu;
     if (groups <= 4 * grid) grid = groups;        // (short launches: one group per workgroup in dispatch order - the rule of launch_tiled)
     if (grid > groups) grid = groups;
-    unsigned* ctr = groups <= grid ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = groups <= grid ? nullptr : take_counters(s, st);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), C::LDS_BYTES, st, in, H, out, (unsigned)batch, scaling, accumulate,
                        (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
     PF_CHECK(hipGetLastError());

@@ -9,6 +9,9 @@
 
 namespace pf {
 
+// XCD-contiguous block ranges of the split kernels (fft_fir.h xcd_local); PFFASTCONV_HIP_XCD=0 switches them off (A/B)
+static const int g_fir_xcd = [] { const char* e = getenv("PFFASTCONV_HIP_XCD"); return e ? atoi(e) : 1; }();
+
 template <class C>
 static int fir_dma_cfg(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen,
                        int lastOut, hipStream_t st, const FcBatch& fb) {
@@ -19,7 +22,7 @@ static int fir_dma_cfg(Setup* ps, const float* d_Hc, const float* d_x, float* d_
     const size_t groups = ((size_t)nblk * fb.nsig + C::T_PER_WG - 1) / C::T_PER_WG;
     size_t grid = (size_t)num_cus();
     if (grid > groups) grid = groups;
-    unsigned* ctr = groups <= grid ? nullptr : ps->d_ctr + 2 * (ps->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = groups <= grid ? nullptr : take_counters(ps, st);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), G::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
                        nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, ctr,
                        fb.nsig, fb.xstride, fb.ystride);
@@ -59,11 +62,18 @@ static int fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y
     auto k = fastconv_split1_kernel<W>;
     int rc = allow_big_lds(k, S::LDS_BYTES);
     if (rc) return rc;
-    if (!*ab_cache) {    // the folded coefficients of this filter: once, on the caller's stream (ordered before the kernel below)
-        PF_CHECK(hipMalloc(ab_cache, sizeof(float) * 4 * (size_t)S::n));
-        hipLaunchKernelGGL(fastconv_split1_coef_kernel<W>, dim3(1), dim3(S::WG), 0, st, (const cx<float>*)d_Hc, (const cx<float>*)ps->d_twr,
-                           (vec4<float>*)*ab_cache);
-        if (hipGetLastError() != hipSuccess) { (void)hipFree(*ab_cache); *ab_cache = nullptr; return fail(hipErrorLaunchFailure, "fastconv_split1_coef_kernel"); }
+    if (!*ab_cache) {
+        // the folded coefficients of this filter: built ONCE and COMPLETE before the pointer is published - null stream + synchronisation,
+        // like every other lazily built table (fc_ensure_big, split_sub_table).  Built on the caller's stream (round 4) a second call on
+        // another non-blocking stream saw the pointer set and could read a half-written table: the setup's mutex orders hosts, not streams.
+        void* ab = nullptr;
+        PF_CHECK(hipMalloc(&ab, sizeof(float) * 4 * (size_t)S::n));
+        hipLaunchKernelGGL(fastconv_split1_coef_kernel<W>, dim3(1), dim3(S::WG), 0, nullptr, (const cx<float>*)d_Hc, (const cx<float>*)ps->d_twr,
+                           (vec4<float>*)ab);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) { (void)hipFree(ab); return fail(e, "fastconv_split1_coef_kernel"); }
+        *ab_cache = ab;
     }
     const cx<float>* tw512 = nullptr;
     if ((rc = split_sub_table(&tw512, S::M))) return rc;
@@ -73,7 +83,7 @@ static int fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(S::WG), S::LDS_BYTES, st, d_x, d_y, (const vec4<float>*)*ab_cache, nblk, step, inputLen,
-                       lastOut, (const cx<float>*)ps->d_tw, tw512, fb.nsig, fb.xstride, fb.ystride);
+                       lastOut, (const cx<float>*)ps->d_tw, tw512, fb.nsig, fb.xstride, fb.ystride, g_fir_xcd);
     PF_CHECK(hipGetLastError());
     return 0;
 }
@@ -103,10 +113,11 @@ static int fir_split(Setup* ps, const float* d_Hc, const float* d_x, float* d_y,
     const size_t groups = (size_t)nblk * fb.nsig;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
-    unsigned* ctr = groups <= grid ? nullptr : ps->d_ctr + 2 * (ps->ctr_slot.fetch_add(1) % CTR_RING);
+    const int xmode = (g_fir_xcd && groups < 0xfffffff0ull) ? 1 : 0;
+    unsigned* ctr = groups <= grid ? nullptr : take_counters(ps, st, xmode ? 5 : 1);   // (per-XCD counters: nine words)
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(S::WG), S::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
                        nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, tw1024, (const cx<float>*)ps->d_twr, ctr,
-                       fb.nsig, fb.xstride, fb.ystride);
+                       fb.nsig, fb.xstride, fb.ystride, xmode);
     PF_CHECK(hipGetLastError());
     return 0;
 }

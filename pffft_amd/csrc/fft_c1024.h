@@ -314,6 +314,32 @@ fft_c1024_f32_mix_kernel(const float* in, float* out, unsigned batch, const cx<f
     c1024_dyn_body<FWD, 0, OUT_INTERNAL, 1>(in, out, batch, twg, ctr, mix);
 }
 
+// ---- short launches: ONE transform per wavefront, W wavefronts per workgroup, workgroups in hardware dispatch order ----
+// A launch of a few transforms per resident wavefront never reaches the steady state the persistent loop is built for: its 256
+// workgroups of 8 wavefronts hold 64 KiB of loads per CU in flight and every lane opens with its 29 twiddle loads before the first
+// butterfly (batch 2^12: 24 us against 8.4 us of HBM time).  Here 4 workgroups x 4 wavefronts are resident per CU (35 KiB of LDS, 84
+// VGPRs each), every wavefront requests its vector FIRST and its twiddles behind it (L1 / L2 hits after the first workgroup of a CU),
+// and a retiring workgroup is replaced by the dispatcher.  Same part A / part B as the loop: bit-identical spectra whatever the launch
+// shape (tests/test_gpu_round4.py).
+template <int DIR, int IN_INTERNAL, int OUT_INTERNAL, int W>
+__global__ void __launch_bounds__(W * 64, 4)
+fft_c1024_f32_once_kernel(const float* in, float* out, unsigned batch, const cx<float>* __restrict__ twg) {
+    typedef cx<float> C;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
+    const size_t t = (size_t)blockIdx.x * W + wave;
+    if (t >= batch) return;                                   // wave-uniform; the kernel has no workgroup barrier
+    char* wbase = smem_raw + wave * C1024_WAVE_BYTES;
+    C* wl = reinterpret_cast<C*>(wbase);
+    float* wf = reinterpret_cast<float*>(wbase);
+    C1024V4 raw[8];
+    c1024_load(raw, in, t, L);
+    C w1[7][2], w2[15];
+    c1024_load_twiddles(twg, L, w1, w2);
+    c1024_part_a<DIR, IN_INTERNAL>(raw, wl, wf, w1, L);
+    c1024_part_b<DIR, OUT_INTERNAL>(out, t, wl, wf, w2, L);
+}
+
 // ---- static persistent assignment (variant 2, kept for A/B measurements) ----
 template <int DIR, int IN_INTERNAL, int OUT_INTERNAL>
 __global__ void __launch_bounds__(C1024_WAVES * 64, 2)

@@ -37,6 +37,16 @@ __device__ __forceinline__ void fc_split(long long ba, int nblk, int nsig, int& 
     sig = (int)(ba / nblk); blk = (int)(ba - (long long)sig * nblk);
 }
 
+// Position of workgroup b in a sweep of `grid` consecutive blocks such that every XCD takes a CONTIGUOUS run of the sweep: workgroup b
+// runs on XCD b mod 8 (observed placement, MI355X_MICROARCH.md - used for speed only, any placement is correct), XCD x takes positions
+// [x base + min(x, r), ...) with base = grid / 8, r = grid mod 8 - a bijection on [0, grid).  Adjacent overlap-save blocks share
+// taps - 1 input samples; taken by workgroups of different XCDs those are fetched through two L2s (rocprofv3, round 4: 1.13 x the
+// algorithmic bytes on the long signals, 1.59 x on the stated C4 call), inside one XCD the second reader hits.
+__device__ __forceinline__ unsigned xcd_local(unsigned b, unsigned grid) {
+    const unsigned base = grid >> 3, r = grid & 7u, x = b & 7u, q = b >> 3;
+    return x * base + (x < r ? x : r) + q;
+}
+
 struct __attribute__((packed, aligned(4))) F4u { float a, b, c, d; };  // block offsets are multiples of 4 bytes only
 
 template <class C>

@@ -59,7 +59,7 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
                       const cx<float>* __restrict__ twn,      // W_n^j, j < n
                       const cx<float>* __restrict__ tw1024,   // W_1024^j
                       const cx<float>* __restrict__ twr,      // W_N^k, k <= n/2, N = 2n
-                      unsigned* ctr, int nsig, size_t xstride, size_t ystride) {
+                      unsigned* ctr, int nsig, size_t xstride, size_t ystride, int xmode) {
     typedef float T;
     typedef cx<T> CX;
     typedef SplitFirT<W> S;
@@ -109,13 +109,25 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
 
     const bool dyn = ctr != nullptr;
     unsigned pend = 0;
-    unsigned g = blockIdx.x;
-    // the first TWO groups of a workgroup are static (its index, and that plus the grid); the counter hands out what follows: value v =
-    // group 2 grid + v.  (Every workgroup used to open with two grabs: ~2 000 atomics on one address, served at ~80 M/s, stood between the
-    // launch and the last workgroup's first load - 25-35 us of every launch, tools/r4_small_batch.py.)
-    pend = blockIdx.x + gridDim.x;
+    // the first TWO groups of a workgroup are static (its position in the sweep, and that plus the grid); the counter hands out what follows.
+    // (Every workgroup used to open with two grabs: ~2 000 atomics on one address, served at ~80 M/s, stood between the launch and the last
+    // workgroup's first load - 25-35 us of every launch, tools/r4_small_batch.py.)
+    // xmode (round 5): every XCD works on CONTIGUOUS blocks (fft_fir.h xcd_local) - the static sweeps through the XCD-contiguous map, the
+    // rest [2 grid, nblk_all) in eight contiguous ranges with one counter each (ctr[0 .. 7] next, ctr[8] done)
+    const unsigned xl = xmode ? xcd_local(blockIdx.x, gridDim.x) : blockIdx.x;
+    unsigned g = xl;
+    pend = xl + gridDim.x;
     __syncthreads();
     const long long nblk_all = (long long)nblk * nsig;
+    const unsigned xcd = blockIdx.x & 7u;
+    const long long rest = nblk_all - 2ll * gridDim.x, xper = rest > 0 ? (rest + 7) / 8 : 0;
+    const long long xbase = 2ll * gridDim.x + xcd * xper, xend = xbase + xper < nblk_all ? xbase + xper : nblk_all;
+    unsigned* cnext = ctr + (xmode ? xcd : 0u);
+    auto grabbed = [&](unsigned v) -> unsigned {
+        if (!xmode) return 2u * gridDim.x + v;
+        const long long gg = xbase + v;
+        return gg < xend ? (unsigned)gg : 0xffffffffu;
+    };
     // copies that would run past the signal are clamped to its last 16 bytes (their samples are replaced by the zero padding of
     // src/pffastconv.c:231-233 when the operands are picked up)
     const float* nx_src = x;                                 // the next block's signal and first sample for this lane (issue_pieces)
@@ -143,7 +155,7 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     for (unsigned it = 0; (long long)g < nblk_all; ++it) {
         if (dyn && tid == 0) {
             s_next[(it + 1) & 1] = pend;
-            pend = 2u * gridDim.x + atomicAdd(&ctr[0], 1u);
+            pend = grabbed(atomicAdd(cnext, 1u));
         }
         PF_DSTAMP(0);
         wait_vmcnt<0>();
@@ -331,8 +343,11 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     wait_vmcnt<0>();
     if (dyn && tid == 0) {
         __threadfence();
-        unsigned d = atomicAdd(&ctr[1], 1u);
-        if (d == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+        unsigned d = atomicAdd(&ctr[xmode ? 8 : 1], 1u);
+        if (d == gridDim.x - 1) {
+            if (xmode) { for (int i = 0; i < 9; ++i) atomicExch(&ctr[i], 0u); }
+            else { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+        }
     }
 }
 
@@ -388,7 +403,7 @@ fastconv_split1_kernel(const float* __restrict__ x, float* __restrict__ y, const
                        int nblk, int step, int inputLen, int lastOut,
                        const cx<float>* __restrict__ twn,      // W_n^j, j < n
                        const cx<float>* __restrict__ tw512,    // W_512^j
-                       int nsig, size_t xstride, size_t ystride) {
+                       int nsig, size_t xstride, size_t ystride, int xmode) {
     typedef float T;
     typedef cx<T> CX;
     typedef SplitOneT<W> S;
@@ -424,7 +439,8 @@ fastconv_split1_kernel(const float* __restrict__ x, float* __restrict__ y, const
     };
     const unsigned it = 3; (void)it;      // (PF_DSTAMP's iteration filter: one-shot kernel)
     PF_DSTAMP(0);
-    long long g = blockIdx.x;
+    // (xmode: sweep positions through the XCD-contiguous map - adjacent blocks share taps - 1 samples and meet in one L2)
+    long long g = xmode ? xcd_local(blockIdx.x, gridDim.x) : blockIdx.x;
     if (g < nblk_all) gather(g);
     PF_DSTAMP(1);
     // ---- per-thread constants

@@ -22,7 +22,7 @@ static int mw_launch(Setup* s, const T* in, T* out, size_t batch, int dir, int o
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
     const int flags = ((!fwd && !ordered) ? 1 : 0) | ((fwd && !ordered) ? 2 : 0);
-    unsigned* ctr = groups <= grid ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = groups <= grid ? nullptr : take_counters(s, st);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), C::LDS_BYTES, st, in, out, (unsigned)batch, flags,
                        (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
     PF_CHECK(hipGetLastError());

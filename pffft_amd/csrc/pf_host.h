@@ -31,6 +31,9 @@ int fail(hipError_t e, const char* what);
 
 int num_cus();
 
+// is `st` recording into a HIP graph right now (hipStreamIsCapturing; errors read as "no")
+bool stream_capturing(hipStream_t st);
+
 // opt-in to more than 64 KiB of dynamic LDS: once per (kernel, size) - the attribute call sat on every launch
 int allow_big_lds_impl(const void* kernel, size_t bytes);
 template <typename K>
@@ -46,6 +49,7 @@ int cached_occupancy(const void* kernel, int threads, size_t lds, int* per_cu);
 enum Kernel { K_GENERIC = 0, K_C1024_F32 = 1, K_TILED = 2, K_BIG = 3 };
 constexpr size_t LDS_MAX = 160 * 1024;
 constexpr unsigned CTR_RING = 4096;
+constexpr unsigned CTR_CAPTURED = 512;   // counter pairs set aside for launches recorded into a HIP graph (take_counters)
 
 struct Setup {
     uint32_t magic;
@@ -68,8 +72,8 @@ struct Setup {
     void* d_tw = nullptr;   // W_n^j, j < n
     void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
     void* d_twc[2] = {nullptr, nullptr};  // compact per-stage base twiddles of the Stockham plans (forward / backward order)
-    unsigned* d_ctr = nullptr;             // ring of {next, done} work counters for the dynamic kernels
-    std::atomic<unsigned> ctr_slot{0};
+    unsigned* d_ctr = nullptr;             // ring of {next, done} work counters for the dynamic kernels (+ the captured region behind it)
+    std::atomic<unsigned> ctr_slot{0}, cap_slot{0};
     // sizes beyond LDS with a small factor (fft_big.h, three streaming passes): n = bigR x sub->n
     int bigR = 0;
     Setup* sub = nullptr;
@@ -78,7 +82,11 @@ struct Setup {
     void* d_bigtw[2] = {nullptr, nullptr};
     // HBM work buffers of the beyond-LDS path: one pair PER STREAM (kernels of one stream serialise; two streams running
     // the same setup concurrently must not share scratch).  big_mu is held while a call enqueues its passes (launch_big).
-    struct Scratch { void* buf[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; unsigned long long last_use = 0; };
+    // captured: a launch using these buffers was recorded into a HIP graph - a replay dereferences the pointers it froze, so such an
+    // entry is never evicted and a buffer it outgrows is retired (freed with the setup) instead of freed
+    struct Scratch { void* buf[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; unsigned long long last_use = 0; bool captured = false; };
+    std::mutex retired_mu;
+    std::vector<void*> retired;
     unsigned long long scratch_clock = 0;      // (under big_mu) orders the streams' last uses: the idlest one is evicted first
     std::mutex big_mu;
     std::map<hipStream_t, Scratch> big_scratch;
@@ -92,6 +100,15 @@ struct Setup {
     size_t hstage_bytes[4] = {0, 0, 0, 0};
 };
 constexpr uint32_t MAGIC = 0x50464654u;  // "PFFT"
+
+// The {next, done} work-counter pairs of ONE launch of an in-order kernel (`pairs` consecutive pairs: the per-XCD kernels take five).  A
+// direct launch takes the next slot of the setup's ring: reused CTR_RING launches later, i.e. at most CTR_RING launches of one setup in
+// flight at once (include/pffft_hip.h).  A launch that is being RECORDED INTO A GRAPH freezes its counter address for every replay: it gets
+// a slot of a region of its own, outside the ring, so that no later direct launch can share counters with a replay running on another
+// stream (tiles skipped or run twice).  CTR_CAPTURED captured launches per setup have private counters; beyond that the region wraps, which
+// is safe as long as the launches that share a slot do not run concurrently (nodes of one graph on one stream never do).
+struct Setup;
+unsigned* take_counters(Setup* s, hipStream_t st, unsigned pairs = 1);
 
 struct FcBatch { int nsig; size_t xstride, ystride; };   // signals of one pffastconv call (1 for the reference entries)
 

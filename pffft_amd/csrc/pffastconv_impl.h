@@ -32,7 +32,8 @@ struct FastConv {
     float* d_td = nullptr;
     void* d_split1_ab = nullptr;   // folded per-bin coefficients of the few-block split kernel (fft_split.h), built on first use
     // work image of the composed path: one per stream (two streams running one setup must not share scratch)
-    struct Work { float* p = nullptr; size_t floats = 0; unsigned long long last_use = 0; };
+    struct Work { float* p = nullptr; size_t floats = 0; unsigned long long last_use = 0; bool captured = false; };   // captured: pf_host.h Scratch
+    std::vector<float*> retired;
     unsigned long long work_clock = 0;
     std::map<hipStream_t, Work> work;
     float* d_x = nullptr; size_t x_floats = 0;   // staging of pffastconv_apply's host pointers (large signals)
@@ -192,7 +193,7 @@ static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, 
     if (grid > groups) grid = groups;
     Setup* ps = pst ? pst : s->st;
     if (!d_Hc) d_Hc = s->d_Hc;
-    unsigned* ctr = groups <= grid ? nullptr : ps->d_ctr + 2 * (ps->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = groups <= grid ? nullptr : take_counters(ps, st);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), C::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
                        nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, ctr,
                        fb.nsig, fb.xstride, fb.ystride);
@@ -504,14 +505,18 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     }
     // composed path (complex-I/O modes with long filters): signal by signal on the same stream through one work image
     if (s->work.size() >= 8 && !s->work.count(st)) {   // the stream that used this setup longest ago gives up its image (hipFree waits for its kernels)
-        auto victim = s->work.begin();
+        auto victim = s->work.end();                   // (never an image a HIP graph has recorded: a replay dereferences the frozen pointer)
         for (auto it = s->work.begin(); it != s->work.end(); ++it)
-            if (it->second.last_use < victim->second.last_use) victim = it;
-        if (victim->second.p) (void)hipFree(victim->second.p);
-        s->work.erase(victim);
+            if (!it->second.captured && (victim == s->work.end() || it->second.last_use < victim->second.last_use)) victim = it;
+        if (victim != s->work.end()) {
+            if (victim->second.p) (void)hipFree(victim->second.p);
+            s->work.erase(victim);
+        }
     }
     FastConv::Work& wk = s->work[st];
     wk.last_use = ++s->work_clock;
+    if (stream_capturing(st)) wk.captured = true;
+    if (wk.captured && wk.p && wk.floats < (size_t)nblk * Nfft) { s->retired.push_back(wk.p); wk.p = nullptr; wk.floats = 0; }   // outgrown: retired, not freed
     rc = fc_grow(&wk.p, &wk.floats, (size_t)nblk * Nfft);
     if (rc) return rc;
     float* const d_work = wk.p;
@@ -576,6 +581,7 @@ PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
     for (float* p : {s->d_Hf, s->d_Hc, s->d_Hc_big, s->d_Hp, s->d_td, s->d_x, s->d_y}) if (p) (void)hipFree(p);
     if (s->st_part) pffft_destroy_setup(s->st_part);
     for (auto& kv : s->work) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (float* p : s->retired) if (p) (void)hipFree(p);
     if (s->d_split1_ab) (void)hipFree(s->d_split1_ab);
     for (float* p : {s->h_x, s->h_y}) if (p) (void)hipHostFree(p);
     s->magic = 0;

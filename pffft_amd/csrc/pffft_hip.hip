@@ -283,6 +283,7 @@ static void destroy_setup(Setup* s) {
     for (void* p : s->d_bigtw) if (p) (void)hipFree(p);
     for (auto& kv : s->big_scratch) for (void* p : kv.second.buf) if (p) (void)hipFree(p);
     for (auto& kv : s->conv_scratch) for (void* p : kv.second.buf) if (p) (void)hipFree(p);
+    for (void* p : s->retired) if (p) (void)hipFree(p);
     for (void* p : s->d_stage) if (p) (void)hipFree(p);
     for (void* p : s->h_stage) if (p) (void)hipHostFree(p);
     s->magic = 0;
@@ -312,9 +313,22 @@ static int alloc_counter_ring(Setup* s) {
     // launches later, i.e. at most CTR_RING launches of one setup may be in flight at once
     // (stated in include/pffft_hip.h; launches on one stream serialise, so this bounds concurrent streams x depth).
     if (s->d_ctr) return 0;
-    PF_CHECK(hipMalloc((void**)&s->d_ctr, sizeof(unsigned) * (2 * CTR_RING + 16)));   // (+ 16: a launch may take several consecutive pairs)
-    PF_CHECK(hipMemset(s->d_ctr, 0, sizeof(unsigned) * (2 * CTR_RING + 16)));
+    // (+ 16 after each region: a launch may take several consecutive pairs from the last slot)
+    constexpr size_t words = 2 * (size_t)CTR_RING + 16 + 2 * (size_t)CTR_CAPTURED + 16;
+    PF_CHECK(hipMalloc((void**)&s->d_ctr, sizeof(unsigned) * words));
+    PF_CHECK(hipMemset(s->d_ctr, 0, sizeof(unsigned) * words));
     return 0;
+}
+
+bool stream_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs == hipStreamCaptureStatusActive;
+}
+
+unsigned* take_counters(Setup* s, hipStream_t st, unsigned pairs) {
+    if (stream_capturing(st)) return s->d_ctr + 2 * (size_t)CTR_RING + 16 + 2 * (s->cap_slot.fetch_add(pairs) % CTR_CAPTURED);
+    return s->d_ctr + 2 * (s->ctr_slot.fetch_add(pairs) % CTR_RING);
 }
 
 template <typename T>
@@ -434,18 +448,54 @@ int num_cus() {
     return cus;
 }
 
+template <int W>
+static int launch_c1024_once(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    const unsigned grid = (unsigned)((batch + W - 1) / W);
+    const size_t lds = (size_t)W * C1024_WAVE_BYTES;
+    const cx<float>* tw = (const cx<float>*)s->d_tw;
+#define PF_LAUNCH_C1024_ONCE(D, I, O)                                                                 \
+    do {                                                                                              \
+        auto k = fft_c1024_f32_once_kernel<D, I, O, W>;                                               \
+        int rc = allow_big_lds(k, lds);                                                               \
+        if (rc) return rc;                                                                            \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(W * 64), lds, st, in, out, (unsigned)batch, tw);       \
+    } while (0)
+    if (dir == PFFFT_FORWARD) {
+        if (ordered) PF_LAUNCH_C1024_ONCE(FWD, 0, 0); else PF_LAUNCH_C1024_ONCE(FWD, 0, 1);
+    } else {
+        if (ordered) PF_LAUNCH_C1024_ONCE(BWD, 0, 0); else PF_LAUNCH_C1024_ONCE(BWD, 1, 0);
+    }
+#undef PF_LAUNCH_C1024_ONCE
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int launch_c1024(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    // short launches: one transform per wavefront in dispatch order (fft_c1024.h once kernel) up to `rounds` resident sets of
+    // 16 wavefronts per CU; PFFFT_HIP_C1024_ONCE="W,rounds" (A/B; rounds 0 = always the loop)
+    static const std::pair<int, int> once = [] {
+        int w = 4, r = 4;
+        const char* e = getenv("PFFFT_HIP_C1024_ONCE");
+        if (e) sscanf(e, "%d,%d", &w, &r);
+        return std::make_pair(w, r);
+    }();
+    if (g_variant == 0 && once.second > 0 && batch <= (size_t)once.second * 16 * (size_t)num_cus()) {
+        if (once.first == 2) return launch_c1024_once<2>(s, in, out, batch, dir, ordered, st);
+        if (once.first == 8) return launch_c1024_once<8>(s, in, out, batch, dir, ordered, st);
+        return launch_c1024_once<4>(s, in, out, batch, dir, ordered, st);
+    }
     const unsigned wgs_needed = (unsigned)((batch + C1024_WAVES - 1) / C1024_WAVES);
     // variants (bench A/B only): 0 = dynamic in-order, 1 WG/CU (default); 3 = dynamic, 2 WG/CU;
     // 2 = static persistent assignment, 2 WG/CU
     const bool dyn = g_variant != 2;
-    unsigned grid = (unsigned)num_cus() * ((g_variant == 2 || g_variant == 3) ? 2 : 1);
+    static const int loop_wgs = [] { const char* e = getenv("PFFFT_HIP_C1024_WGS"); return e ? atoi(e) : 1; }();   // A/B: workgroups per CU
+    unsigned grid = (unsigned)num_cus() * ((g_variant == 2 || g_variant == 3) ? 2 : loop_wgs);
     if (grid > wgs_needed) grid = wgs_needed;
     const dim3 blk(C1024_WAVES * 64);
     const size_t lds = C1024_LDS_BYTES;
     const cx<float>* tw = (const cx<float>*)s->d_tw;
     const unsigned b = (unsigned)batch;
-    unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = take_counters(s, st);
 #define PF_LAUNCH_C1024(D, I, O)                                                                      \
     do {                                                                                              \
         if (dyn) {                                                                                    \
@@ -480,7 +530,7 @@ static int launch_c1024_mix(Setup* s, const float* in, float* out, size_t batch,
     const size_t lds = C1024_LDS_BYTES;
     const cx<float>* tw = (const cx<float>*)s->d_tw;
     const unsigned b = (unsigned)batch;
-    unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = take_counters(s, st);
     C1024Mix mix;
     step_turns -= std::rint(step_turns);
     phase_turns -= std::rint(phase_turns);
@@ -644,7 +694,7 @@ static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, in
     if (oneshot && groups <= oneshot * grid && groups < 0x7fffffffull) grid = groups;
     if (grid > groups) grid = groups;
     const int flags = (((dir == PFFFT_BACKWARD) && !ordered) ? 1 : 0) | (((dir == PFFFT_FORWARD) && !ordered) ? 2 : 0);
-    unsigned* ctr = groups <= grid ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = groups <= grid ? nullptr : take_counters(s, st);
     hipLaunchKernelGGL(e.fn, dim3((unsigned)grid), dim3(e.wg), e.lds, st, in, out, (unsigned)batch, flags,
                        (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
     PF_CHECK(hipGetLastError());
@@ -748,7 +798,7 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
             if (want_dyn && oneshot_env && groups <= oneshot_env * grid) grid = groups;
             if (grid > groups) grid = groups;
             if (grid > 0x7fffffffu) grid = 0x7fffffffu;
-            unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+            unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : take_counters(s, st);
             hipLaunchKernelGGL(cf, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch, twp,
                                (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
             PF_CHECK(hipGetLastError());
@@ -766,7 +816,7 @@ static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, in
     if (g_variant >= 10 && g_variant < 20 && per_cu > g_variant - 10 && g_variant > 10) per_cu = g_variant - 10;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
-    unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+    unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : take_counters(s, st);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch, sp, flags, twp,
                        (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
     PF_CHECK(hipGetLastError());
@@ -880,6 +930,40 @@ static int launch_block(Setup* s, int mode, const T* in, T* out, size_t batch, h
     return 0;
 }
 
+// Per-stream scratch of a setup (held under the setup's scratch lock).  More than SCRATCH_STREAMS streams: ONE entry goes - the stream that
+// used this setup longest ago (hipFree waits for its kernels) - not the whole map: a caller cycling through nine streams would otherwise
+// free and re-allocate every stream's buffers on every call.  An entry a HIP graph has recorded (Scratch::captured) is never the victim,
+// and a buffer it outgrows is retired instead of freed: a replay dereferences the pointers it froze at capture time.
+constexpr size_t SCRATCH_STREAMS = 8;
+static int stream_scratch(std::map<hipStream_t, Setup::Scratch>& tab, unsigned long long& clock, hipStream_t st, Setup::Scratch** out) {
+    if (tab.size() >= SCRATCH_STREAMS && !tab.count(st)) {
+        auto victim = tab.end();
+        for (auto it = tab.begin(); it != tab.end(); ++it)
+            if (!it->second.captured && (victim == tab.end() || it->second.last_use < victim->second.last_use)) victim = it;
+        if (victim != tab.end()) {
+            for (void* p : victim->second.buf) if (p) (void)hipFree(p);
+            tab.erase(victim);
+        }
+    }
+    Setup::Scratch& sc = tab[st];
+    sc.last_use = ++clock;
+    if (stream_capturing(st)) sc.captured = true;
+    *out = &sc;
+    return 0;
+}
+static int scratch_grow(Setup* s, Setup::Scratch& sc, int i, size_t bytes) {
+    if (sc.bytes[i] >= bytes) return 0;
+    // (hipFree waits for the device: kernels of this stream still using the old buffer finish first)
+    if (sc.buf[i]) {
+        if (sc.captured) { std::lock_guard<std::mutex> lk(s->retired_mu); s->retired.push_back(sc.buf[i]); }
+        else (void)hipFree(sc.buf[i]);
+    }
+    sc.buf[i] = nullptr; sc.bytes[i] = 0;
+    PF_CHECK(hipMalloc(&sc.buf[i], bytes));   // (while the stream is capturing this fails: warm the setup up with the largest batch first)
+    sc.bytes[i] = bytes;
+    return 0;
+}
+
 // n beyond LDS: canonical complex four-step through two HBM work buffers, with the real pair pass and the
 // internal layout composed around it (fft_big.h)
 template <typename T>
@@ -900,26 +984,12 @@ static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int 
     // this setup (hipFree waits for their kernels), so idle streams do not pin 2 x batch x n x sizeof(cx) bytes each.
     std::lock_guard<std::mutex> lk(s->big_mu);
     {
-        constexpr size_t BIG_SCRATCH_STREAMS = 8;
-        if (s->big_scratch.size() >= BIG_SCRATCH_STREAMS && !s->big_scratch.count(st)) {
-            // ONE entry goes - the stream that used this setup longest ago (hipFree waits for its kernels) - not the whole map:
-            // a caller cycling through nine streams would otherwise free and re-allocate every stream's pair on every call
-            auto victim = s->big_scratch.begin();
-            for (auto it = s->big_scratch.begin(); it != s->big_scratch.end(); ++it)
-                if (it->second.last_use < victim->second.last_use) victim = it;
-            for (void* p : victim->second.buf) if (p) (void)hipFree(p);
-            s->big_scratch.erase(victim);
-        }
-        Setup::Scratch& sc = s->big_scratch[st];
-        sc.last_use = ++s->scratch_clock;
+        Setup::Scratch* scp = nullptr;
+        int rcs = stream_scratch(s->big_scratch, s->scratch_clock, st, &scp);
+        if (rcs) return rcs;
+        Setup::Scratch& sc = *scp;
         for (int i = 0; i < 2; ++i)
-            if (sc.bytes[i] < bytes) {
-                // hipFree waits for the device: kernels of this stream still using the old buffer finish first
-                if (sc.buf[i]) (void)hipFree(sc.buf[i]);
-                sc.buf[i] = nullptr; sc.bytes[i] = 0;
-                PF_CHECK(hipMalloc(&sc.buf[i], bytes));
-                sc.bytes[i] = bytes;
-            }
+            if ((rcs = scratch_grow(s, sc, i, bytes))) return rcs;
         bufA = (cx<T>*)sc.buf[0];
         bufB = (cx<T>*)sc.buf[1];
     }
@@ -1137,7 +1207,7 @@ static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, 
         const size_t img = to_canon ? (size_t)zrd_canon_img16<T>(s->n) * 16 : vimg;
         const size_t lds = (size_t)G * img + 16;
         if (lds <= LDS_MAX) {
-            unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+            unsigned* ctr = take_counters(s, st);
             const int nchk = 2 * s->n / CH;
             const dim3 grid((unsigned)num_cus()), blk(ZRD_THREADS);
             const int real = s->transform == PFFFT_REAL;
@@ -1174,7 +1244,7 @@ static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, 
         if (kc > 64) kc = 64;
         // static by default: 0.61-0.70 of the roofline against 0.47-0.62 with in-order chunks (variant 42) and
         // 0.41-0.61 for the direct kernel (tools/aux_bench.py)
-        unsigned* ctr = (kc < 1 || g_variant != 42) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+        unsigned* ctr = (kc < 1 || g_variant != 42) ? nullptr : take_counters(s, st);
         if (kc < 1) kc = 1;
         const int nchk = 2 * s->n / CH;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(ZR_THREADS), lds, st, in, out, batch, s->n,
@@ -1208,7 +1278,7 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
             Q / Zd<T>::CHUNK < 0xffffffffull) {
             int rc = ensure_device<T>(s);
             if (rc) return rc;
-            unsigned* ctr = s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+            unsigned* ctr = take_counters(s, st);
             const int real = s->transform == PFFFT_REAL;
             const dim3 grid((unsigned)num_cus()), blk(ZD_WAVES * 64);
             const unsigned nq = (unsigned)(s->n / 2) * Zd<T>::UPG;   // units per vector
@@ -1228,7 +1298,7 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
         if (grid > chunks) grid = chunks;
         size_t kc = 4, cap = chunks / (8 * grid);
         if (kc > cap) kc = cap;
-        unsigned* ctr = (kc < 1 || g_variant != 42) ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(1) % CTR_RING);
+        unsigned* ctr = (kc < 1 || g_variant != 42) ? nullptr : take_counters(s, st);
         if (kc < 1) kc = 1;
         const int real = s->transform == PFFFT_REAL;
         if (accumulate)
@@ -1290,21 +1360,10 @@ static int convolve_batch(Setup* s, const T* in, const T* H, T* out, T scaling, 
     }
     const size_t bytes = batch * s->vec_scalars * sizeof(T);
     std::lock_guard<std::mutex> lk(s->conv_mu);
-    if (s->conv_scratch.size() >= 8 && !s->conv_scratch.count(st)) {   // the idlest stream's image goes (hipFree waits for its kernels)
-        auto victim = s->conv_scratch.begin();
-        for (auto it = s->conv_scratch.begin(); it != s->conv_scratch.end(); ++it)
-            if (it->second.last_use < victim->second.last_use) victim = it;
-        if (victim->second.buf[0]) (void)hipFree(victim->second.buf[0]);
-        s->conv_scratch.erase(victim);
-    }
-    Setup::Scratch& sc = s->conv_scratch[st];
-    sc.last_use = ++s->conv_clock;
-    if (sc.bytes[0] < bytes) {
-        if (sc.buf[0]) (void)hipFree(sc.buf[0]);
-        sc.buf[0] = nullptr; sc.bytes[0] = 0;
-        PF_CHECK(hipMalloc(&sc.buf[0], bytes));
-        sc.bytes[0] = bytes;
-    }
+    Setup::Scratch* scp = nullptr;
+    if ((rc = stream_scratch(s->conv_scratch, s->conv_clock, st, &scp))) return rc;
+    Setup::Scratch& sc = *scp;
+    if ((rc = scratch_grow(s, sc, 0, bytes))) return rc;
     T* X = (T*)sc.buf[0];
     if ((rc = transform_batch<T>(s, in, X, batch, PFFFT_FORWARD, 0, st))) return rc;
     if ((rc = zconvolve_batch<T>(s, X, H, X, scaling, batch, 0, h_broadcast, st))) return rc;

@@ -72,7 +72,7 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     // (bit 2: per-XCD counters for the column passes with 64-byte runs only - adjacent tiles share every line there)
     const bool xctr = dynm && ((xmode_env & 2) || ((xmode_env & 4) && PP == 4 && D.seq_contig)) && grid % 8 == 0 && ngroups >= 64 && D.group <= 1;
     // (per-XCD counters: nine words = five {next, done} pairs of the ring, which is allocated with that much room past its end)
-    unsigned* ctr = !dynm ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(xctr ? 5 : 1) % CTR_RING);
+    unsigned* ctr = !dynm ? nullptr : take_counters(s, st, xctr ? 5 : 1);
     TileDesc D2 = D;
     static const int cstart_env = [] { const char* e = getenv("PFFFT_HIP_TILE_CSTART"); return e ? atoi(e) : 0; }();   // A/B: start-up grabs from the counter
     D2.xmode = (xctr ? 2u : 0u) | ((!dynm && (xmode_env & 1) && D.group <= 1) ? 1u : 0u) | (cstart_env ? 8u : 0u);

@@ -31,7 +31,7 @@ static int rtile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, co
     static const int x_env = [] { const char* e = getenv("PFFFT_HIP_RFFT_X"); return e ? atoi(e) : 2; }();
     const bool dynm = !(ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
     const bool xctr = RMODE == 2 && dynm && (x_env & 2) && grid % 8 == 0 && ntiles >= 64;
-    unsigned* ctr = !dynm ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(xctr ? 5 : 1) % CTR_RING);
+    unsigned* ctr = !dynm ? nullptr : take_counters(s, st, xctr ? 5 : 1);
     TileDesc D2 = D;
     D2.xmode = xctr ? 2u : 0u;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D2, ctr);

@@ -92,7 +92,7 @@ static int tile_gen_launch(const TileGenPlan& P, const cx<T>* in, cx<T>* out, un
     const bool dynm = !(ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
     const bool xctr = dynm && xctr_env && grid % 8 == 0 && ntiles >= 64;
     // (per-XCD counters: nine words = five {next, done} pairs of the ring, which is allocated with that much room past its end)
-    unsigned* ctr = !dynm ? nullptr : s->d_ctr + 2 * (s->ctr_slot.fetch_add(xctr ? 5 : 1) % CTR_RING);
+    unsigned* ctr = !dynm ? nullptr : take_counters(s, st, xctr ? 5 : 1);
     static const int xcd_env = [] { const char* e = getenv("PFFFT_HIP_TILE_XCD"); return e ? atoi(e) : 1; }();
     // (the XCD-contiguous tile map of the static stride is a bijection of workgroup index to tile only on a grid of whole eights: rounded
     //  up, the workgroups beyond the tiles retire at once)
