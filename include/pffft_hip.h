@@ -181,6 +181,13 @@ int pffastconv_hip_apply_batch(PFFASTCONV_Setup *, const float *d_input, int inp
  * run-time plan because the size has no generated compile-time plan (no legal size today), "fourstep" = tile / streaming
  * passes beyond LDS): for tests/bench. */
 const char *pffft_hip_kernel_name(const void *setup);
+/* The routes of a setup as text: one line for the setup and one per (direction, layout) with the kernel family, its configuration,
+ * the launch rule (dispatch order / static stride / in-order loop and the bound below which a launch runs in dispatch order) and,
+ * beyond LDS, the sweeps over HBM (tile lengths, which pass reads / stores the internal layout).  Decided once, at pffft_new_setup
+ * (reference: the ifac[] / twiddle plan of struct PFFFT_Setup, src/pffft_priv_impl.h:1051-1060, is fixed at setup time too).  Writes at
+ * most len - 1 characters + a terminating 0 into buf and returns the length of the whole text (snprintf convention), -1 for an
+ * invalid handle.  Works for PFFFT_Setup and PFFFTD_Setup handles; no device needed. */
+int pffft_hip_describe(const void *setup, char *buf, size_t len);
 /* The tile plan of a complex core transform of n points beyond LDS (n = N for complex setups, N / 2 for real ones): returns the
  * number of tile passes over HBM — 2 or 3 — and their tile lengths in `lengths` (column pass(es) first, the row pass last), or 0
  * when the size runs on the streaming passes (or is LDS-resident: the planner is not consulted then).  `deep` = 1: the size's
@@ -195,9 +202,11 @@ const char *pffft_hip_last_error(void);
  * vector with NaN (all-ones bytes) and increments this counter.  PFFFT_HIP_ABORT=1 makes it abort() instead. */
 unsigned pffft_hip_error_count(void);
 int pffft_hip_device_count(void);
-/* 0 = default; other values select alternative kernels / work distributions for A/B measurements and for the parity
- * tests that hold every alternative to the same bar.  The selector is THREAD-LOCAL: it affects only calls made by the
- * thread that set it. */
+/* 0 = the planner's routes; the other values (enum AbValue, pffft_amd/csrc/pf_route.h) select an ALTERNATIVE ROUTE to the same
+ * result - the streaming passes instead of the tile passes beyond LDS, the composed convolution instead of the fused kernel ... -
+ * which the parity tests hold to the same bar as the default one; a development build (-DPFFFT_HIP_VARIANTS) knows a few more.  A
+ * value the build does not know runs the default route.  The selector is THREAD-LOCAL: it affects only calls made by the thread
+ * that set it. */
 void pffft_hip_set_variant(int variant);
 /* 1 when the library was built with -DPFFFT_HIP_VARIANTS (development build: both variants of every Stockham plan are
  * instantiated for A/B measurements), 0 for the product build (the adopted variant only; a selector that asks for the

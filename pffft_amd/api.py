@@ -96,6 +96,7 @@ def lib():
     L.pffft_hip_shift_transform_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double,
                                                   C.c_double, C.c_void_p]
     L.pffft_hip_kernel_name.restype = C.c_char_p; L.pffft_hip_kernel_name.argtypes = [C.c_void_p]
+    L.pffft_hip_describe.restype = C.c_int; L.pffft_hip_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.pffft_hip_last_error.restype = C.c_char_p
     L.pffft_hip_device_count.restype = C.c_int
     L.pffft_hip_set_variant.restype = None; L.pffft_hip_set_variant.argtypes = [C.c_int]
@@ -162,6 +163,15 @@ def tile_plan(n, is_double=False, deep=False):
 
 def kernel_name(setup: "Setup") -> str:
     return lib().pffft_hip_kernel_name(setup.handle).decode()
+
+
+def describe(setup: "Setup") -> str:
+    """pffft_hip_describe: the routes the planner chose for this setup, one line per (direction, layout)."""
+    buf = C.create_string_buffer(4096)
+    n = lib().pffft_hip_describe(setup.handle, buf, len(buf))
+    if n < 0:
+        raise ValueError("pffft_hip_describe: invalid handle")
+    return buf.value.decode()
 
 
 def _is_torch(x) -> bool:

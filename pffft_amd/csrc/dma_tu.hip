@@ -9,8 +9,6 @@
 
 namespace pf {
 
-// XCD-contiguous block ranges of the split kernels (fft_fir.h xcd_local); PFFASTCONV_HIP_XCD=0 switches them off (A/B)
-static const int g_fir_xcd = [] { const char* e = getenv("PFFASTCONV_HIP_XCD"); return e ? atoi(e) : 1; }();
 
 template <class C>
 static int fir_dma_cfg(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen,
@@ -83,7 +81,7 @@ static int fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(S::WG), S::LDS_BYTES, st, d_x, d_y, (const vec4<float>*)*ab_cache, nblk, step, inputLen,
-                       lastOut, (const cx<float>*)ps->d_tw, tw512, fb.nsig, fb.xstride, fb.ystride, g_fir_xcd);
+                       lastOut, (const cx<float>*)ps->d_tw, tw512, fb.nsig, fb.xstride, fb.ystride, env().fir_xcd);
     PF_CHECK(hipGetLastError());
     return 0;
 }
@@ -113,7 +111,7 @@ static int fir_split(Setup* ps, const float* d_Hc, const float* d_x, float* d_y,
     const size_t groups = (size_t)nblk * fb.nsig;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
-    const int xmode = (g_fir_xcd && groups < 0xfffffff0ull) ? 1 : 0;
+    const int xmode = (env().fir_xcd && groups < 0xfffffff0ull) ? 1 : 0;
     unsigned* ctr = groups <= grid ? nullptr : take_counters(ps, st, xmode ? 5 : 1);   // (per-XCD counters: nine words)
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(S::WG), S::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
                        nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, tw1024, (const cx<float>*)ps->d_twr, ctr,
@@ -133,10 +131,12 @@ int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, i
             //  efficiency at 2048 taps (0.394 against 0.428); not instantiated here)
             return fir_dma_cfg<DmaCfgF32::D4096>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
         case 8192:
-            // 16384-sample blocks: cross-wave radix 8 + wave-local 1024-point transforms (fft_split.h); variant 97 = the lock-step
-            // LDS-DMA kernel it replaced, 116 = without the pairwise flags and the spread pieces (A/B)
-            if (g_variant == 97) return fir_dma_cfg<DmaCfgF32::D8192>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-            if (g_variant == 116) return fir_split<0, 0>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            // 16384-sample blocks: cross-wave radix 8 + wave-local 1024-point transforms (fft_split.h).  Development build: AB_FIR_LOCKSTEP =
+            // the lock-step LDS-DMA kernel it replaced, AB_FIR_SPLIT_PLAIN = without the pairwise flags and the spread pieces
+#ifdef PFFFT_HIP_VARIANTS
+            if (ab().is(AB_FIR_LOCKSTEP)) return fir_dma_cfg<DmaCfgF32::D8192>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+            if (ab().is(AB_FIR_SPLIT_PLAIN)) return fir_split<0, 0>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+#endif
             return fir_split<1, 1>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
         default: return -1;
     }

@@ -340,25 +340,4 @@ fft_c1024_f32_once_kernel(const float* in, float* out, unsigned batch, const cx<
     c1024_part_b<DIR, OUT_INTERNAL>(out, t, wl, wf, w2, L);
 }
 
-// ---- static persistent assignment (variant 2, kept for A/B measurements) ----
-template <int DIR, int IN_INTERNAL, int OUT_INTERNAL>
-__global__ void __launch_bounds__(C1024_WAVES * 64, 2)
-fft_c1024_f32_kernel(const float* in, float* out, unsigned batch, const cx<float>* __restrict__ twg) {
-    typedef cx<float> C;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
-    char* wbase = smem_raw + wave * C1024_WAVE_BYTES;
-    C* wl = reinterpret_cast<C*>(wbase);
-    float* wf = reinterpret_cast<float*>(wbase);
-    C w1[7][2], w2[15];
-    c1024_load_twiddles(twg, L, w1, w2);
-    const unsigned nwaves = gridDim.x * C1024_WAVES;
-    for (unsigned t = blockIdx.x * C1024_WAVES + wave; t < batch; t += nwaves) {
-        C1024V4 raw[8];
-        c1024_load(raw, in, t, L);
-        c1024_part_a<DIR, IN_INTERNAL>(raw, wl, wf, w1, L);
-        c1024_part_b<DIR, OUT_INTERNAL>(out, t, wl, wf, w2, L);
-    }
-}
-
 }  // namespace pf

@@ -186,17 +186,17 @@ tileg_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned lon
     // the prefetch knows its tile (the protocol of fft_tile.h)
     // static stride: workgroup b runs on XCD b mod 8 (round-robin dispatch); XCD x takes the CONTIGUOUS tiles x per .. (x + 1) per - 1 of every
     // sweep of the grid, so that tiles which share 128-byte lines (a stride between points that is not a multiple of 16 elements) meet in
-    // one L2 (PFFFT_HIP_TILE_XCD=0: tile = workgroup index, A/B through TileDesc::group bit 8)
+    // one L2 (TileDesc::xmode bit 0; off: tile = workgroup index)
     const unsigned per = (gridDim.x + 7) / 8;
-    const bool xmap = !(D.group & 256u);
+    const bool xmap = (D.xmode & 1u) != 0;
     const unsigned long long first = xmap ? (unsigned long long)(blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
     const unsigned long long sweep = xmap ? 8ull * per : gridDim.x;
     unsigned long long tile = first, tile1 = first + sweep;
     unsigned pend = 0;
     // in order from the counter: ONE counter per XCD (workgroup b runs on XCD b mod 8), each over a contiguous eighth of the tiles, so that
     // the tiles in flight on an XCD are neighbours and the 128-byte lines two of them share are fetched through one L2 (ctr[0 .. 7] next,
-    // ctr[8] done; TileDesc::group bit 11 off: one counter for all - A/B)
-    const bool xctr = dyn && (D.group & 2048u);
+    // ctr[8] done; TileDesc::xmode bit 1, off: one counter for all)
+    const bool xctr = dyn && (D.xmode & 2u);
     const unsigned long long xper = (ntiles + 7) / 8, xbase = xctr ? (blockIdx.x % 8) * xper : 0;
     const unsigned long long xend = xctr ? (xbase + xper < ntiles ? xbase + xper : ntiles) : ntiles;
     unsigned* cnext = ctr + (xctr ? blockIdx.x % 8 : 0);

@@ -17,11 +17,11 @@
 #include "fft_generic.h"
 #include "fft_big.h"
 #include "stock_plan.h"
+#include "pf_route.h"
 
 namespace pf {
 
 extern thread_local std::string g_last_error;
-extern thread_local int g_variant;   // A/B selector (pffft_hip_set_variant): per calling thread
 int fail(hipError_t e, const char* what);
 #define PF_CHECK(expr)                                   \
     do {                                                 \
@@ -57,6 +57,8 @@ struct Setup {
     int n;           // complex length of the device transform
     size_t vec_scalars;  // scalars per vector: N (real) / 2N (complex)
     Kernel kernel;
+    // what runs for [direction][ordered], decided at pffft_new_setup (plan_routes); pffft_hip_describe() prints it
+    Route route[2][2];
     GenericPlan gp;
     int gthreads;
     size_t glds;
@@ -115,10 +117,6 @@ struct FcBatch { int nsig; size_t xstride, ystride; };   // signals of one pffas
 // dma_tu.hip: the LDS-DMA staged FIR block kernel (fft_dma.h); -1 when the block length has no such kernel
 int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
                    hipStream_t st, const FcBatch& fb);
-
-// mw_tu.hip: the multi-wave register-tiled configurations (fft_tiled.h TiledMwF32: 1024 threads per vector); -1 when the size
-// has none.  which: 0 = adopted, 1 .. = measured alternatives
-int launch_tiled_mw(Setup* s, const void* in, void* out, size_t batch, int dir, int ordered, hipStream_t st, int which);
 
 // tile_real_tu.hip: REAL transforms beyond LDS in two sweeps (fft_tile.h RMODE): N real points -> canonical half spectrum through a
 // work buffer of tile_rfft_work_elems(N) complex elements per vector; -1: no plan for this length / direction

@@ -203,8 +203,7 @@ static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, 
 
 // filters of up to this many taps take the wave kernel (from g_fir_wave_min on, below): beyond, the 16384-sample split kernel (fft_split.h, round 4) is faster - 800 taps 0.44 / 0.465 (wave) against
 // 0.41 / 0.46 (split), 900 taps 0.40 / 0.43 against 0.41 / 0.46, 1024 taps 0.37 / 0.39 against 0.40 / 0.45 (tools/fir_shapes.py)
-static int g_fir_wave_max = [] { const char* e = getenv("PFFASTCONV_HIP_WAVE_MAX"); return e ? atoi(e) : 850; }();
-static int g_fir_dma = [] { const char* e = getenv("PFFASTCONV_HIP_DMA"); return e ? atoi(e) : -1; }();   // -1 = default
+static const int g_fir_wave_max = dev_env("PFFASTCONV_HIP_WAVE_MAX", 850);
 
 // Internal block length for the throughput regime.  What a caller can observe of the reference's blocks is only HOW MANY
 // samples a call produces (fc_schedule); the values are those of the exact convolution whatever the block length, so
@@ -212,7 +211,7 @@ static int g_fir_dma = [] { const char* e = getenv("PFFASTCONV_HIP_DMA"); return
 // efficiency (Nfft - len + 1) / Nfft goes from ~0.5 (the reference's Nfft = 2 next_pow2(len-1), src/pffastconv.c:62-63)
 // to 0.75-0.94.  PFFASTCONV_HIP_NFFT=<n> forces a length (A/B), =0 switches this off.
 static int fc_big_nfft(const FastConv* s, long produced, int nsig) {
-    static const int forced = [] { const char* e = getenv("PFFASTCONV_HIP_NFFT"); return e ? atoi(e) : -1; }();
+    const int forced = env().fir_nfft;
     if (forced == 0) return 0;
     const int taps = s->filterLen;
     // measured table (MI355X, tools/fir_quick.py with PFFASTCONV_HIP_NFFT forced; fraction of the 8 B / sample roofline on
@@ -306,8 +305,7 @@ static int fc_launch_part(FastConv* s, const float* d_x, float* d_y, long produc
     long kchunk = ((long)nblk * fb.nsig + 2 * waves - 1) / (2 * waves);
     if (kchunk < 10 * (P - 1)) kchunk = 10 * (P - 1);
     if (kchunk < 8) kchunk = 8;
-    static const int k_env = [] { const char* e = getenv("PFFASTCONV_HIP_PART_K"); return e ? atoi(e) : 0; }();   // A/B
-    if (k_env > 0) kchunk = k_env;
+    if (dev_env("PFFASTCONV_HIP_PART_K", 0) > 0) kchunk = dev_env("PFFASTCONV_HIP_PART_K", 0);
     if (kchunk > nblk) kchunk = nblk;
     const long ntask = ((nblk + kchunk - 1) / kchunk) * fb.nsig;
     long grid = (ntask + C::T_PER_WG - 1) / C::T_PER_WG;
@@ -319,7 +317,6 @@ static int fc_launch_part(FastConv* s, const float* d_x, float* d_y, long produc
     return 0;
 }
 #endif
-static int g_fir_part = [] { const char* e = getenv("PFFASTCONV_HIP_PART"); return e ? atoi(e) : -1; }();   // -1 = default
 
 // one wavefront per 2048-sample block, step = 2048 - taps + 1 (fft_fir.h fastconv_wave_kernel): filters up to 1024 taps
 static int fc_launch_wave(FastConv* s, const float* d_x, float* d_y, long produced, int inputLen, hipStream_t st, const FcBatch& fb) {
@@ -336,8 +333,6 @@ static int fc_launch_wave(FastConv* s, const float* d_x, float* d_y, long produc
     const long waves = (long)num_cus() * per_cu * C::T_PER_WG;
     long kchunk = ((long)nblk * fb.nsig + 2 * waves - 1) / (2 * waves);   // ~2 tasks per wavefront (fc_launch_part)
     if (kchunk < 4) kchunk = 4;
-    static const int k_env = [] { const char* e = getenv("PFFASTCONV_HIP_PART_K"); return e ? atoi(e) : 0; }();   // A/B
-    if (k_env > 0) kchunk = k_env;
     if (kchunk > nblk) kchunk = nblk;
     const long ntask = ((nblk + kchunk - 1) / kchunk) * fb.nsig;
     long grid = (ntask + C::T_PER_WG - 1) / C::T_PER_WG;
@@ -353,7 +348,7 @@ static int fc_launch_wave(FastConv* s, const float* d_x, float* d_y, long produc
 // time domain or partitioned kernel -> wave kernel): 8-24 taps 0.47 / 0.50-0.52 -> 0.47-0.49 / 0.56 (a tie: the time-domain
 // kernel stays), 32 taps 0.45 / 0.49 -> 0.52 / 0.57, 64 taps 0.38 / 0.43 -> 0.52 / 0.55, 128 taps 0.25 / 0.30 -> 0.52 / 0.55,
 // 200 taps 0.31 / 0.38 -> 0.54 / 0.54, 600 taps 0.31 / 0.38 -> 0.39 / 0.47, 800 taps -> 0.35 / 0.43, 1024 taps 0.30 / 0.37 (equal).
-static int g_fir_wave_min = [] { const char* e = getenv("PFFASTCONV_HIP_WAVE_MIN"); return e ? atoi(e) : 32; }();
+static const int g_fir_wave_min = dev_env("PFFASTCONV_HIP_WAVE_MIN", 32);
 
 // Block schedule of src/pffastconv.c:156-166 / :204-210.  Returns the number of time blocks and the
 // number of outputs of the last one; *produced = value returned by pffastconv_apply (in real samples).
@@ -401,7 +396,8 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     const int nblk = mode ? 2 * nbt : nbt;
     const int Nfft = s->Nfft;
     const int step = s->cplxFactor == 2 ? ((Nfft - s->filterLen + 1) & ~1) : (Nfft - s->filterLen + 1);
-    if (mode == 0 && s->cplxFactor == 1 && g_variant == 0 && g_fir_part != 0 && s->filterLen >= g_fir_wave_min && s->filterLen <= PART_B && s->filterLen <= g_fir_wave_max && produced > 0) {
+    const AbSel sel = ab();
+    if (mode == 0 && s->cplxFactor == 1 && !sel.any() && s->filterLen >= g_fir_wave_min && s->filterLen <= PART_B && s->filterLen <= g_fir_wave_max && produced > 0) {
         // many blocks of a filter of up to 1024 taps: one wavefront per 2048-sample block, step = 2048 - taps + 1 (round 3;
         // the partitioned kernel below advances 1024 samples per block whatever the filter)
         const int wstep = (2 * PART_B - s->filterLen + 1) & ~3;
@@ -412,7 +408,7 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     }
 #ifdef PFFFT_HIP_VARIANTS
     if (mode == 0 && s->cplxFactor == 1 && s->filterLen > TD_MAX_TAPS / 4 && s->filterLen <= PART_B * PART_MAXP &&
-        (g_variant == 88 || g_fir_part > 0) && produced > 0) {
+        sel.is(AB_FIR_PARTITIONED) && produced > 0) {
         // development build: the uniformly partitioned one-wavefront-per-block kernel (fft_fir.h fastconv_part_kernel, round 2;
         // variant 88 / PFFASTCONV_HIP_PART=1 force it).  Measured (fraction of the 8 B / sample roofline, 2^26 samples / 256
         // signals of 2^20): one partition 0.30 / 0.37 - superseded by the wave kernel above, which advances by the samples the
@@ -428,18 +424,16 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         }
     }
 #endif
-    if (mode == 0 && s->cplxFactor == 1 && g_variant != 30) {
+    if (mode == 0 && s->cplxFactor == 1) {
         const int nbig = fc_big_nfft(s, produced, fb.nsig);
         if (nbig) {
             if ((rc = fc_ensure_big(s, nbig))) return rc;
             const int bstep = nbig - s->filterLen + 1;
             const int bblk = (int)(((long)produced + bstep - 1) / bstep);
             const int blast = (int)(produced - (long)(bblk - 1) * bstep);
-            // The LDS-DMA staged block kernel (fft_dma.h) where it measured faster (tools/dma_ab.py, fraction of the 8 B / sample
-            // roofline, register-staged -> DMA): Nfft 16384: 2^26 samples 0.190 -> 0.209, 256 signals x 2^20 0.204 -> 0.246;
-            // Nfft 8192: a tie (0.22-0.29 both).  Variant 97 / PFFASTCONV_HIP_DMA=1 force it, =0 switches it off (A/B).
-            const bool use_dma = g_variant == 97 || g_variant == 116 || (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && nbig == 16384)));
-            if (use_dma) {
+            // 16384-sample blocks: the LDS-DMA staged split kernel (fft_split.h; the lock-step one it replaced: development build).  Shorter
+            // internal blocks: the register-staged fused kernel (tools/dma_ab.py: a tie with the DMA kernel at Nfft 8192, 0.22-0.29 both)
+            if (nbig == 16384) {
                 rc = launch_fir_dma(s->st_big, s->d_Hc_big, d_x, d_y, bblk, bstep, inputLen, blast, st, fb);
                 if (rc != -1) return rc;
             }
@@ -453,8 +447,8 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         }
     }
     const int taps = s->cplxFactor == 2 ? (s->filterLen + 1) / 2 : s->filterLen;   // the caller's filter length
-    if (taps <= TD_MAX_TAPS && g_variant != 30 && g_variant != 81) {
-        // short real filter: time domain (variant 81 = off); the complex modes are the stride-2 sum over the float stream
+    if (taps <= TD_MAX_TAPS) {
+        // short real filter: time domain; the complex modes are the stride-2 sum over the float stream
         if (!s->d_td) {
             PF_CHECK(hipMalloc((void**)&s->d_td, sizeof(float) * s->h_td.size()));
             PF_CHECK(hipMemcpy(s->d_td, s->h_td.data(), sizeof(float) * s->h_td.size(), hipMemcpyHostToDevice));
@@ -475,30 +469,33 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         PF_CHECK(hipGetLastError());
         return 0;
     }
-    if (mode == 0 && (g_variant == 97 || g_variant == 116 || (g_variant == 0 && (g_fir_dma > 0 || (g_fir_dma < 0 && Nfft == 16384)))) &&
-        (long)nblk * fb.nsig >= 2L * num_cus()) {
+    if (mode == 0 && Nfft == 16384 && (long)nblk * fb.nsig >= 2L * num_cus()) {
         rc = launch_fir_dma(s->st, s->d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);   // many reference-sized blocks
         if (rc != -1) return rc;
     }
-    if (mode == 0 && g_variant != 30 && g_variant != 114 && g_variant != 115 && (Nfft == 8192 || Nfft == 4096)) {
+    if (mode == 0 && !sel.is(AB_FIR_FEW_16PT) && !sel.is(AB_FIR_FEW_LOCKSTEP) && (Nfft == 8192 || Nfft == 4096)) {
         // few blocks of 8192 / 4096 samples: cross-wave radix 8 / 4 + wave-local 512-point transforms (fft_split.h
-        // fastconv_split1_kernel, round 4); variant 115 = the lock-step kernel on 512 / 256 threads, 114 = on 256 / 128
+        // fastconv_split1_kernel, round 4); AB_FIR_FEW_LOCKSTEP = the lock-step kernel on 512 / 256 threads (the second route of
+        // tests/test_gpu_round4.py), AB_FIR_FEW_16PT (development build) = on 256 / 128
         rc = launch_fir_split1(s->st, s->d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, &s->d_split1_ab);
         if (rc != -1) return rc;
     }
-    if (mode == 0 && g_variant != 30) {  // one real stream: the fused one-kernel path when Nfft/2 has a tiled kernel
+    if (mode == 0) {  // one real stream: the fused one-kernel path when Nfft/2 has a tiled kernel
         switch (Nfft / 2) {
             case 512: return fc_launch_fused<FirCfg::C512>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             case 1024: return fc_launch_fused<FirCfg::C1024>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             // 2048 / 4096 points: twice the threads per block, eight points per thread (FirCfg::C*m, round 4): the stated C4 call
             // 10.9 -> 9.5 us, 2048 taps on 2^19 samples 8.8 -> 7.3 us; n = 8192 on 1024 threads measured slower (15.9 -> 17.9 us).
-            // Variant 114 = the 16-points-per-thread configurations (A/B)
             case 2048:
-                if (g_variant != 114) return fc_launch_fused<FirCfg::C2048m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-                return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+#ifdef PFFFT_HIP_VARIANTS
+                if (sel.is(AB_FIR_FEW_16PT)) return fc_launch_fused<FirCfg::C2048>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+#endif
+                return fc_launch_fused<FirCfg::C2048m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             case 4096:
-                if (g_variant != 114) return fc_launch_fused<FirCfg::C4096m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
-                return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+#ifdef PFFFT_HIP_VARIANTS
+                if (sel.is(AB_FIR_FEW_16PT)) return fc_launch_fused<FirCfg::C4096>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
+#endif
+                return fc_launch_fused<FirCfg::C4096m>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             case 8192: return fc_launch_fused<FirCfg::C8192>(s, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);
             default: break;
         }

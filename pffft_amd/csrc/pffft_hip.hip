@@ -42,7 +42,28 @@ constexpr bool PF_HAS_VARIANTS = false;
 // error plumbing
 // ------------------------------------------------------------------------------------------------
 thread_local std::string g_last_error;
-thread_local int g_variant = 0;
+static thread_local int g_ab_raw = 0;   // pffft_hip_set_variant(): per calling thread
+AbSel ab() { AbSel a; a.raw = g_ab_raw; return a; }
+
+// every environment switch of the product build, read once (pf_route.h)
+const Env& env() {
+    static const Env e = [] {
+        auto num = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+        Env r;
+        r.abort_on_error = num("PFFFT_HIP_ABORT", 0) == 1;
+        r.zero_copy = num("PFFFT_HIP_NO_ZEROCOPY", 0) != 1;
+        r.oneshot = num("PFFFT_HIP_ONESHOT", 4);
+        r.c1024_rounds = num("PFFFT_HIP_C1024_ONCE", 4);
+        r.tile_plans = num("PFFFT_HIP_TILE_PLANS", 1);
+        r.tile_force = getenv("PFFFT_HIP_TILE_FORCE");
+        r.fir_nfft = num("PFFASTCONV_HIP_NFFT", -1);
+        r.fir_xcd = num("PFFASTCONV_HIP_XCD", 1);
+        if (r.oneshot < 0) r.oneshot = 0;
+        if (r.c1024_rounds < 0) r.c1024_rounds = 0;
+        return r;
+    }();
+    return e;
+}
 
 int fail(hipError_t e, const char* what) {
     char buf[512];
@@ -59,10 +80,7 @@ int fail(hipError_t e, const char* what) {
 // nothing: the vector length would have to be read from the very object that failed validation.
 // PFFFT_HIP_ABORT=1 restores fail-fast (abort()).
 static std::atomic<unsigned> g_error_count{0};
-static bool abort_on_error() {
-    static const bool v = [] { const char* e = getenv("PFFFT_HIP_ABORT"); return e && e[0] == '1'; }();
-    return v;
-}
+static bool abort_on_error() { return env().abort_on_error; }
 static void legacy_fatal(int code, const char* entry, void* out, size_t out_bytes, bool out_is_host) {
     const unsigned nth = g_error_count.fetch_add(1);
     const unsigned seq = nth + 1;
@@ -127,6 +145,7 @@ static void aligned_free64(void* p) {
 // ------------------------------------------------------------------------------------------------
 
 static void destroy_setup(Setup* s);
+static void plan_routes(Setup* s);
 
 // does the canonical forward transform of this (sub-)setup run on one of the fast kernels: register-tiled power-of-two
 // sizes, or a Stockham plan that exists as a compile-time constant (the run-time-plan twin runs at 0.3)
@@ -268,6 +287,14 @@ static Setup* new_setup(int N, int transform, int is_double) {
         destroy_setup(s);
         return nullptr;
     }
+    plan_routes(s);       // what runs for every (direction, layout): decided here, printed by pffft_hip_describe()
+    for (int d = 0; d < 2; ++d)
+        for (int o = 0; o < 2; ++o)
+            if (s->route[d][o].fam == FAM_NONE) {
+                g_last_error = "pffft_hip: no kernel plan for this size";
+                destroy_setup(s);
+                return nullptr;
+            }
     return s;
 }
 
@@ -470,26 +497,18 @@ static int launch_c1024_once(Setup* s, const float* in, float* out, size_t batch
     return 0;
 }
 
-static int launch_c1024(Setup* s, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st) {
-    // short launches: one transform per wavefront in dispatch order (fft_c1024.h once kernel) up to `rounds` resident sets of
-    // 16 wavefronts per CU; PFFFT_HIP_C1024_ONCE="W,rounds" (A/B; rounds 0 = always the loop)
-    static const std::pair<int, int> once = [] {
-        int w = 4, r = 4;
-        const char* e = getenv("PFFFT_HIP_C1024_ONCE");
-        if (e) sscanf(e, "%d,%d", &w, &r);
-        return std::make_pair(w, r);
-    }();
-    if (g_variant == 0 && once.second > 0 && batch <= (size_t)once.second * 16 * (size_t)num_cus()) {
-        if (once.first == 2) return launch_c1024_once<2>(s, in, out, batch, dir, ordered, st);
-        if (once.first == 8) return launch_c1024_once<8>(s, in, out, batch, dir, ordered, st);
-        return launch_c1024_once<4>(s, in, out, batch, dir, ordered, st);
-    }
+// resident wavefronts per CU of the short-launch kernel: 4 workgroups x C1024_ONCE_W wavefronts (35 KiB of LDS and 84 VGPRs each)
+constexpr int C1024_ONCE_W = 4, C1024_ONCE_RESIDENT = 16;
+
+static int launch_c1024(Setup* s, const Route& r, const float* in, float* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    // Short launches - up to r.oneshot resident sets of 16 wavefronts per CU - run one transform per wavefront in dispatch order
+    // (fft_c1024.h once kernel; tools/r5_c1024_batch.py, us per launch, loop -> once: batch 2^10 12.5 -> 7.7, 2^11 19.3 -> 8.2, 2^12 24.1 -> 14.0,
+    // 2^13 34.8 -> 27.6, 2^14 55.2 -> 50.8; from 2^15 on the loop wins: 96 against 99 us; 2- and 8-wavefront workgroups within 1 us of these).
+    if (r.oneshot > 0 && batch <= (size_t)r.oneshot * C1024_ONCE_RESIDENT * (size_t)num_cus())
+        return launch_c1024_once<C1024_ONCE_W>(s, in, out, batch, dir, ordered, st);
+    // the persistent in-order loop: ONE 8-wavefront workgroup per CU (two per CU measured 2^12 .. 2^17 10-50 % slower, 2^18 on equal)
     const unsigned wgs_needed = (unsigned)((batch + C1024_WAVES - 1) / C1024_WAVES);
-    // variants (bench A/B only): 0 = dynamic in-order, 1 WG/CU (default); 3 = dynamic, 2 WG/CU;
-    // 2 = static persistent assignment, 2 WG/CU
-    const bool dyn = g_variant != 2;
-    static const int loop_wgs = [] { const char* e = getenv("PFFFT_HIP_C1024_WGS"); return e ? atoi(e) : 1; }();   // A/B: workgroups per CU
-    unsigned grid = (unsigned)num_cus() * ((g_variant == 2 || g_variant == 3) ? 2 : loop_wgs);
+    unsigned grid = (unsigned)num_cus();
     if (grid > wgs_needed) grid = wgs_needed;
     const dim3 blk(C1024_WAVES * 64);
     const size_t lds = C1024_LDS_BYTES;
@@ -498,17 +517,10 @@ static int launch_c1024(Setup* s, const float* in, float* out, size_t batch, int
     unsigned* ctr = take_counters(s, st);
 #define PF_LAUNCH_C1024(D, I, O)                                                                      \
     do {                                                                                              \
-        if (dyn) {                                                                                    \
-            auto k = fft_c1024_f32_dyn_kernel<D, I, O>;                                               \
-            int rc = allow_big_lds(k, lds);                                                           \
-            if (rc) return rc;                                                                        \
-            hipLaunchKernelGGL(k, dim3(grid), blk, lds, st, in, out, b, tw, ctr);                     \
-        } else {                                                                                      \
-            auto k = fft_c1024_f32_kernel<D, I, O>;                                                   \
-            int rc = allow_big_lds(k, lds);                                                           \
-            if (rc) return rc;                                                                        \
-            hipLaunchKernelGGL(k, dim3(grid), blk, lds, st, in, out, b, tw);                          \
-        }                                                                                             \
+        auto k = fft_c1024_f32_dyn_kernel<D, I, O>;                                                   \
+        int rc = allow_big_lds(k, lds);                                                               \
+        if (rc) return rc;                                                                            \
+        hipLaunchKernelGGL(k, dim3(grid), blk, lds, st, in, out, b, tw, ctr);                         \
     } while (0)
     if (dir == PFFFT_FORWARD) {
         if (ordered) PF_LAUNCH_C1024(FWD, 0, 0); else PF_LAUNCH_C1024(FWD, 0, 1);
@@ -557,272 +569,215 @@ static int launch_c1024_mix(Setup* s, const float* in, float* out, size_t batch,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// register-tiled power-of-two family (fft_tiled.h): which configuration serves (n, direction, transform, layout)
+// ------------------------------------------------------------------------------------------------
 template <typename T>
-struct TiledEntry {
-    void (*fn)(const T*, T*, unsigned, int, const cx<T>*, const cx<T>*, unsigned*);
-    size_t lds;
-    int wg, t_per_wg;
-};
+using TiledFn = void (*)(const T*, T*, unsigned, int, const cx<T>*, const cx<T>*, unsigned*);
+
 template <typename T, class C>
-static TiledEntry<T> tiled_entry(int dir, int real) {
-    TiledEntry<T> e;
-    e.lds = C::LDS_BYTES; e.wg = C::WG_THREADS; e.t_per_wg = C::T_PER_WG;
-    if (dir == PFFFT_FORWARD) e.fn = real ? fft_tiled_kernel<C, FWD, 1> : fft_tiled_kernel<C, FWD, 0>;
-    else e.fn = real ? fft_tiled_kernel<C, BWD, 1> : fft_tiled_kernel<C, BWD, 0>;
+static TiledSel tiled_sel(int dir, int real, const char* name) {
+    TiledSel e;
+    e.lds = C::LDS_BYTES; e.wg = C::WG_THREADS; e.t_per_wg = C::T_PER_WG; e.cfg = name;
+    TiledFn<T> fn;
+    if (dir == PFFFT_FORWARD) fn = real ? fft_tiled_kernel<C, FWD, 1> : fft_tiled_kernel<C, FWD, 0>;
+    else fn = real ? fft_tiled_kernel<C, BWD, 1> : fft_tiled_kernel<C, BWD, 0>;
+    e.fn = reinterpret_cast<const void*>(fn);
     return e;
 }
+#define PF_TSEL(C) tiled_sel<T, C>(dir, real, #C)
+#define PF_TSELP(C) tiled_sel<T, typename TiledPick<T>::C>(dir, real, "TiledPick::" #C)
+
+// A measured table.  Constraint: both layouts of a direction share one configuration wherever the configurations differ in their twiddle
+// arithmetic, because pffft_transform_ordered == pffft_zreorder(pffft_transform) holds bit for bit (benchmarks/bench_pffft.c:343-349).
 template <typename T>
-static bool tiled_lookup(int n, int dir, int real, int ordered, TiledEntry<T>* e) {
-#ifdef PFFFT_HIP_VARIANTS
+static bool tiled_pick(int n, int dir, int real, int ordered, TiledSel* e) {
+    const bool fwd = dir == PFFFT_FORWARD;
     if constexpr (sizeof(T) == 4) {
-        // variant 20: no register prefetch, 128-VGPR budget, two workgroups per CU (measured alternatives of round 1)
-        if (g_variant == 20) {
-            switch (n) {
-                case 2048: *e = tiled_entry<T, TiledAltF32::C2048>(dir, real); return true;
-                case 4096: *e = tiled_entry<T, TiledAltF32::C4096>(dir, real); return true;
-                case 8192: *e = tiled_entry<T, TiledAltF32::C8192>(dir, real); return true;
-            }
-        }
-    }
-#endif
-    if constexpr (sizeof(T) == 4) {
-        // Routing re-measured in round 3 after the packed-arithmetic change (tools/route_ab.py, 1 GiB per launch, 10 + 20
-        // launches, sum of both layouts of a direction; both layouts of a direction share one configuration):
-        //   n = 8192: real forward (C3) three-stage T8192np 0.657 / 0.706; complex forward runs the Stockham plan (0.70 / 0.76
-        //             against 0.68 / 0.68), complex backward the four-stage TiledPick (0.77 / 0.71 against 0.70 / 0.70)
-        //   n = 4096: forward three-stage (complex 0.72 / 0.73 against 0.69 / 0.71; real N = 8192 0.66 / 0.71 against 0.59 / 0.66),
-        //             backward the four-stage TiledPick (complex 0.79 / 0.74 against 0.73 / 0.73; real 0.70 / 0.71 against 0.71 / 0.66)
-        //   n = 2048: complex forward three-stage, one wavefront per transform (0.76 / 0.76 against 0.75 / 0.74); complex backward
-        //             and real (N = 4096) the four-stage TiledPick (0.81 / 0.76 against 0.75 / 0.76; real 0.64 / 0.70 / 0.72 / 0.72
-        //             against 0.65 / 0.66 / 0.64 / 0.61)
-        if (n == 8192 && g_variant == 0 && real && dir == PFFFT_FORWARD) { *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real); return true; }
-        if (g_variant == 0 && n == 2048 && !real && dir == PFFFT_FORWARD) { *e = tiled_entry<T, TiledAltF32b::T2048>(dir, real); return true; }
-        if (g_variant == 0 && n == 4096 && dir == PFFFT_FORWARD) {   // (backward, real too: TiledPick 0.70 / 0.71 against 0.71 / 0.66)
-            const bool pf = !real && ordered;
-            *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real);
+        // round 3, after the packed-arithmetic change (tools/route_ab.py, 1 GiB per launch, sum of both layouts of a direction):
+        //   n = 8192: real forward (C3) three-stage T8192np 0.657 / 0.706; complex forward runs the Stockham plan (0.70 / 0.76 against
+        //             0.68 / 0.68), complex backward the four-stage TiledPick (0.77 / 0.71 against 0.70 / 0.70)
+        //   n = 4096: forward three-stage (complex 0.72 / 0.73 against 0.69 / 0.71; real N = 8192 0.66 / 0.71 against 0.59 / 0.66), backward
+        //             the four-stage TiledPick (complex 0.79 / 0.74 against 0.73 / 0.73; real 0.70 / 0.71 against 0.71 / 0.66)
+        //   n = 2048: complex forward three-stage, one wavefront per transform (0.76 / 0.76 against 0.75 / 0.74); complex backward and real
+        //             (N = 4096) the four-stage TiledPick (0.81 / 0.76 against 0.75 / 0.76)
+        //   n = 16384: 512 threads x 32 points with the register prefetch (tools/c16k_quick.py, 1024-thread configuration -> this one):
+        //             complex fwd canonical 0.66 -> 0.69, bwd 0.63 / 0.67 -> 0.68 / 0.70, real N = 32768 bwd 0.52 / 0.59 -> 0.54 / 0.64; real
+        //             forward spills into the internal layout (0.55 -> 0.45) and stays on TiledPick
+        if (n == 8192 && real && fwd) { *e = PF_TSEL(TiledAltF32b::T8192np); return true; }
+        if (n == 2048 && !real && fwd) { *e = PF_TSEL(TiledAltF32b::T2048); return true; }
+        if (n == 4096 && fwd) {
+            *e = (!real && ordered) ? PF_TSEL(TiledAltF32b::T4096) : PF_TSEL(TiledAltF32b::T4096np);
             return true;
         }
-#ifdef PFFFT_HIP_VARIANTS
-        if (g_variant == 77 || g_variant == 78) {
-            const bool pf = g_variant == 77;
-            if (n == 2048) { *e = pf ? tiled_entry<T, TiledAltF32b::T2048>(dir, real) : tiled_entry<T, TiledAltF32b::T2048np>(dir, real); return true; }
-            if (n == 4096) { *e = pf ? tiled_entry<T, TiledAltF32b::T4096>(dir, real) : tiled_entry<T, TiledAltF32b::T4096np>(dir, real); return true; }
-        }
-#endif
-        // n = 16384: 512 threads x 32 points with the register prefetch (tools/c16k_quick.py, fraction of 8 TB/s on 4 GiB,
-        // 1024-thread configuration -> this one): complex fwd canonical 0.66 -> 0.69, bwd 0.63 / 0.67 -> 0.68 / 0.70, real
-        // N = 32768 bwd 0.52 / 0.59 -> 0.54 / 0.64; real forward spills into the internal layout (0.55 -> 0.45) and stays.
-        // Both layouts of a direction share one configuration (ordered == zreorder(unordered) bit for bit).
-        if (n == 16384 && g_variant == 0 && (!real || dir == PFFFT_BACKWARD)) { *e = tiled_entry<T, TiledAltF32b::T16384>(dir, real); return true; }
-#ifdef PFFFT_HIP_VARIANTS
-        if (n == 16384 && g_variant == 83) { *e = tiled_entry<T, TiledAltF32b::T16384>(dir, real); return true; }
-        if (n == 16384 && g_variant == 84) { *e = tiled_entry<T, TiledAltF32b::T16384np>(dir, real); return true; }
-        if (n == 16384 && g_variant == 85) { *e = tiled_entry<T, TiledAltF32b::T16384b>(dir, real); return true; }
-        if (n == 8192 && g_variant == 79) { *e = tiled_entry<T, TiledAltF32b::T8192np0>(dir, real); return true; }
-        if (n == 8192 && g_variant == 75) { *e = tiled_entry<T, TiledAltF32b::T8192>(dir, real); return true; }
-        if (n == 8192 && g_variant == 76) { *e = tiled_entry<T, TiledAltF32b::T8192np>(dir, real); return true; }
-#endif
+        if (n == 16384 && (!real || !fwd)) { *e = PF_TSEL(TiledAltF32b::T16384); return true; }
     }
     if constexpr (sizeof(T) == 8) {
-        // alt: 0 = TiledPick, 1 = A (register base twiddles), 2 = B (prefetch), 3 = C (both); fft_tiled.h TiledAltF64
-        int alt = (g_variant >= 70 && g_variant <= 72) ? g_variant - 69 : 0;
-        if (g_variant == 0) {
-            // Selection from tools/c5_ab.py on MI355X (gpurun_out/c5_ab*.log).  Constraint: both layouts of one direction
-            // must share the twiddle arithmetic (A and C recompute powers, pick and B read tables), because
-            // transform_ordered == zreorder(transform) holds bit for bit (benchmarks/bench_pffft.c:343-349).
-            const bool fwd = dir == PFFFT_FORWARD;
-            if (n == 1024) alt = (real && fwd) ? 1 : 3;
-            else if (n == 512) alt = (real && fwd && !ordered) ? 1 : 3;
-            else if (n == 256) alt = !real ? (fwd ? 1 : 3) : (fwd ? 0 : 3);
-            else if (n == 128) alt = (real && !fwd) ? 3 : 0;
-            // 2048 / 4096: these variants beat the Stockham kernel that had taken double >= 2048 over (0.65-0.73 -> 0.70-0.80)
-            else if (n == 2048) alt = (real && fwd && !ordered) ? 1 : 3;
-            else if (n == 4096) alt = !real ? ((!fwd && ordered) ? 1 : 3) : ((fwd && !ordered) ? 1 : 3);
-        }
-#ifdef PFFFT_HIP_VARIANTS
-#define PF_ALT64_B(N) if (alt == 2) { *e = tiled_entry<T, TiledAltF64::B##N>(dir, real); return true; }
-#else
-#define PF_ALT64_B(N)
-#endif
+        // alt: 0 = TiledPick, 1 = A (register base twiddles), 3 = C (A + prefetch); fft_tiled.h TiledAltF64.  tools/c5_ab.py on MI355X;
+        // 2048 / 4096: these beat the Stockham kernel that had taken double >= 2048 over (0.65-0.73 -> 0.70-0.80)
+        int alt = 0;
+        if (n == 1024) alt = (real && fwd) ? 1 : 3;
+        else if (n == 512) alt = (real && fwd && !ordered) ? 1 : 3;
+        else if (n == 256) alt = !real ? (fwd ? 1 : 3) : (fwd ? 0 : 3);
+        else if (n == 128) alt = (real && !fwd) ? 3 : 0;
+        else if (n == 2048) alt = (real && fwd && !ordered) ? 1 : 3;
+        else if (n == 4096) alt = !real ? ((!fwd && ordered) ? 1 : 3) : ((fwd && !ordered) ? 1 : 3);
 #define PF_ALT64(N)                                                                   \
         case N:                                                                       \
-            if (alt == 1) { *e = tiled_entry<T, TiledAltF64::A##N>(dir, real); return true; } \
-            PF_ALT64_B(N)                                                             \
-            if (alt == 3) { *e = tiled_entry<T, TiledAltF64::C##N>(dir, real); return true; } \
+            if (alt == 1) { *e = PF_TSEL(TiledAltF64::A##N); return true; }           \
+            if (alt == 3) { *e = PF_TSEL(TiledAltF64::C##N); return true; }           \
             break;
         switch (n) { PF_ALT64(128) PF_ALT64(256) PF_ALT64(512) PF_ALT64(1024) PF_ALT64(2048) PF_ALT64(4096) }
 #undef PF_ALT64
-#undef PF_ALT64_B
     }
     switch (n) {
-        case 16: *e = tiled_entry<T, typename TiledPick<T>::C16>(dir, real); return true;
-        case 32: *e = tiled_entry<T, typename TiledPick<T>::C32>(dir, real); return true;
-        case 64: *e = tiled_entry<T, typename TiledPick<T>::C64>(dir, real); return true;
-        case 128: *e = tiled_entry<T, typename TiledPick<T>::C128>(dir, real); return true;
-        case 256: *e = tiled_entry<T, typename TiledPick<T>::C256>(dir, real); return true;
-        case 512: *e = tiled_entry<T, typename TiledPick<T>::C512>(dir, real); return true;
-        case 1024: *e = tiled_entry<T, typename TiledPick<T>::C1024>(dir, real); return true;
-        case 2048: *e = tiled_entry<T, typename TiledPick<T>::C2048>(dir, real); return true;
-        case 4096: *e = tiled_entry<T, typename TiledPick<T>::C4096>(dir, real); return true;
-        case 8192: *e = tiled_entry<T, typename TiledPick<T>::C8192>(dir, real); return true;
-        case 16384: *e = tiled_entry<T, typename TiledPick<T>::C16384>(dir, real); return true;
+        case 16: *e = PF_TSELP(C16); return true;
+        case 32: *e = PF_TSELP(C32); return true;
+        case 64: *e = PF_TSELP(C64); return true;
+        case 128: *e = PF_TSELP(C128); return true;
+        case 256: *e = PF_TSELP(C256); return true;
+        case 512: *e = PF_TSELP(C512); return true;
+        case 1024: *e = PF_TSELP(C1024); return true;
+        case 2048: *e = PF_TSELP(C2048); return true;
+        case 4096: *e = PF_TSELP(C4096); return true;
+        case 8192: *e = PF_TSELP(C8192); return true;
+        case 16384: *e = PF_TSELP(C16384); return true;
     }
     return false;
 }
+#undef PF_TSEL
+#undef PF_TSELP
 
 template <typename T>
-static int launch_tiled(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
-    TiledEntry<T> e;
-    const int real = s->transform == PFFFT_REAL;
-    if (!tiled_lookup<T>(s->n, dir, real, ordered, &e)) return -1;
-    int rc = allow_big_lds(e.fn, e.lds);
+static int launch_tiled(Setup* s, const Route& r, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    const TiledSel& e = r.tiled;
+    TiledFn<T> fn = reinterpret_cast<TiledFn<T>>(const_cast<void*>(e.fn));
+    int rc = allow_big_lds(fn, e.lds);
     if (rc) return rc;
     int per_cu = 0;
-    if ((rc = cached_occupancy(reinterpret_cast<const void*>(e.fn), e.wg, e.lds, &per_cu))) return rc;
-    if (g_variant >= 10 && g_variant < 20 && per_cu > g_variant - 10 && g_variant > 10) per_cu = g_variant - 10;  // A/B: cap WGs per CU
+    if ((rc = cached_occupancy(e.fn, e.wg, e.lds, &per_cu))) return rc;
     size_t groups = (batch + e.t_per_wg - 1) / e.t_per_wg;
     size_t grid = (size_t)num_cus() * per_cu;
-    // Launches of up to FOUR groups per resident workgroup run as ONE group per workgroup in hardware dispatch order instead of the
-    // persistent in-order loop: that loop pays for itself only over a long run of groups (tools/r4_small_batch.py, us per call, persistent ->
-    // one-shot: C3's kernel at 64 / 128 MiB of vectors 46 / 72 -> 30 / 60, N = 4096 complex 44 / 69 -> 24 / 49, N = 256 at 32 MiB 25 -> 14,
-    // N = 1024 double at 64 MiB 34 -> 27; from 8 groups per workgroup on the loop wins: N = 1024 double at 256 MiB 98 against 110, C3 at 512
-    // MiB 197 against 206; 1 GiB: 0.71-0.82 against 0.62-0.76).  PFFFT_HIP_TILED_ONESHOT=<k> sets the bound, 0 = always the loop (A/B)
-    static const size_t oneshot_env = [] { const char* e = getenv("PFFFT_HIP_TILED_ONESHOT"); return e ? (size_t)atol(e) : (size_t)4; }();
-    // (N = 4096 complex float alone prefers the dispatch order up to SIXTEEN groups per workgroup: 256 / 512 MiB 111 / 193 -> 91 / 178 us; every
-    //  other size measured loses there - 4096 real 104 -> 154 us at 256 MiB, 16384 complex 217 -> 283 at 512 MiB)
-    const size_t oneshot = (oneshot_env == 4 && sizeof(T) == 4 && s->n == 4096 && !real) ? (size_t)16 : oneshot_env;
-    if (oneshot && groups <= oneshot * grid && groups < 0x7fffffffull) grid = groups;
+    // LR_INORDER: launches of up to r.oneshot groups per resident workgroup run as ONE group per workgroup in hardware dispatch order instead of
+    // the persistent in-order loop, which pays for itself only over a long run of groups (tools/r4_small_batch.py, us per call, loop ->
+    // dispatch order: C3's kernel at 64 / 128 MiB of vectors 46 / 72 -> 30 / 60, N = 4096 complex 44 / 69 -> 24 / 49, N = 256 at 32 MiB 25 -> 14,
+    // N = 1024 double at 64 MiB 34 -> 27; from 8 groups per workgroup on the loop wins: N = 1024 double at 256 MiB 98 against 110)
+    if (r.oneshot > 0 && groups <= (size_t)r.oneshot * grid && groups < 0x7fffffffull) grid = groups;
     if (grid > groups) grid = groups;
     const int flags = (((dir == PFFFT_BACKWARD) && !ordered) ? 1 : 0) | (((dir == PFFFT_FORWARD) && !ordered) ? 2 : 0);
     unsigned* ctr = groups <= grid ? nullptr : take_counters(s, st);
-    hipLaunchKernelGGL(e.fn, dim3((unsigned)grid), dim3(e.wg), e.lds, st, in, out, (unsigned)batch, flags,
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(e.wg), e.lds, st, in, out, (unsigned)batch, flags,
                        (const cx<T>*)s->d_tw, (const cx<T>*)s->d_twr, ctr);
     PF_CHECK(hipGetLastError());
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// mixed-radix Stockham plans (fft_stock.h): kernel twin, organisation and launch rule of a (direction, layout)
+// ------------------------------------------------------------------------------------------------
+// false: the product build has no kernel for this plan (a development build runs the run-time-plan kernel: r.stock.fn == nullptr)
 template <typename T>
-static int launch_stock(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
-    const bool bwd = dir == PFFFT_BACKWARD;
-    // variant 52: workgroup-phase kernel also where the wave-local one applies (A/B)
-    const bool wl = s->skw_ok && !(PF_HAS_VARIANTS && g_variant == 52);   // (its plans have run-time twins only: development build)
-    const StockPlan& sp = wl ? s->skw[bwd ? 1 : 0] : s->sk[bwd ? 1 : 0];
-    const int threads = wl ? s->skw_threads : s->sk_threads;
-    const size_t lds = stock_lds<T>(sp).total;
-    const cx<T>* twp = (const cx<T>*)(sp.twmode == 2 ? s->d_twc[bwd ? 1 : 0] : s->d_tw);
-    const int flags = ((bwd && !ordered) ? 1 : 0) | ((!bwd && !ordered) ? 2 : 0) | (bwd ? 4 : 0) |
-                      (s->transform == PFFFT_REAL ? 8 : 0);
-    const size_t groups = (batch + sp.G - 1) / sp.G;
-    // Static assignment by default: unlike the register-tiled kernels (0.64 -> 0.83 with in-order pulling) these
-    // kernels sit at ~0.6 of the roofline on latency / issue, not on the HBM access order, and the hand-over of
-    // the next chunk costs more than the ordering buys (measured: 0.63 static vs 0.54 chunked-dynamic on N = 96..800,
-    // 0.64 vs 0.56 on N = 2400, 0.68 vs 0.59 on N = 4000).  Variant 42 = chunked in-order pulling (A/B).
-    // Round 3, steady state at 1 GiB per launch (tools/scan_variant.py 42 ... steady): the workgroup-phase kernels of the LARGE
-    // complex plans - one workgroup per CU, vectors of 34 KiB and more - do gain from the order: float n = 4320 .. 5760
-    // +0.01 .. +0.04, n = 8192 forward 0.68 -> 0.77 / 0.80, n = 8640 0.65 -> 0.77, n = 9216 +0.01 .. +0.03 (n = 6000 .. 8000: -0.01 ..
-    // -0.05 with two groups per atomic, 0 .. +0.03 with one); double n = 2160 .. 4800 +0.02 .. +0.09, n = 4096 forward 0.69 -> 0.81 / 0.79.  Real
-    // transforms are neutral up to 64 KiB (their small plans lose 0.4: one atomic per 20 KiB) and stay static there.  Variant 43 =
-    // static everywhere.
+static bool plan_stock(const Setup* s, int dir, int ordered, const AbSel& sel, Route& r) {
+    const bool bwd = dir == PFFFT_BACKWARD, real = s->transform == PFFFT_REAL;
+    StockSel& k = r.stock;
+    k.wl = s->skw_ok && !(PF_HAS_VARIANTS && sel.is(AB_STOCK_WORKGROUP));   // (workgroup plans of the small sizes have run-time twins only)
+    if (!k.wl && !s->sk_ok) return false;
+    const StockPlan& sp = k.wl ? s->skw[bwd ? 1 : 0] : s->sk[bwd ? 1 : 0];
+    k.lds = stock_lds<T>(sp).total;
+    k.flags = ((bwd && !ordered) ? 1 : 0) | ((!bwd && !ordered) ? 2 : 0) | (bwd ? 4 : 0) | (real ? 8 : 0);
+    // Static stride by default: these kernels sit at ~0.6-0.75 of the roofline on latency, not on the HBM access order, and the hand-over
+    // of the next chunk costs more than the ordering buys (0.63 static against 0.54 in-order chunks on N = 96 .. 800).  The workgroup-phase
+    // kernels of the LARGE plans - one workgroup per CU - do gain from the order (round 3, 1 GiB per launch, tools/scan_variant.py): complex
+    // float n = 4320 .. 5760 +0.01 .. +0.04, n = 8192 forward 0.68 -> 0.77 / 0.80, n = 8640 0.65 -> 0.77; double n = 2160 .. 4800 +0.02 .. +0.09,
+    // n = 4096 forward 0.69 -> 0.81 / 0.79; real transforms are neutral up to 64 KiB and gain 0 .. +0.04 beyond.
     const size_t vbytes = (size_t)sp.n * sizeof(cx<T>);
     bool auto_dyn = false;
-    if (s->transform == PFFFT_COMPLEX && !wl)
-        auto_dyn = vbytes >= (sizeof(T) == 8 ? 32 : 34) * 1024;
-    else if (!wl)
-        auto_dyn = vbytes >= 65536;      // real, n = 8192 float / 4096 double and up: 0 .. +0.04
-    static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_DYN"); return e ? atoi(e) : -1; }();   // A/B: force off / on
-    const bool want_dyn = dyn_env >= 0 ? dyn_env != 0 : (g_variant == 42 || (auto_dyn && g_variant != 43));
-    // groups are pulled from the counter in chunks of K (>= 64 KiB per atomic: all workgroups hit one address),
-    // but never so large that a workgroup sees fewer than ~8 chunks
+    if (!k.wl) auto_dyn = real ? vbytes >= 65536 : vbytes >= (sizeof(T) == 8 ? 32u : 34u) * 1024u;
+    const bool dyn = sel.is(AB_INORDER_SMALL) || (auto_dyn && !sel.is(AB_STATIC_LARGE));
+    r.rule = dyn ? LR_INORDER : LR_STATIC;
+    r.oneshot = dyn ? env().oneshot : 0;
+    // the kernel body instantiated on this very plan as a compile-time constant; per plan, direction and layout either the deposit
+    // variant or the direct first stage (operands straight from HBM into registers, fft_stock.h sk_df_body) is adopted from a measured
+    // table (stock_df_gen.h, tools/tune_stock_df.py): the product build instantiates the adopted one only
+    const bool rt_forced = PF_HAS_VARIANTS && sel.is(AB_STOCK_RUNTIME);
+    const bool df_ok = !(k.flags & 1) && !rt_forced;
+    const bool want_df = df_ok && (sel.is(AB_STOCK_DF_ON) ? true : sel.is(AB_STOCK_DF_OFF) ? false
+                                   : stock_df_adopted(sizeof(T) == 8, real, sp.n, (k.flags & 2) != 0, bwd));
+    auto cf = want_df ? stock_ct_lookup(sp, k.flags | 16, k.wl, (const T*)nullptr) : nullptr;
+    k.df = cf != nullptr;
+    if (!cf && !rt_forced) cf = stock_ct_lookup(sp, k.flags, k.wl, (const T*)nullptr);
+    if (!cf && !rt_forced && df_ok) { cf = stock_ct_lookup(sp, k.flags | 16, k.wl, (const T*)nullptr); k.df = cf != nullptr; }
+    k.fn = reinterpret_cast<const void*>(cf);
+    k.threads = (cf && k.df) ? sk_df_threads(sp, k.flags & 15, k.wl) : (k.wl ? s->skw_threads : s->sk_threads);
+    // grid of the static stride: groups per workgroup from the measured table (stock_grid_gen.h, tools/tune_stock_grid.py: 2-3 for the
+    // complex plans, 3-4 for the real ones, N = 384 / 768 complex float 0.71-0.75 -> 0.78-0.80) or the size rule - 16 x the resident set
+    // for vectors <= 4 KiB, 8 x up to 20 KiB, the resident set beyond (tools/stock_bench2.py: N = 96 .. 480 0.63-0.69 -> 0.71-0.77)
+    k.groups_per_wg = stock_grid_its(sizeof(T) == 8, real, sp.n);
+    k.grid_mul = vbytes <= 4096 ? 16 : vbytes <= 20480 ? 8 : 1;
+    return cf != nullptr || PF_HAS_VARIANTS;
+}
+
+template <typename T>
+static int launch_stock(Setup* s, const Route& r, const T* in, T* out, size_t batch, int dir, hipStream_t st) {
+    const StockSel& k = r.stock;
+    const bool bwd = dir == PFFFT_BACKWARD;
+    const StockPlan& sp = k.wl ? s->skw[bwd ? 1 : 0] : s->sk[bwd ? 1 : 0];
+    const cx<T>* twp = (const cx<T>*)(sp.twmode == 2 ? s->d_twc[bwd ? 1 : 0] : s->d_tw);
+    const size_t groups = (batch + sp.G - 1) / sp.G;
+    const bool dyn = r.rule == LR_INORDER;
+    // in-order groups are pulled in chunks of ONE group from 44 KiB per group on (double n = 3072 .. 4000 0.71-0.75 -> 0.78-0.82 against two),
+    // below that of as many as keep one counter address under its ~80 M atomics/s; never so large that a workgroup sees fewer than ~8 chunks
     const size_t gbytes = (size_t)sp.G * sp.n * sizeof(cx<T>);
-    // (44 000 B: ONE group per atomic from 44 KiB vectors on - measured against two: double n = 3072 .. 4000 0.71-0.75 -> 0.78-0.82,
-    //  float n = 5760 0.74 -> 0.76-0.79, n = 6000 .. 8000 0.70-0.75 -> 0.71-0.78; below that two groups keep the counter under its
-    //  ~80 M atomics/s.  PFFFT_HIP_STOCK_CHUNK=<bytes> overrides, A/B)
-    static const size_t chunk_bytes = [] { const char* e = getenv("PFFFT_HIP_STOCK_CHUNK"); return e ? (size_t)atol(e) : (size_t)44000; }();
     auto chunk_for = [&](size_t grid) -> unsigned {
-        size_t k = (chunk_bytes + gbytes - 1) / gbytes, cap = groups / (8 * grid);
-        if (k > cap) k = cap;
-        return (unsigned)(k < 1 ? 1 : (k > 64 ? 64 : k));
+        size_t kk = (44000 + gbytes - 1) / gbytes, cap = groups / (8 * grid);
+        if (kk > cap) kk = cap;
+        return (unsigned)(kk < 1 ? 1 : (kk > 64 ? 64 : kk));
     };
-    // the same kernel body instantiated on this very plan as a compile-time constant, when there is one
-    // (stock_plans_gen.h; variant 53 = always the run-time plan, A/B)
-    {
-        // direct-first-stage variant of the same plan (fft_stock.h sk_df_body) for natural-layout input
-        // (PFFFT_HIP_STOCK_DF=0/1 forces it off / on wherever it exists, A/B)
-        // adopted per plan from a measured table (stock_df_gen.h, written by tools/tune_stock_df.py on the GPU);
-        // variants 54 / 55 force it on / off at run time for that measurement
-        static const int df_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_DF"); return e ? atoi(e) : -1; }();
-        const bool rt_forced = PF_HAS_VARIANTS && g_variant == 53;   // variant 53 = always the run-time plan (development build)
-        const bool df_ok = !(flags & 1) && !rt_forced;
-        const bool want_df = df_ok && (g_variant == 54 ? true : g_variant == 55 ? false : df_env >= 0 ? df_env != 0
-                                       : stock_df_adopted(sizeof(T) == 8, (flags & 8) != 0, sp.n, (flags & 2) != 0, bwd));
-        auto cf = want_df ? stock_ct_lookup(sp, flags | 16, wl, (const T*)nullptr) : nullptr;
-        bool df = cf != nullptr;
-        if (!cf && !rt_forced) cf = stock_ct_lookup(sp, flags, wl, (const T*)nullptr);
-        // product build (no -DPFFFT_HIP_VARIANTS): one of the two twins exists per plan, whatever a selector asked for
-        if (!cf && !rt_forced && df_ok) { cf = stock_ct_lookup(sp, flags | 16, wl, (const T*)nullptr); df = cf != nullptr; }
-        if (cf) {
-            const int threads = df ? sk_df_threads(sp, flags & 15, wl) : (wl ? s->skw_threads : s->sk_threads);
-            int rc = allow_big_lds(cf, lds);
-            if (rc) return rc;
-            int per_cu = 0;
-            if ((rc = cached_occupancy(reinterpret_cast<const void*>(cf), threads, lds, &per_cu))) return rc;
-            if (g_variant > 10 && g_variant < 20 && per_cu > g_variant - 10) per_cu = g_variant - 10;  // A/B: cap WGs per CU
-            if (g_variant > 20 && g_variant < 30) per_cu = g_variant - 20;                             // A/B: force WGs per CU
-            size_t grid = (size_t)num_cus() * per_cu;
-            // Small vectors: a grid of 8x (<= 20 KiB per vector) or 16x (<= 4 KiB) the resident workgroups - still a static
-            // stride, the later workgroups start as the first ones retire - measured (tools/stock_bench2.py, fraction of
-            // 8 TB/s, 1x -> 8x / 16x): N = 96 .. 480 complex float 0.63-0.69 -> 0.71-0.77, N = 640 .. 2400 0.60-0.64 ->
-            // 0.65-0.70, real and double alike; vectors above 20 KiB lose (N = 4000: 0.62 -> 0.60) and keep exactly the
-            // resident set.  One group per workgroup (variant 94) is slower (0.32-0.66).
-            // PFFFT_HIP_STOCK_GRIDMUL=<m> overrides the factor (A/B).
-            static const int gridmul_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_GRIDMUL"); return e ? atoi(e) : 0; }();
-            // Round 4: what the static-stride kernels respond to is the number of GROUPS PER WORKGROUP, not the factor: N = 384 / 768
-            // complex float and N = 640 / 800 double peak at the same ~3-4 groups per workgroup on 0.5 GiB (16 x) and on 1 GiB (32 x)
-            // launches (0.71-0.75 -> 0.77-0.79), real transforms near 8-12, vectors of 32 KiB near 64 (tools/r4_stock_sweep.py,
-            // tools/tune_stock_grid.py).  A measured table per plan (stock_grid_gen.h: groups per workgroup) overrides the size
-            // rule where it beat it by more than the noise; the grid never drops below the resident set.  Variants 210 + k force
-            // SK_ITS[k] groups per workgroup (the tuner's knob), 200 + k the factor 2^k, 208 the size rule alone (A/B).
-            static const int SK_ITS[12] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
-            const int tab_its = stock_grid_its(sizeof(T) == 8, (flags & 8) != 0, sp.n);
-            auto by_its = [&](int its) { const size_t want = (groups + (size_t)its - 1) / (size_t)its; if (want > grid) grid = want; };
-            if (g_variant == 94) grid = groups;
-            else if (g_variant >= 200 && g_variant <= 207) grid *= (size_t)1 << (g_variant - 200);
-            else if (g_variant >= 210 && g_variant <= 221) by_its(SK_ITS[g_variant - 210]);
-            else if (gridmul_env > 0) grid *= (size_t)gridmul_env;
-            else if (tab_its > 0 && g_variant != 208) by_its(tab_its);
-            else if ((size_t)sp.n * sizeof(cx<T>) <= 4096) grid *= 16;
-            else if ((size_t)sp.n * sizeof(cx<T>) <= 20480) grid *= 8;
-            // (in-order plans: launches of up to four groups per resident workgroup as one group per workgroup - n = 8192 complex float at 32 MiB
-            //  of vectors 25 -> 16 us, launch_tiled has the rule's measurements; PFFFT_HIP_STOCK_ONESHOT=<k>, 0 = off)
-            static const size_t oneshot_env = [] { const char* e = getenv("PFFFT_HIP_STOCK_ONESHOT"); return e ? (size_t)atol(e) : (size_t)4; }();
-            if (want_dyn && oneshot_env && groups <= oneshot_env * grid) grid = groups;
-            if (grid > groups) grid = groups;
-            if (grid > 0x7fffffffu) grid = 0x7fffffffu;
-            unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : take_counters(s, st);
-            hipLaunchKernelGGL(cf, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch, twp,
-                               (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
-            PF_CHECK(hipGetLastError());
-            return 0;
+    if (k.fn) {
+        StockCtFn<T> cf = reinterpret_cast<StockCtFn<T>>(const_cast<void*>(k.fn));
+        int rc = allow_big_lds(cf, k.lds);
+        if (rc) return rc;
+        int per_cu = 0;
+        if ((rc = cached_occupancy(k.fn, k.threads, k.lds, &per_cu))) return rc;
+        size_t grid = (size_t)num_cus() * per_cu;
+        if (k.groups_per_wg > 0) {
+            const size_t want = (groups + (size_t)k.groups_per_wg - 1) / (size_t)k.groups_per_wg;
+            if (want > grid) grid = want;                       // (never below the resident set)
+        } else {
+            grid *= (size_t)k.grid_mul;
         }
+#ifdef PFFFT_HIP_VARIANTS
+        {   // the tuner's knob (tools/tune_stock_grid.py): selectors 210 + i force SK_ITS[i] groups per workgroup, 208 the size rule alone
+            static const int SK_ITS[12] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+            const int v = ab().raw;
+            if (v >= 210 && v <= 221) { grid = (size_t)num_cus() * per_cu; const size_t want = (groups + SK_ITS[v - 210] - 1) / SK_ITS[v - 210]; if (want > grid) grid = want; }
+            if (v == 208) grid = (size_t)num_cus() * per_cu * (size_t)k.grid_mul;
+        }
+#endif
+        if (dyn && r.oneshot > 0 && groups <= (size_t)r.oneshot * grid) grid = groups;   // (n = 8192 complex float at 32 MiB of vectors 25 -> 16 us)
+        if (grid > groups) grid = groups;
+        if (grid > 0x7fffffffu) grid = 0x7fffffffu;
+        unsigned* ctr = (groups <= grid || !dyn) ? nullptr : take_counters(s, st);
+        hipLaunchKernelGGL(cf, dim3((unsigned)grid), dim3(k.threads), k.lds, st, in, out, batch, twp, (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
+        PF_CHECK(hipGetLastError());
+        return 0;
     }
 #ifdef PFFFT_HIP_VARIANTS
     // the same bodies on the run-time plan (0.3 of the roofline: issue-bound).  Every legal size has a compile-time plan
-    // (tests/test_generated_sources.py), so the product build does not carry these four kernels (2 MB); variant 53 forces them here.
-    auto k = wl ? fft_stock_wl_kernel<T> : fft_stock_kernel<T>;
-    int rc = allow_big_lds(k, lds);
+    // (tests/test_generated_sources.py), so the product build does not carry these kernels (2 MB); AB_STOCK_RUNTIME forces them here.
+    auto kf = k.wl ? fft_stock_wl_kernel<T> : fft_stock_kernel<T>;
+    int rc = allow_big_lds(kf, k.lds);
     if (rc) return rc;
     int per_cu = 0;
-    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), threads, lds, &per_cu))) return rc;
-    if (g_variant >= 10 && g_variant < 20 && per_cu > g_variant - 10 && g_variant > 10) per_cu = g_variant - 10;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(kf), k.threads, k.lds, &per_cu))) return rc;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
-    unsigned* ctr = (groups <= grid || !want_dyn) ? nullptr : take_counters(s, st);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, st, in, out, batch, sp, flags, twp,
-                       (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
+    unsigned* ctr = (groups <= grid || !dyn) ? nullptr : take_counters(s, st);
+    hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(k.threads), k.lds, st, in, out, batch, sp, k.flags, twp, (const cx<T>*)s->d_twr, ctr, chunk_for(grid));
     PF_CHECK(hipGetLastError());
     return 0;
 #else
-    (void)threads; (void)lds; (void)twp; (void)want_dyn; (void)chunk_for;
+    (void)twp; (void)chunk_for;
     g_last_error = "pffft_hip: no compile-time Stockham plan for this size (product build)";
     return (int)hipErrorInvalidValue;
 #endif
@@ -911,12 +866,9 @@ static int launch_block(Setup* s, int mode, const T* in, T* out, size_t batch, h
     long long grid = (tiles + BLK_WAVES - 1) / BLK_WAVES;
     // ONE tile per wavefront in hardware dispatch order (grid = every tile): real N = 2^18 forward unordered 0.210 -> 0.224 of the
     // roofline for the whole transform, backward 0.200-0.204 -> 0.213-0.214, against persistent wavefronts on a static stride
-    // (PFFFT_HIP_BLOCK_CHUNK=0) or chunks of k consecutive tiles per wavefront (=k: 4 .. 32 measured, no better) - the order of
-    // the accesses again
-    static const int blk_k = [] { const char* e = getenv("PFFFT_HIP_BLOCK_CHUNK"); return e ? atoi(e) : 1; }();
-    int kchunk = 1;
-    if (blk_k > 0) { kchunk = blk_k; grid = (tiles + (long long)BLK_WAVES * kchunk - 1) / ((long long)BLK_WAVES * kchunk); if (grid > 0x7fffffffll) grid = 0x7fffffffll; }
-    else if (grid > (long long)num_cus() * 8) grid = (long long)num_cus() * 8;
+    // or chunks of 4 .. 32 consecutive tiles per wavefront (no better) - the order of the accesses again
+    const int kchunk = 1;
+    if (grid > 0x7fffffffll) grid = 0x7fffffffll;
     const dim3 g((unsigned)grid), b(BLK_WAVES * 64);
     switch (mode) {
         case 0: hipLaunchKernelGGL((big_block_kernel<T, 0>), g, b, 0, st, in, out, (long long)batch, n, kchunk); break;
@@ -964,115 +916,131 @@ static int scratch_grow(Setup* s, Setup::Scratch& sc, int i, size_t bytes) {
     return 0;
 }
 
-// n beyond LDS: canonical complex four-step through two HBM work buffers, with the real pair pass and the
-// internal layout composed around it (fft_big.h)
+// ------------------------------------------------------------------------------------------------
+// n beyond LDS: the sweeps over HBM of a (direction, layout), planned once (BigPlan), executed by launch_big
+// ------------------------------------------------------------------------------------------------
+static void plan_big(const Setup* s, int dir, int ordered, const AbSel& sel, BigPlan& b) {
+    const bool real = s->transform == PFFFT_REAL, fwd = dir == PFFFT_FORWARD, dbl = s->is_double != 0;
+    const bool strided = sel.is(AB_BIG_STRIDED), no_tiles = strided || sel.is(AB_BIG_NO_TILES);
+    b = BigPlan();
+    // real forward into the canonical spectrum in TWO sweeps where they measured faster (tile_real_tu.hip RMODE; AB_RFFT_THREE = always the
+    // complex core + pair sweep, AB_RFFT_TWO = two sweeps wherever the length splits).  Ordered and unordered take the SAME route -
+    // pffft_transform_ordered == pffft_zreorder(pffft_transform) bit for bit -: the unordered spectrum is the canonical one of the two
+    // sweeps through the one-sweep permutation big_block_kernel<5>
+    if (real && fwd && !sel.is(AB_RFFT_THREE) && !no_tiles && tile_rfft_has_plan(2LL * s->n, dbl, !sel.is(AB_RFFT_TWO))) {
+        b.core = BIG_RFFT2;
+        b.post = ordered ? -1 : 5;
+        b.sweeps = ordered ? 2 : 3;
+        return;
+    }
+    const bool blk = !sel.is(AB_BIG_SEPARATE_SWEEPS), fuse_ok = !sel.is(AB_BIG_SEPARATE_LAYOUT);
+    // two (three beyond 2^20) tile passes: power-of-two n and the n whose odd part splits over two tile lengths (tile_tu.hip)
+    // (deep: the row length of the streaming route is itself beyond LDS, or there is no streaming plan - five sweeps)
+    const bool deep = !s->bigR || !s->sub || s->sub->kernel == K_BIG;
+    b.tmode = deep ? 1 : real ? 2 : 0;
+    bool tiled = !no_tiles && tile_has_plan(s->n, dbl, b.tmode);
+    const int tlay = tiled ? tile_plan_layouts(s->n, dbl, b.tmode) : 0;
+    // a complex plan with a run-time tile pass that cannot carry the internal layout costs two passes + a reorder sweep against the three
+    // streaming passes, which fuse it (measured 0.13-0.15 against 0.18-0.24) - and ordered / unordered must run the SAME arithmetic:
+    // such a plan is used for both layouts or for none; it stays where the streaming route would take five sweeps (deep)
+    if (tiled && !real && !deep && s->bigR && tlay != 3) tiled = false;
+    // backward from the internal layout: the first tile pass / the column pass of the streaming route (R a multiple of 4) reads it itself
+    b.fuse_in = !fwd && !ordered && !real && tiled && (tlay & 2) && fuse_ok;
+    b.col_in = !fwd && !ordered && !real && !tiled && s->bigR && s->bigR % 4 == 0 && !strided && fuse_ok;
+    if (!b.fuse_in && !b.col_in) {
+        if (!fwd && !ordered) b.pre = real ? 3 : 1;      // internal -> canonical (complex) / -> packed spectrum of the inverse (real)
+        else if (!fwd && real) b.pre = 4;                // canonical half-complex spectrum -> packed spectrum
+        b.pre_separate = b.pre >= 0 && !blk;
+    }
+    if (tiled) {
+        b.core = BIG_TILES;
+        b.fuse_out = fwd && !ordered && !real && (tlay & 1) && fuse_ok;      // the last tile pass stores the internal layout
+        b.sweeps = tile_plan_lengths(s->n, dbl, b.tmode, b.lens);
+    } else if (s->bigR && !strided) {
+        b.core = BIG_STREAM;
+        b.fuse_out = fwd && !ordered && !real && fuse_ok;                    // the transpose pass stores it
+        b.lens[0] = s->bigR; b.lens[1] = s->sub->n;
+        b.sweeps = s->sub->kernel == K_BIG ? 5 : 3;
+    } else {
+        b.core = BIG_STRIDED;
+        b.lens[0] = s->bigp[0].n; b.lens[1] = s->bigp[1].n;
+        b.sweeps = 2;
+    }
+    if (fwd && !ordered && !b.fuse_out) { b.post = real ? 2 : 0; b.post_separate = !blk; }   // (real: pair pass +) canonical -> internal
+    else if (fwd && real) b.pair_after = true;                                                 // real forward ordered: in-place pair pass
+    b.sweeps += (b.pre >= 0 ? (b.pre_separate && b.pre != 1 ? 2 : 1) : 0) + (b.post >= 0 ? (b.post_separate && b.post == 2 ? 2 : 1) : 0) + (b.pair_after ? 1 : 0);
+}
+
 template <typename T>
-static int launch_big(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+static int launch_big(Setup* s, const Route& r, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
+    const BigPlan& b = r.big;
     size_t bytes = batch * (size_t)s->n * sizeof(cx<T>);
-    // real forward into the canonical spectrum, power-of-two N = 2^16 .. 2^20: two sweeps where they measured faster
-    // (tile_real_tu.hip; variant 121 = always the three sweeps - complex transform + pair sweep -, 122 = two sweeps wherever the
-    // length splits, A/B and tests).  Its work rows (k1 <= N1/2, whole row tiles) need a little more than n.
-    // (ordered and unordered take the SAME route: pffft_transform_ordered == pffft_zreorder(pffft_transform) bit for bit - the unordered
-    //  spectrum is the canonical one of the two sweeps through the one-sweep permutation big_block_kernel<5>)
-    const bool rfft2 = s->transform == PFFFT_REAL && dir == PFFFT_FORWARD && g_variant != 121 && g_variant != 80 &&
-                       g_variant != 82 && tile_rfft_has_plan(2LL * s->n, s->is_double != 0, g_variant != 122);
-    if (rfft2) bytes = std::max(bytes, batch * tile_rfft_work_elems(2LL * s->n, s->is_double != 0) * sizeof(cx<T>));
+    // (the work rows of the real two-sweep route - k1 <= N1/2, whole row tiles - need a little more than n)
+    if (b.core == BIG_RFFT2) bytes = std::max(bytes, batch * tile_rfft_work_elems(2LL * s->n, s->is_double != 0) * sizeof(cx<T>));
     cx<T>*bufA, *bufB;
-    // big_mu is held until EVERY pass of this call is enqueued: it guards host-side enqueue only, and a second thread
-    // growing the same stream's scratch (hipFree synchronises with the device) can then never free buffers whose kernels
-    // are not yet in the stream.  Scratch of other streams is dropped once more than BIG_SCRATCH_STREAMS streams have used
-    // this setup (hipFree waits for their kernels), so idle streams do not pin 2 x batch x n x sizeof(cx) bytes each.
+    // big_mu is held until EVERY pass of this call is enqueued: it guards host-side enqueue only, and a second thread growing the same
+    // stream's scratch (hipFree synchronises with the device) can then never free buffers whose kernels are not yet in the stream
     std::lock_guard<std::mutex> lk(s->big_mu);
     {
         Setup::Scratch* scp = nullptr;
         int rcs = stream_scratch(s->big_scratch, s->scratch_clock, st, &scp);
         if (rcs) return rcs;
-        Setup::Scratch& sc = *scp;
         for (int i = 0; i < 2; ++i)
-            if ((rcs = scratch_grow(s, sc, i, bytes))) return rcs;
-        bufA = (cx<T>*)sc.buf[0];
-        bufB = (cx<T>*)sc.buf[1];
+            if ((rcs = scratch_grow(s, *scp, i, bytes))) return rcs;
+        bufA = (cx<T>*)scp->buf[0];
+        bufB = (cx<T>*)scp->buf[1];
     }
-    const bool real = s->transform == PFFFT_REAL;
-    const bool fwd = dir == PFFFT_FORWARD;
-    if (rfft2) {
-        const int r2 = launch_tile_rfft(s, in, bufB, ordered ? (void*)out : (void*)bufA, batch, 2LL * s->n, dir, st);
-        if (r2 > 0) return r2;
-        if (r2 == 0) return ordered ? 0 : launch_block<T>(s, 5, (const T*)bufA, out, batch, st);
-    }
-    // (pair pass in place: one pair per thread, every workgroup once, in dispatch order - PFFFT_HIP_PAIR_CAP=1: the persistent
-    //  grid-stride launch it replaces, A/B)
-    static const int pair_cap = [] { const char* e = getenv("PFFFT_HIP_PAIR_CAP"); return e ? atoi(e) : 0; }();
-    const size_t pair_wgs = (batch * ((size_t)s->n / 2 + 1) + 255) / 256;
-    const unsigned egrid = (unsigned)std::min<size_t>(pair_wgs, pair_cap ? (size_t)num_cus() * 16 : (size_t)0x7fffffff);
-    const cx<T>* cur = (const cx<T>*)in;
+    const bool real = s->transform == PFFFT_REAL, fwd = dir == PFFFT_FORWARD;
     int rc;
-    // variant 87: the separate sweeps (zreorder_kernel + in-place pair pass) instead of the one-sweep block kernels (A/B)
-    const bool blk = g_variant != 87;
-    // two (three beyond 2^20) tile passes: power-of-two n and the n whose odd part splits over two tile lengths (tile_tu.hip)
-    // (deep: the row length of the streaming route is itself beyond LDS, or there is no streaming plan - five sweeps)
-    const bool deep = !s->bigR || !s->sub || s->sub->kernel == K_BIG;
-    const int tmode = deep ? 1 : real ? 2 : 0;
-    bool tiled = g_variant != 80 && g_variant != 82 && tile_has_plan(s->n, s->is_double, tmode);
-    // complex backward from the internal layout on the tile passes: the first one reads the layout itself (variant 86 = off)
-    const int tlay = tiled ? tile_plan_layouts(s->n, s->is_double, tmode) : 0;
-    // a complex plan with a run-time tile pass (fft_tileg.h) cannot fuse the internal layout on that side: two passes + a reorder sweep
-    // against the three streaming passes, which fuse it (measured 0.13-0.15 against 0.18-0.24) - and ordered / unordered must run the SAME
-    // arithmetic (ordered == zreorder(unordered) bit for bit): such a plan is used for both layouts or for none.  It stays where the
-    // streaming route would take five sweeps (deep)
-    if (tiled && !real && !deep && s->bigR && tlay != 3) tiled = false;
-    const bool fuse_in = !fwd && !ordered && !real && tiled && (tlay & 2) && g_variant != 86;
-    // ... and so does the column pass of the three-pass route when R is a multiple of 4
-    const bool col_in = !fwd && !ordered && !real && !tiled && s->bigR && s->bigR % 4 == 0 && g_variant != 80 && g_variant != 86;
-    if (fuse_in || col_in) {
-    } else if (!fwd && !ordered && blk) {   // internal -> canonical (complex) / -> packed spectrum of the inverse (real), one sweep
-        if ((rc = launch_block<T>(s, real ? 3 : 1, in, (T*)bufA, batch, st))) return rc;
+    if (b.core == BIG_RFFT2) {
+        rc = launch_tile_rfft(s, in, bufB, ordered ? (void*)out : (void*)bufA, batch, 2LL * s->n, dir, st);
+        if (rc < 0) { g_last_error = "pffft_hip: the planned two-sweep real route has no kernel"; return (int)hipErrorInvalidValue; }
+        if (rc) return rc;
+        return b.post == 5 ? launch_block<T>(s, 5, (const T*)bufA, out, batch, st) : 0;
+    }
+    // in-place pair pass: one pair per thread, every workgroup once, in dispatch order
+    const size_t pair_wgs = (batch * ((size_t)s->n / 2 + 1) + 255) / 256;
+    const unsigned egrid = (unsigned)std::min<size_t>(pair_wgs, (size_t)0x7fffffff);
+    // ---- before the core
+    const cx<T>* cur = (const cx<T>*)in;
+    if (b.pre >= 0 && !b.pre_separate) {
+        if ((rc = launch_block<T>(s, b.pre, in, (T*)bufA, batch, st))) return rc;
         cur = bufA;
-    } else if (!fwd && real && blk) {   // canonical half-complex spectrum -> packed spectrum, out of place, one sweep
-        if ((rc = launch_block<T>(s, 4, in, (T*)bufA, batch, st))) return rc;
-        cur = bufA;
-    } else {
-        if (!fwd && !ordered) {  // internal -> canonical
+    } else if (b.pre >= 0) {
+        if (b.pre != 4) {     // internal -> canonical
             if ((rc = zreorder_batch<T>(s, in, (T*)bufA, batch, PFFFT_FORWARD, st))) return rc;
             cur = bufA;
         }
-        if (!fwd && real) {      // half-complex spectrum -> packed spectrum (in place, never on the caller's input)
+        if (real) {           // half-complex spectrum -> packed spectrum (in place, never on the caller's input)
             if (cur != bufA) { PF_CHECK(hipMemcpyAsync(bufA, cur, bytes, hipMemcpyDeviceToDevice, st)); cur = bufA; }
             hipLaunchKernelGGL((real_pair_kernel<T, BWD>), dim3(egrid), dim3(256), 0, st, bufA, (long long)batch, (long long)s->n);
             PF_CHECK(hipGetLastError());
         }
     }
-    cx<T>* dest = (fwd && !ordered) ? bufA : (cx<T>*)out;
-    bool done = false, out_is_internal = false;
-    if (tiled) {
-        // power-of-two sizes: two passes over HBM up to n = 2^20, three beyond; sizes with an odd part that splits over two tile
-        // lengths: two passes (fft_tile.h); variant 82 = the three-to-five-pass composition below, 83 = that only for the latter (A/B)
-        // complex forward into the internal layout: the last tile pass stores the layout itself (variant 86 = separate reorder sweep, A/B)
-        const bool fuse_int = fwd && !ordered && !real && (tlay & 1) && g_variant != 86;
-        const int trc = launch_tile_fft(s, cur, bufB, fuse_int ? (cx<T>*)out : dest, batch, (long long)s->n, dir, st, fuse_int ? 1 : fuse_in ? 2 : 0, tmode);
-        if (trc > 0) return trc;
-        if (trc < 0 && fuse_in) { g_last_error = "pffft_hip: no tile plan for this size beyond LDS"; return (int)hipErrorInvalidValue; }
-        done = trc == 0;
-        out_is_internal = done && fuse_int;
+    // ---- the core: canonical complex transform cur -> dest (or straight into `out` in the internal layout)
+    cx<T>* dest = (b.post >= 0) ? bufA : (cx<T>*)out;
+    switch (b.core) {
+        case BIG_TILES:
+            rc = launch_tile_fft(s, cur, bufB, dest, batch, (long long)s->n, dir, st, b.fuse_out ? 1 : b.fuse_in ? 2 : 0, b.tmode);
+            if (rc < 0) { g_last_error = "pffft_hip: the planned tile passes have no kernel"; return (int)hipErrorInvalidValue; }
+            if (rc) return rc;
+            break;
+        case BIG_STREAM:
+            if ((rc = big_small_factor<T>(s, cur, bufB, dest, batch, dir, st, b.fuse_out, b.col_in))) return rc;
+            break;
+        default:
+            if ((rc = launch_strided<T>(s, 0, cur, bufB, batch, dir, st))) return rc;
+            if ((rc = launch_strided<T>(s, 1, bufB, dest, batch, dir, st))) return rc;
+            break;
     }
-    if (done) {
-    } else if (s->bigR && g_variant != 80) {   // three streaming passes (fft_big.h); variant 80 = the strided kernels (A/B)
-        // complex forward into the internal layout: the transpose pass stores it (variant 86 = separate sweep)
-        const bool tint = fwd && !ordered && !real && g_variant != 86;
-        if ((rc = big_small_factor<T>(s, cur, bufB, tint ? (cx<T>*)out : dest, batch, dir, st, tint, col_in))) return rc;
-        out_is_internal = tint;
-    } else {
-        if ((rc = launch_strided<T>(s, 0, cur, bufB, batch, dir, st))) return rc;
-        if ((rc = launch_strided<T>(s, 1, bufB, dest, batch, dir, st))) return rc;
-    }
-    if (fwd && !ordered && !out_is_internal && blk)   // (real: pair pass +) canonical -> internal in one sweep
-        return launch_block<T>(s, real ? 2 : 0, (const T*)bufA, out, batch, st);
-    if (fwd && real) {
+    // ---- after the core
+    if (b.post >= 0 && !b.post_separate) return launch_block<T>(s, b.post, (const T*)bufA, out, batch, st);
+    if (b.pair_after || (b.post == 2 && b.post_separate)) {
         hipLaunchKernelGGL((real_pair_kernel<T, FWD>), dim3(egrid), dim3(256), 0, st, dest, (long long)batch, (long long)s->n);
         PF_CHECK(hipGetLastError());
     }
-    if (fwd && !ordered && !out_is_internal)     // canonical -> internal
-        if ((rc = zreorder_batch<T>(s, (const T*)bufA, out, batch, PFFFT_BACKWARD, st))) return rc;
+    if (b.post >= 0) return zreorder_batch<T>(s, (const T*)bufA, out, batch, PFFFT_BACKWARD, st);   // canonical -> internal
+    (void)fwd;
     return 0;
 }
 
@@ -1085,9 +1053,8 @@ static int launch_tiny(Setup* s, const T* in, T* out, size_t batch, int dir, int
     const size_t groups = (batch + 63) / 64;
     size_t grid = (groups + waves - 1) / waves;
     const size_t cap = (size_t)num_cus() * (LDS_MAX / lds > 8 ? 8 : LDS_MAX / lds);
-    // one group of 64 vectors per wavefront in hardware dispatch order measured faster than persistent waves with a static
-    // stride (256-byte vectors: 0.75-0.78 against 0.67-0.72; 128-byte vectors: equal); variant 93 = persistent (A/B)
-    if (grid > cap && g_variant == 93) grid = cap;
+    // (one group of 64 vectors per wavefront in hardware dispatch order: plan_route has the measurement)
+    (void)cap;
     const bool real = s->transform == PFFFT_REAL, fwd = dir == PFFFT_FORWARD;
     const cx<T>* twr = (const cx<T>*)s->d_twr;
 #define PF_TINY(D, R, I, O)                                                                                        \
@@ -1109,61 +1076,186 @@ static int launch_tiny(Setup* s, const T* in, T* out, size_t batch, int dir, int
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// the planner: one Route per (direction, layout), computed at pffft_new_setup (plan_routes) - and again, into a temporary, only for a
+// call made under a non-default A/B selector
+// ------------------------------------------------------------------------------------------------
+// power-of-two sizes where the Stockham kernel on its compile-time plan measured faster than the register-tiled one (1 GiB of vectors,
+// tools/stock_ab.py, tools/route_ab.py):
+//   float   complex n = 16: 0.46 vs 0.26, 32: 0.70 vs 0.59, 64: 0.70 vs 0.65, 128: 0.65 -> 0.71-0.74, 8192: 0.68-0.73 vs 0.62-0.70 (both directions since
+//           the large plans are pulled in order: backward 0.78 / 0.72 -> 0.77 / 0.78); real N = 32: 0.38 vs 0.26, 64: 0.66 vs 0.60, N = 128 0.66-0.69 ->
+//           0.62-0.75, N = 16384 backward 0.61-0.68 vs 0.51-0.60 (symmetric spectrum-side stage)
+//   double  complex n = 16: 0.50 vs 0.26, 32: 0.70 vs 0.48, 64: 0.69 vs 0.47, 128 / 256 0.68 -> 0.75, 2048 0.70-0.72 -> 0.75-0.77, 4096 forward
+//           0.70 -> 0.73 / 0.75, backward 0.71 -> 0.77; real N = 32: 0.42 vs 0.29, 64: 0.66 vs 0.55, 128 0.39-0.50 -> 0.66-0.76, N = 256 backward 0.70 ->
+//           0.76, N = 512 0.70-0.73 -> 0.73-0.75, N = 4096 0.69-0.72 -> 0.71-0.75, N = 8192 forward 0.68 / 0.69 -> 0.73 / 0.70
+template <typename T>
+static bool pow2_prefers_stock(int n, bool cplx, bool fwd) {
+    if (sizeof(T) == 4) return cplx ? (n <= 64 || n == 128 || n == 8192) : (n <= 64 || (n == 8192 && !fwd));
+    return cplx ? (n <= 256 || n >= 2048) : (n <= 64 || (n == 128 && !fwd) || n == 256 || n >= 2048);
+}
+
+template <typename T>
+static Route plan_route(const Setup* s, int dir, int ordered, const AbSel& sel) {
+    Route r;
+    const bool real = s->transform == PFFFT_REAL, fwd = dir == PFFFT_FORWARD;
+    // n = 16 / 32: one thread per transform (fft_tiny.h), one group of 64 vectors per wavefront in dispatch order (measured faster than
+    // persistent wavefronts on a static stride: 256-byte vectors 0.75-0.78 against 0.67-0.72)
+    if (!sel.is(AB_NO_TINY) && (s->n == 16 || (sizeof(T) == 4 && s->n == 32))) { r.fam = FAM_TINY; r.rule = LR_DISPATCH; return r; }
+    const bool stock_all = sel.is(AB_STOCK_FOR_TILED) && s->sk_ok;
+    if (sizeof(T) == 4 && s->kernel == K_C1024_F32 && !stock_all) {
+        r.fam = FAM_C1024; r.rule = LR_INORDER; r.oneshot = env().c1024_rounds;
+        return r;
+    }
+    if (s->kernel == K_TILED && !stock_all) {
+        const bool stock = s->sk_ok && pow2_prefers_stock<T>(s->n, !real, fwd);
+        if (!stock && tiled_pick<T>(s->n, dir, real ? 1 : 0, ordered, &r.tiled)) {
+            r.fam = FAM_TILED; r.rule = LR_INORDER;
+            // (N = 4096 complex float alone prefers the dispatch order up to SIXTEEN groups per workgroup: 256 / 512 MiB 111 / 193 -> 91 / 178 us; every
+            //  other size measured loses there - 4096 real 104 -> 154 us at 256 MiB, 16384 complex 217 -> 283 at 512 MiB)
+            r.oneshot = (env().oneshot == 4 && sizeof(T) == 4 && s->n == 4096 && !real) ? 16 : env().oneshot;
+            return r;
+        }
+    }
+    if (s->kernel == K_BIG) { r.fam = FAM_BIG; r.rule = LR_INORDER; plan_big(s, dir, ordered, sel, r.big); return r; }
+    if ((s->sk_ok || s->skw_ok) && plan_stock<T>(s, dir, ordered, sel, r)) { r.fam = FAM_STOCK; return r; }
+    r.fam = FAM_NONE;   // (every legal size is routed above: new_setup sends whatever has no Stockham plan to the streaming passes, K_BIG)
+    return r;
+}
+
+static void plan_routes(Setup* s) {
+    const AbSel none;
+    for (int d = 0; d < 2; ++d)
+        for (int o = 0; o < 2; ++o)
+            s->route[d][o] = s->is_double ? plan_route<double>(s, d, o, none) : plan_route<float>(s, d, o, none);
+}
+
 template <typename T>
 static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     if (!s || s->magic != MAGIC || s->is_double != (sizeof(T) == 8)) {
         g_last_error = "pffft_hip: bad setup handle";
         return (int)hipErrorInvalidHandle;
     }
+    if ((dir != PFFFT_FORWARD && dir != PFFFT_BACKWARD)) { g_last_error = "pffft_hip: bad direction"; return (int)hipErrorInvalidValue; }
     if (batch == 0) return 0;
     int rc = ensure_device<T>(s);
     if (rc) return rc;
-    if (g_variant != 91) {   // one thread per transform for the minimum sizes (fft_tiny.h); variant 91 = off
-        if (s->n == 16) return launch_tiny<T, 16>(s, in, out, batch, dir, ordered, st);
-        if constexpr (sizeof(T) == 4) { if (s->n == 32) return launch_tiny<T, 32>(s, in, out, batch, dir, ordered, st); }
-    }
-    if constexpr (sizeof(T) == 4) {
-        if (s->kernel == K_C1024_F32 && g_variant != 50 && batch < (1ull << 32))
-            return launch_c1024(s, in, out, batch, dir, ordered, st);
-    }
-    if (s->kernel == K_TILED && g_variant >= 100 && g_variant < 110 && batch < (1ull << 32)) {   // A/B: multi-wave configurations
-        const int rc2 = launch_tiled_mw(s, in, out, batch, dir, ordered, st, g_variant - 100);
-        if (rc2 != -1) return rc2;
-    }
-    if (s->kernel == K_TILED && g_variant != 50 && batch < (1ull << 32)) {
-        // power-of-two sizes where the Stockham kernel instantiated on its compile-time plan measured faster than
-        // the register-tiled one (float, 1 GiB of vectors, tools/stock_ab.py; variant 54 = always tiled):
-        //   complex n = 16: 0.46 vs 0.26, 32: 0.70 vs 0.59, 64: 0.70 vs 0.65, 4096 unordered: 0.67 vs 0.62,
-        //   8192: 0.68/0.73 vs 0.62/0.70;  real N = 32: 0.38 vs 0.26, 64: 0.66 vs 0.60, 16384: 0.61-0.68 vs 0.51-0.60 (symmetric spectrum-side stage)
-        //   double: complex n = 16: 0.50 vs 0.26, 32: 0.70 vs 0.48, 64: 0.69 vs 0.47, 2048: 0.65 vs 0.53, 4096: 0.73 vs 0.51;
-        //   real N = 32: 0.42 vs 0.29, 64: 0.66 vs 0.55, 4096: 0.63 vs 0.45, 8192: 0.67 vs 0.44; a tie from 128 to 1024
-        //   (double n = 2048 / 4096 went back to the tiled family with its TiledAltF64 variants: 0.75-0.80 vs 0.65-0.73;
-        //    only the real backward N = 8192 stays here: 0.70 / 0.73 vs 0.68 / 0.76)
-        bool stock = false;
-        if (s->sk_ok && g_variant != 54 && !(g_variant >= 70 && g_variant <= 79)) {
-            const int n = s->n;
-            const bool cplx = s->transform == PFFFT_COMPLEX;
-            const bool fw = dir == PFFFT_FORWARD;
-            // (round 3, tools/route_ab.py: float complex n = 128 0.65 -> 0.71-0.74, n = 8192 forward 0.68 -> 0.70 / 0.76; float real
-            //  N = 128 0.66 / 0.66 / 0.69 / 0.69 -> 0.62 / 0.75 / 0.73 / 0.73; double complex n = 128 / 256 0.68 -> 0.75, n = 4096 forward
-            //  0.70 -> 0.73 / 0.75; double real N = 128 0.39-0.50 -> 0.66-0.76, N = 256 backward 0.70 -> 0.76, N = 512 0.70-0.73 -> 0.73-0.75)
-            // (round 3, with the large plans pulled in order (launch_stock): float complex n = 8192 backward 0.78 / 0.72 -> 0.77 / 0.78;
-            //  double complex n = 2048 0.70-0.72 -> 0.75-0.77, n = 4096 backward 0.71 -> 0.77; double real N = 4096 0.69-0.72 ->
-            //  0.71-0.75, N = 8192 forward 0.68 / 0.69 -> 0.73 / 0.70)
-            if (sizeof(T) == 4) stock = cplx ? (n <= 64 || n == 128 || n == 8192) : (n <= 64 || (n == 8192 && !fw));
-            else stock = cplx ? (n <= 256 || n >= 2048) : (n <= 64 || (n == 128 && !fw) || n == 256 || n >= 2048);
-            (void)fw;
+    const AbSel sel = ab();
+    Route tmp;
+    const Route* r = &s->route[dir][ordered ? 1 : 0];
+    if (sel.any()) { tmp = plan_route<T>(s, dir, ordered ? 1 : 0, sel); r = &tmp; }
+    switch (r->fam) {
+        case FAM_TINY:
+            if (s->n == 16) return launch_tiny<T, 16>(s, in, out, batch, dir, ordered, st);
+            if constexpr (sizeof(T) == 4) return launch_tiny<T, 32>(s, in, out, batch, dir, ordered, st);
+            break;
+        case FAM_C1024:
+        case FAM_TILED: {
+            // (these kernels count vectors in 32 bits: longer batches go out in slices on the same stream)
+            constexpr size_t SLICE = (size_t)3 << 30;
+            for (size_t b0 = 0; b0 < batch; b0 += SLICE) {
+                const size_t nb = batch - b0 < SLICE ? batch - b0 : SLICE;
+                const T* pi = in + b0 * s->vec_scalars;
+                T* po = out + b0 * s->vec_scalars;
+                if constexpr (sizeof(T) == 4) {
+                    if (r->fam == FAM_C1024) { if ((rc = launch_c1024(s, *r, pi, po, nb, dir, ordered, st))) return rc; continue; }
+                }
+                if ((rc = launch_tiled<T>(s, *r, pi, po, nb, dir, ordered, st))) return rc;
+            }
+            return 0;
         }
-        if (!stock) return launch_tiled<T>(s, in, out, batch, dir, ordered, st);
-        return launch_stock<T>(s, in, out, batch, dir, ordered, st);
+        case FAM_STOCK: return launch_stock<T>(s, *r, in, out, batch, dir, st);
+        case FAM_BIG: return launch_big<T>(s, *r, in, out, batch, dir, ordered, st);
+        default: break;
     }
-    if (s->kernel == K_BIG) return launch_big<T>(s, in, out, batch, dir, ordered, st);
-    // variant 50 (A/B only): the Stockham kernel also for the sizes that have a tiled kernel
-    if (s->sk_ok && (s->kernel == K_GENERIC || g_variant == 50))
-        return launch_stock<T>(s, in, out, batch, dir, ordered, st);
-    // (every legal size is routed above: new_setup sends whatever has no Stockham plan to the streaming passes, K_BIG)
     g_last_error = "pffft_hip: no kernel for this size";
     return (int)hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pffft_hip_describe: the routes of a setup as text
+// ------------------------------------------------------------------------------------------------
+const char* family_name(Family f) {
+    switch (f) {
+        case FAM_TINY: return "tiny";
+        case FAM_C1024: return "c1024_f32";
+        case FAM_TILED: return "tiled";
+        case FAM_STOCK: return "stockham";
+        case FAM_BIG: return "fourstep";
+        default: return "none";
+    }
+}
+const char* launch_rule_name(LaunchRule r) {
+    switch (r) {
+        case LR_DISPATCH: return "dispatch-order";
+        case LR_STATIC: return "static-stride";
+        default: return "in-order";
+    }
+}
+static int describe_route(const Setup* s, const Route& r, char* buf, size_t len) {
+    switch (r.fam) {
+        case FAM_TINY: return snprintf(buf, len, "tiny: one thread per transform, %s", launch_rule_name(r.rule));
+        case FAM_C1024:
+            return snprintf(buf, len, "c1024_f32: loop 8 waves/wg x 1 wg/CU %s; <= %d resident sets: once kernel %d waves/wg %s",
+                            launch_rule_name(r.rule), r.oneshot, C1024_ONCE_W, launch_rule_name(LR_DISPATCH));
+        case FAM_TILED:
+            return snprintf(buf, len, "tiled: cfg %s wg %d vec/wg %d lds %zu %s oneshot<=%d groups/wg", r.tiled.cfg, r.tiled.wg, r.tiled.t_per_wg,
+                            r.tiled.lds, launch_rule_name(r.rule), r.oneshot);
+        case FAM_STOCK: {
+            char grid[48];
+            if (r.stock.groups_per_wg > 0) snprintf(grid, sizeof grid, "%d groups/wg (table)", r.stock.groups_per_wg);
+            else snprintf(grid, sizeof grid, "%d x resident set", r.stock.grid_mul);
+            return snprintf(buf, len, "stockham: %s%s%s threads %d lds %zu %s grid %s%s", r.stock.wl ? "wave-local" : "workgroup",
+                            r.stock.df ? " direct-first-stage" : " deposit", r.stock.fn ? "" : " run-time-plan", r.stock.threads, r.stock.lds,
+                            launch_rule_name(r.rule), r.rule == LR_INORDER ? "resident set" : grid,
+                            r.rule == LR_INORDER ? (r.oneshot ? " oneshot" : "") : "");
+        }
+        case FAM_BIG: {
+            const BigPlan& b = r.big;
+            char core[96];
+            switch (b.core) {
+                case BIG_RFFT2: snprintf(core, sizeof core, "real two-sweep tiles"); break;
+                case BIG_TILES:
+                    if (b.lens[2]) snprintf(core, sizeof core, "tiles %d x %d x %d (mode %d)", b.lens[0], b.lens[1], b.lens[2], b.tmode);
+                    else snprintf(core, sizeof core, "tiles %d x %d (mode %d)", b.lens[0], b.lens[1], b.tmode);
+                    break;
+                case BIG_STREAM: snprintf(core, sizeof core, "streaming %d x %d%s", b.lens[0], b.lens[1], (s->sub && s->sub->kernel == K_BIG) ? " (rows beyond LDS)" : ""); break;
+                default: snprintf(core, sizeof core, "strided %d x %d", b.lens[0], b.lens[1]); break;
+            }
+            return snprintf(buf, len, "fourstep: %s; pre %d%s fuse_in %d col_in %d fuse_out %d post %d%s pair_after %d; %d sweeps", core, b.pre,
+                            b.pre_separate ? "(separate)" : "", (int)b.fuse_in, (int)b.col_in, (int)b.fuse_out, b.post, b.post_separate ? "(separate)" : "",
+                            (int)b.pair_after, b.sweeps);
+        }
+        default: return snprintf(buf, len, "none");
+    }
+}
+// the family a SIZE is built for (pffft_hip_kernel_name); a (direction, layout) of a power of two may still run its Stockham plan
+static const char* setup_family(const Setup* s) {
+    if (!ab().is(AB_NO_TINY) && (s->n == 16 || (s->n == 32 && !s->is_double))) return "tiny";
+    switch (s->kernel) {
+        case K_C1024_F32: return "c1024_f32";
+        case K_TILED: return "tiled";
+        case K_BIG: return "fourstep";
+        // "stockham_rt": the plan has no compile-time twin and runs the run-time-plan kernel (0.3 of the roofline and less)
+        default: return s->sk_ok ? (sub_is_fast(s) ? "stockham" : "stockham_rt") : "none";
+    }
+}
+static int describe_setup(const Setup* s, char* buf, size_t len) {
+    std::string out;
+    char line[512];
+    snprintf(line, sizeof line, "pffft_hip setup N=%d %s %s: core n=%d, family %s\n", s->N, s->transform == PFFFT_REAL ? "real" : "complex",
+             s->is_double ? "f64" : "f32", s->n, setup_family(s));
+    out += line;
+    static const char* dn[2] = {"forward ", "backward"};
+    static const char* on[2] = {"unordered", "ordered  "};
+    for (int d = 0; d < 2; ++d)
+        for (int o = 1; o >= 0; --o) {
+            char body[400];
+            describe_route(s, s->route[d][o], body, sizeof body);
+            snprintf(line, sizeof line, "  %s %s: %s\n", dn[d], on[o], body);
+            out += line;
+        }
+    if (buf && len) { const size_t c = out.size() < len - 1 ? out.size() : len - 1; memcpy(buf, out.data(), c); buf[c] = 0; }
+    return (int)out.size();
 }
 
 // frequency shift (src/pf_mixer.cpp) immediately followed by the forward FFT, the usual SDR
@@ -1180,7 +1272,7 @@ static int shift_transform_batch(Setup* s, const float* in, float* out, size_t b
     int rc = ensure_device<float>(s);
     if (rc) return rc;
     const double phase_turns = phase_rad / pfmix::MIX_TWO_PI;
-    if (s->kernel == K_C1024_F32 && g_variant != 60 && batch < (1ull << 32))   // variant 60: the two-pass composition (A/B)
+    if (s->kernel == K_C1024_F32 && !ab().is(AB_AUX_DIRECT) && batch < (1ull << 32))   // AB_AUX_DIRECT: the two-pass composition (second route of the tests)
         return launch_c1024_mix(s, in, out, batch, ordered, rate, phase_turns, st);
     const double S[1][2] = {{std::cos(phase_rad), std::sin(phase_rad)}};
     rc = pfmix::launch_mix(reinterpret_cast<const float2*>(in), reinterpret_cast<float2*>(out), batch * (size_t)s->N, 1, S,
@@ -1198,8 +1290,9 @@ static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, 
     const size_t vimg = ((size_t)(s->n / 16) * BCH + 1) * 16;   // block image of one vector, bytes
     const size_t vbytes = s->vec_scalars * sizeof(T);
     // long batches of vectors <= 64 KiB: in-order streaming kernel with next-group prefetch (fft_aux.h); variant 61 = off
-    if (vbytes <= ZRD_GROUP_BYTES && batch * vbytes >= ((size_t)64 << 20) && g_variant != 60 && g_variant != 61 &&
-        g_variant != 42 && in != out) {
+    const AbSel sel = ab();
+    const bool direct = sel.is(AB_AUX_DIRECT), inorder_small = sel.is(AB_INORDER_SMALL);
+    if (vbytes <= ZRD_GROUP_BYTES && batch * vbytes >= ((size_t)64 << 20) && !direct && !sel.is(AB_AUX_NO_STREAM) && !inorder_small && in != out) {
         int rc = ensure_device<T>(s);
         if (rc) return rc;
         const int G = (int)(ZRD_GROUP_BYTES / vbytes);
@@ -1224,7 +1317,7 @@ static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, 
             return 0;
         }
     }
-    if (vimg <= 128 * 1024 && g_variant != 60 && in != out) {
+    if (vimg <= 128 * 1024 && !direct && in != out) {
         int rc = ensure_device<T>(s);
         if (rc) return rc;
         int G = (int)(16384 / vimg);
@@ -1244,7 +1337,7 @@ static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, 
         if (kc > 64) kc = 64;
         // static by default: 0.61-0.70 of the roofline against 0.47-0.62 with in-order chunks (variant 42) and
         // 0.41-0.61 for the direct kernel (tools/aux_bench.py)
-        unsigned* ctr = (kc < 1 || g_variant != 42) ? nullptr : take_counters(s, st);
+        unsigned* ctr = (kc < 1 || !inorder_small) ? nullptr : take_counters(s, st);
         if (kc < 1) kc = 1;
         const int nchk = 2 * s->n / CH;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(ZR_THREADS), lds, st, in, out, batch, s->n,
@@ -1267,6 +1360,8 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
                            int b_broadcast, hipStream_t st) {
     if (!s || s->magic != MAGIC) return (int)hipErrorInvalidHandle;
     if (batch == 0) return 0;
+    const AbSel sel = ::pf::ab();      // (`ab` is also this function's output vector)
+    const bool direct = sel.is(AB_AUX_DIRECT), inorder_small = sel.is(AB_INORDER_SMALL);
     size_t total = batch * (size_t)(s->n / 4);
     // float: streaming kernel, two pairs per thread with all loads issued first (fft_aux.h): 0.69-0.70 against 0.65-0.70
     // for the grid-stride kernel, which stays for double (0.65 vs 0.41) and as variant 60; in-order chunks (variant 42)
@@ -1274,7 +1369,7 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
     // long batches (>= 64 MiB per stream): in-order streaming kernel with DPP pair exchange (fft_aux.h); variant 61 = off
     {
         const unsigned long long Q = 2ull * total * Zd<T>::UPG;   // 16-byte units in the batch
-        if (g_variant != 60 && g_variant != 61 && g_variant != 42 && Q / Zd<T>::CHUNK >= 8192u &&
+        if (!direct && !sel.is(AB_AUX_NO_STREAM) && !inorder_small && Q / Zd<T>::CHUNK >= 8192u &&
             Q / Zd<T>::CHUNK < 0xffffffffull) {
             int rc = ensure_device<T>(s);
             if (rc) return rc;
@@ -1290,7 +1385,7 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
             return 0;
         }
     }
-    if (g_variant != 60 && sizeof(T) == 4) {
+    if (!direct && sizeof(T) == 4) {
         int rc = ensure_device<T>(s);
         if (rc) return rc;
         const size_t chunks = (total + ZC_CHUNK - 1) / ZC_CHUNK;
@@ -1298,7 +1393,7 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
         if (grid > chunks) grid = chunks;
         size_t kc = 4, cap = chunks / (8 * grid);
         if (kc > cap) kc = cap;
-        unsigned* ctr = (kc < 1 || g_variant != 42) ? nullptr : take_counters(s, st);
+        unsigned* ctr = (kc < 1 || !inorder_small) ? nullptr : take_counters(s, st);
         if (kc < 1) kc = 1;
         const int real = s->transform == PFFFT_REAL;
         if (accumulate)
@@ -1354,7 +1449,7 @@ static int convolve_batch(Setup* s, const T* in, const T* H, T* out, T scaling, 
     if (batch == 0) return 0;
     int rc = ensure_device<T>(s);
     if (rc) return rc;
-    if (h_broadcast && g_variant != 120) {
+    if (h_broadcast && !ab().is(AB_CONV_COMPOSED)) {
         rc = launch_conv_fused(s, in, H, out, batch, (double)scaling, accumulate, st);
         if (rc != -1) return rc;
     }
@@ -1414,10 +1509,7 @@ static int pinned_buf(Setup* s, int slot, size_t bytes, void** out) {
 // (measured: tools/legacy_bench.py).  Vectors above ZC_LIMIT keep the device staging (kernels there may sweep `out`
 // more than once).  PFFFT_HIP_NO_ZEROCOPY=1 switches it off (A/B).
 constexpr size_t ZC_LIMIT = 256 * 1024;
-static bool zero_copy_enabled() {
-    static const bool v = [] { const char* e = getenv("PFFFT_HIP_NO_ZEROCOPY"); return !(e && e[0] == '1'); }();
-    return v;
-}
+static bool zero_copy_enabled() { return env().zero_copy; }
 
 // run `fn(d_in..., d_out)` with up to 3 inputs + 1 output vector of `bytes` bytes each
 template <typename T, typename F>
@@ -1623,14 +1715,12 @@ PF_EXPORT int pffft_hip_shift_transform_batch(PFFFT_Setup* s, const float* in, f
 PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
     const pf::Setup* s = static_cast<const pf::Setup*>(setup);
     if (!s || s->magic != pf::MAGIC) return "invalid";
-    if (pf::g_variant != 91 && (s->n == 16 || (s->n == 32 && !s->is_double))) return "tiny";
-    switch (s->kernel) {
-        case pf::K_C1024_F32: return "c1024_f32";
-        case pf::K_TILED: return "tiled";
-        case pf::K_BIG: return "fourstep";
-        // "stockham_rt": the plan has no compile-time twin and runs the run-time-plan kernel (0.3 of the roofline and less)
-        default: return s->sk_ok ? (pf::sub_is_fast(s) ? "stockham" : "stockham_rt") : "none";
-    }
+    return pf::setup_family(s);
+}
+PF_EXPORT int pffft_hip_describe(const void* setup, char* buf, size_t len) {
+    const pf::Setup* s = static_cast<const pf::Setup*>(setup);
+    if (!s || s->magic != pf::MAGIC) { if (buf && len) buf[0] = 0; return -1; }
+    return pf::describe_setup(s, buf, len);
 }
 PF_EXPORT int pffft_hip_tile_plan(long long n, int is_double, int deep, int lengths[3]) {
     if (!lengths) return 0;
@@ -1643,7 +1733,7 @@ PF_EXPORT int pffft_hip_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
-PF_EXPORT void pffft_hip_set_variant(int v) { pf::g_variant = v; }
+PF_EXPORT void pffft_hip_set_variant(int v) { pf::g_ab_raw = v; }
 PF_EXPORT int pffft_hip_has_variants(void) {
 #ifdef PFFFT_HIP_VARIANTS
     return 1;

@@ -47,7 +47,7 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     // ... but only for tiles up to 32 KiB: steady scans over every size (profiles/r04_scan_beyond_lds_*.txt against r03's) showed the plans with
     // a 36-54 KiB column tile (L = 288 ... 432) 9-15 % SLOWER at three tiles per workgroup than on the resident set - their prefetch pipeline
     // wants a long run of tiles - and the L = 144 tiles (radix 9 first, 144 threads: columns -11 ... -15 %, rows -4 %) likewise; L = 64 ... 256 gain 7-18 %
-    static const int its_env = [] { const char* e = getenv("PFFFT_HIP_TILE_ITS"); return e ? atoi(e) : 3; }();
+    static const int its_env = dev_env("PFFFT_HIP_TILE_ITS", 3);
     const bool its_ok = (size_t)G::L * G::C * sizeof(cx<T>) <= 32 * 1024 && !(R0 == 9 && LOGL == 4);
     if (its_env > 0 && its_ok) {
         const unsigned long long want = (ntiles + its_env - 1) / its_env;
@@ -57,24 +57,24 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     // in-order tiles only where a tile is 64 KiB or more: one counter address serves ~80 M atomics/s, so 16-32 KiB tiles
     // are throttled by the grab (2^15: 0.30 static, 0.20 in order; 2^18 .. 2^20: 0.27-0.31 / 0.19 static, 0.29-0.32 / 0.24 in
     // order).  PFFFT_HIP_TILE_DYN=0/1 forces it (A/B).
-    static const int dyn_env = [] { const char* e = getenv("PFFFT_HIP_TILE_DYN"); return e ? atoi(e) : -1; }();
+    static const int dyn_env = dev_env("PFFFT_HIP_TILE_DYN", -1);
     const bool want_dyn = dyn_env >= 0 ? dyn_env != 0 : (size_t)G::L * G::C * sizeof(cx<T>) >= 60 * 1024;   // (L = 480: 60 KiB)
     // (in-order tiles: a launch of up to four tiles per resident workgroup runs one tile per workgroup in dispatch order - N = 2^18 complex at 32 MiB
-    //  of vectors 56 -> 38 us per transform, tools/r4_small_batch.py; launch_tiled has the rule's measurements.  PFFFT_HIP_TILE_ONESHOT=<k>, 0 = off)
-    static const unsigned long long oneshot_env = [] { const char* e = getenv("PFFFT_HIP_TILE_ONESHOT"); return e ? (unsigned long long)atol(e) : 4ull; }();
+    //  of vectors 56 -> 38 us per transform, tools/r4_small_batch.py; launch_tiled has the rule's measurements.  PFFFT_HIP_ONESHOT=<k>, 0 = off)
+    const unsigned long long oneshot_env = (unsigned long long)env().oneshot;
     if (want_dyn && oneshot_env && ngroups <= oneshot_env * grid) grid = ngroups;
     // XCD-aware tile order (TileDesc::xmode, round 4): PFFFT_HIP_TILE_XMODE = 0 off, 1 static map only, 2 per-XCD counters only, 3 both (A/B).
     // OFF for these kernels: their strides are whole or half lines, and measured (tools/r4_xmode.sh) the static map costs 0-4 %, the per-XCD
     // counters N = 2^20 0.20-0.23 -> 0.17-0.19 (one in-order sweep over the whole batch is what HBM rewards there); they pay only on the
     // strides of fft_tileg.h that are neither
-    static const int xmode_env = [] { const char* e = getenv("PFFFT_HIP_TILE_XMODE"); return e ? atoi(e) : 0; }();
+    static const int xmode_env = dev_env("PFFFT_HIP_TILE_XMODE", 0);
     const bool dynm = !(ngroups <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
     // (bit 2: per-XCD counters for the column passes with 64-byte runs only - adjacent tiles share every line there)
     const bool xctr = dynm && ((xmode_env & 2) || ((xmode_env & 4) && PP == 4 && D.seq_contig)) && grid % 8 == 0 && ngroups >= 64 && D.group <= 1;
     // (per-XCD counters: nine words = five {next, done} pairs of the ring, which is allocated with that much room past its end)
     unsigned* ctr = !dynm ? nullptr : take_counters(s, st, xctr ? 5 : 1);
     TileDesc D2 = D;
-    static const int cstart_env = [] { const char* e = getenv("PFFFT_HIP_TILE_CSTART"); return e ? atoi(e) : 0; }();   // A/B: start-up grabs from the counter
+    static const int cstart_env = dev_env("PFFFT_HIP_TILE_CSTART", 0);   // A/B: start-up grabs from the counter
     D2.xmode = (xctr ? 2u : 0u) | ((!dynm && (xmode_env & 1) && D.group <= 1) ? 1u : 0u) | (cstart_env ? 8u : 0u);
     if (D2.xmode & 1u) grid = (grid + 7) / 8 * 8;      // (the static map is a bijection on a grid of whole eights; the surplus workgroups retire at once)
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D2, ctr);

@@ -28,7 +28,7 @@ static int rtile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, co
     // neighbours then meet in one L2 - double N = 2^17 .. 2^20 0.226 / 0.303 / 0.273 / 0.220 -> 0.285 / 0.339 / 0.315 / 0.261, float 2^18 /
     // 2^19 0.216 / 0.227 -> 0.242 / 0.246 (tools/r4_rfft_x.py; dropping the streaming hint of those stores: no change).
     // PFFFT_HIP_RFFT_X=0: one counter (A/B)
-    static const int x_env = [] { const char* e = getenv("PFFFT_HIP_RFFT_X"); return e ? atoi(e) : 2; }();
+    static const int x_env = dev_env("PFFFT_HIP_RFFT_X", 2);
     const bool dynm = !(ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
     const bool xctr = RMODE == 2 && dynm && (x_env & 2) && grid % 8 == 0 && ntiles >= 64;
     unsigned* ctr = !dynm ? nullptr : take_counters(s, st, xctr ? 5 : 1);

@@ -11,8 +11,8 @@
 
 namespace pf {
 
-static int g_tile_pp = [] { const char* e = getenv("PFFFT_HIP_TILE_PP"); return e ? atoi(e) : 0; }();   // A/B: force 4 or 8
-static int g_tile_pf = [] { const char* e = getenv("PFFFT_HIP_TILE_PF"); return e ? atoi(e) : -1; }();  // A/B: prefetch off / on
+static int g_tile_pp = dev_env("PFFFT_HIP_TILE_PP", 0);   // A/B: force 4 or 8
+static int g_tile_pf = dev_env("PFFFT_HIP_TILE_PF", -1);  // A/B: prefetch off / on
 
 template <typename T, int PP>
 static int tile_dispatch(int logl, const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
@@ -93,11 +93,9 @@ static int pass_columns(Setup* s, const cx<T>* in, cx<T>* out, unsigned long lon
     D.vstride = tl.len() * cols;
     D.in_a = C; D.out_a = C; D.ips = cols; D.iss = 1; D.ops = cols;
     D.col_a = (unsigned)C; D.M = D.vstride; D.seq_contig = 1;
-    // 64-byte runs (L = 1024: 8 float / 4 double columns per tile): adjacent tiles in pairs per grab (TileDesc::group; TA even so that
-    // a pair never straddles two vectors) - built in round 4 against the 1.456 x traffic of this pass, measured SLOWER (N = 2^20 complex
-    // float 0.236 -> 0.211, double 0.248 -> 0.226, real 2^21 0.181 -> 0.162): off; PFFFT_HIP_TILE_GROUP=2 switches it on (A/B)
-    static const int g_env = [] { const char* e = getenv("PFFFT_HIP_TILE_GROUP"); return e ? atoi(e) : 1; }();
-    D.group = (pp == 4 && D.TA % 2 == 0 && !D.last_units && g_env == 2) ? 2u : 1u;
+    // (adjacent column tiles with 64-byte runs taken in PAIRS per grab - TileDesc::group = 2, built in round 4 against the 1.456 x traffic of
+    //  this pass - measured slower, DESIGN.md appendix A.10: one tile per grab)
+    D.group = 1u;
     const unsigned long long ntiles = nvec * D.TA;
     return tile_any<T>(tl, pp, in, out, ntiles, D, dir, st, s, false, in_int);
 }
@@ -128,10 +126,10 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
 // (ten and more wavefronts per workgroup: 168 registers); row tiles 97-127, 125-140 from L = 576.  Three streaming passes cost
 // ~285 (five ~480 where the row length of that route is itself beyond LDS): plans above that are refused.  Tile lengths with two
 // odd stages (25, 27, 45): columns 118-128 (L = 720: 176-192), rows 102-138 (L = 720: 165-169).  false: no plan - the three streaming passes of fft_big.h.
-static int g_mr_min = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMIN"); return e ? atoi(e) : 48; }();    // A/B: shortest / longest
-static int g_mr_max = [] { const char* e = getenv("PFFFT_HIP_TILE_MRMAX"); return e ? atoi(e) : 768; }();   // tile length of a plan
-static int g_wide_cost = [] { const char* e = getenv("PFFFT_HIP_TILE_WIDECOST"); return e ? atoi(e) : 340; }();   // A/B: 0 = off
-static int g_gen_cost = [] { const char* e = getenv("PFFFT_HIP_TILE_GENCOST"); return e ? atoi(e) : 1; }();   // A/B: 0 = no run-time plans
+static int g_mr_min = dev_env("PFFFT_HIP_TILE_MRMIN", 48);    // A/B: shortest / longest
+static int g_mr_max = dev_env("PFFFT_HIP_TILE_MRMAX", 768);   // tile length of a plan
+static int g_wide_cost = dev_env("PFFFT_HIP_TILE_WIDECOST", 340);   // A/B: 0 = off
+static const int g_gen_cost = env().tile_plans;   // PFFFT_HIP_TILE_PLANS=0: no run-time plans (fft_tileg.h) - those sizes take the streaming passes
 // `stride`: the element stride between the points of the pass's strided side - the column count of a column pass (loads and stores), the
 // row count (outer) of a row pass (stores).  Costs in the unit of the table above (~ us per 0.5 GiB of float vectors / 2.1), round 4,
 // N = 10800 / 11664 / 250000 / 600000 on forced plans (tools/r4_gen_force.sh):
@@ -179,7 +177,7 @@ static const std::vector<TileLen>& tile_lengths(bool is_double) {
                     if (!tile_gen_length_ok(L, dbl != 0)) continue;
                     bool have = false;
                     for (size_t i = 0; i < fixed; ++i) have = have || (long long)v[i].len() == L;
-                    static const int alt_env = [] { const char* e = getenv("PFFFT_HIP_TILE_ALT"); return e ? atoi(e) : 1; }();   // A/B: 0 = off
+                    static const int alt_env = dev_env("PFFFT_HIP_TILE_ALT", 1);   // A/B: 0 = off
                     if (!have || alt_env) v.push_back(TileLen{L, 0, true, have});
                 }
             }
@@ -190,39 +188,30 @@ static const std::vector<TileLen>& tile_lengths(bool is_double) {
 }
 static bool tile_len_ok(const TileLen& t) { return t.gen || ((long long)t.len() >= g_mr_min && (long long)t.len() <= g_mr_max); }
 
-// PFFFT_HIP_TILE_MRPLAN="R1,l1,R2,l2" forces the two tile lengths of the sizes they multiply to (A/B): read ONCE, and only
-// lengths that are instantiated are accepted (an arbitrary pair used to surface as "tile pass length out of range" after the
-// first pass had been enqueued)
-struct ForcedPlan { bool ok = false; TileLen a{1, 0}, b{1, 0}; };
-static const ForcedPlan& forced_plan() {
-    static const ForcedPlan f = [] {
-        ForcedPlan r;
-        const char* e = getenv("PFFFT_HIP_TILE_MRPLAN");
-        int r1, l1, r2, l2;
-        if (e && sscanf(e, "%d,%d,%d,%d", &r1, &l1, &r2, &l2) == 4) {
-            auto known = [](int r0, int l) {
-                for (int dbl = 0; dbl < 2; ++dbl)
-                    for (const TileLen& t : tile_lengths(dbl != 0)) if (t.r0 == r0 && t.logl == l) return true;
-                return false;
-            };
-            if (known(r1, l1) && known(r2, l2)) { r.ok = true; r.a = TileLen{r1, l1}; r.b = TileLen{r2, l2}; }
-            else fprintf(stderr, "pffft_hip: PFFFT_HIP_TILE_MRPLAN=%s names a tile length that is not instantiated: ignored\n", e);
-        }
-        return r;
-    }();
-    return f;
-}
-
 // PFFFT_HIP_TILE_FORCE="L1[g],L2[g]" (A/B): the two tile lengths by value, g = the run-time plan even where a register-tiled kernel exists
 static bool forced_lengths(long long n, bool is_double, TileLen& a, TileLen& b) {
-    static const char* e = getenv("PFFFT_HIP_TILE_FORCE");
-    if (!e) return false;
-    int l1 = 0, l2 = 0;
-    char g1 = 0, g2 = 0;
-    if (sscanf(e, "%d%c%d%c", &l1, &g1, &l2, &g2) < 3) return false;
-    const bool gen1 = g1 == 'g', gen2 = g2 == 'g';
-    if (gen1 && sscanf(e, "%dg,%d%c", &l1, &l2, &g2) < 2) return false;
-    if ((long long)l1 * l2 != n) return false;
+    // parsed once: "L1[g],L2[g]" by hand (round 4 used sscanf("%d%c%d%c"), which stops at the comma behind a leading "g": a plan like
+    // "162g,72g" was dropped silently and the production route ran in its place - ADVICE r04)
+    struct Forced { bool set = false, ok = false; int l1 = 0, l2 = 0; bool g1 = false, g2 = false; };
+    static const Forced F = [] {
+        Forced f;
+        const char* e = env().tile_force;
+        if (!e || !*e) return f;
+        f.set = true;
+        char* end = nullptr;
+        f.l1 = (int)strtol(e, &end, 10);
+        if (end == e) return f;
+        if (*end == 'g') { f.g1 = true; ++end; }
+        if (*end != ',') return f;
+        const char* p2 = end + 1;
+        f.l2 = (int)strtol(p2, &end, 10);
+        if (end == p2) return f;
+        if (*end == 'g') { f.g2 = true; ++end; }
+        f.ok = *end == 0 && f.l1 > 0 && f.l2 > 0;
+        if (!f.ok) fprintf(stderr, "pffft_hip: PFFFT_HIP_TILE_FORCE=%s is not \"L1[g],L2[g]\": ignored\n", e);
+        return f;
+    }();
+    if (!F.ok || (long long)F.l1 * F.l2 != n) return false;
     auto pick = [&](int L, bool gen, TileLen& t) {
         if (!gen)
             for (const TileLen& v : tile_lengths(is_double)) if ((long long)v.len() == L && !v.gen) { t = v; return true; }
@@ -230,7 +219,10 @@ static bool forced_lengths(long long n, bool is_double, TileLen& a, TileLen& b) 
         t = TileLen{L, 0, true};
         return true;
     };
-    return pick(l1, gen1, a) && pick(l2, gen2 || g2 == 'g', b);
+    if (pick(F.l1, F.g1, a) && pick(F.l2, F.g2, b)) return true;
+    static bool warned = false;
+    if (!warned) { warned = true; fprintf(stderr, "pffft_hip: PFFFT_HIP_TILE_FORCE=%s names a tile length without a kernel: ignored\n", env().tile_force); }
+    return false;
 }
 
 // mode: 0 = the streaming route of this size is three sweeps, complex transform; 1 = it is five (deep); 2 = three sweeps, the core of a REAL
@@ -238,12 +230,8 @@ static bool forced_lengths(long long n, bool is_double, TileLen& a, TileLen& b) 
 static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, TileLen& b) {
     const bool deep = mode == 1;
     if (forced_lengths(n, is_double, a, b)) return true;
-    {
-        const ForcedPlan& f = forced_plan();
-        if (f.ok && (long long)f.a.len() * (long long)f.b.len() == n) { a = f.a; b = f.b; return true; }
-    }
     const std::vector<TileLen>& V = tile_lengths(is_double);
-    static const int maxcost_env = [] { const char* e = getenv("PFFFT_HIP_TILE_MAXCOST"); return e ? atoi(e) : 286; }();   // A/B
+    static const int maxcost_env = dev_env("PFFFT_HIP_TILE_MAXCOST", 286);   // A/B
     // one round over the pairs of tile lengths; with_alt: lengths that have a register-tiled kernel also on their run-time plan
     auto search = [&](bool with_alt) -> bool {
         int best = deep ? 460 : maxcost_env;             // (deep: the streaming route takes five sweeps, ~480)
@@ -342,7 +330,7 @@ static bool tile_plan3(long long n, bool is_double, TileLen& a, TileLen& b, Tile
 bool tile_has_plan(long long n, bool is_double, int mode) {
     const bool deep = mode == 1;
     if (n > 0 && (n & (n - 1)) == 0) return n >= (1 << 12) && n <= (1ll << 27);
-    if (g_variant == 83) return false;                   // variant 83: the streaming passes for these sizes (A/B)
+    if (ab().is(AB_BIG_NO_MR_TILES)) return false;       // the streaming passes for these sizes (the second route of tests/test_gpu_round3.py)
     TileLen a, b, c;
     return tile_plan(n, is_double, mode, a, b) || (deep && n <= (1ll << 27) && tile_plan3(n, is_double, a, b, c));
 }
@@ -376,7 +364,7 @@ int tile_plan_lengths(long long n, bool is_double, int mode, int lengths[3]) {
         lengths[0] = 1 << l1; lengths[1] = 1 << (rem / 2); lengths[2] = 1 << (rem - rem / 2);
         return 3;
     }
-    if (g_variant == 83) return 0;
+    if (ab().is(AB_BIG_NO_MR_TILES)) return 0;
     if (tile_plan(n, is_double, mode, a, b)) { lengths[0] = (int)a.len(); lengths[1] = (int)b.len(); return 2; }
     if (deep && n <= (1ll << 27) && tile_plan3(n, is_double, a, b, c)) {
         lengths[0] = (int)a.len(); lengths[1] = (int)b.len(); lengths[2] = (int)c.len();
@@ -395,7 +383,7 @@ static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t b
     int rc;
     if (n & (n - 1)) {
         TileLen a, b, c;
-        if (g_variant == 83) return -1;
+        if (ab().is(AB_BIG_NO_MR_TILES)) return -1;
         if (tile_plan(n, sizeof(T) == 8, mode, a, b)) {
             if ((rc = pass_columns<T>(s, in, work, batch, a, b.len(), dir, st, in_int))) return rc;
             return pass_rows<T>(s, work, out, batch, b, a.len(), 1, dir, st, out_int);

@@ -80,7 +80,7 @@ static int tile_gen_launch(const TileGenPlan& P, const cx<T>* in, cx<T>* out, un
     unsigned long long grid = (unsigned long long)num_cus() * per_cu;
     const size_t tile_bytes = (size_t)P.L * G::C * sizeof(cx<T>);
     // (as tile_host.h: small tiles on a static stride, three per workgroup; tiles of 60 KiB and more in order from the counter)
-    static const int its_env = [] { const char* e = getenv("PFFFT_HIP_TILE_ITS"); return e ? atoi(e) : 3; }();
+    static const int its_env = dev_env("PFFFT_HIP_TILE_ITS", 3);
     if (its_env > 0 && tile_bytes < 60 * 1024) {
         const unsigned long long want = (ntiles + its_env - 1) / its_env;
         if (want > grid) grid = want;
@@ -88,17 +88,17 @@ static int tile_gen_launch(const TileGenPlan& P, const cx<T>* in, cx<T>* out, un
     if (grid > ntiles) grid = ntiles;
     const bool want_dyn = tile_bytes >= 60 * 1024;
     if (want_dyn && ntiles <= 4 * grid) grid = ntiles;     // (short launches of in-order tiles: one tile per workgroup, the rule of tile_host.h)
-    static const int xctr_env = [] { const char* e = getenv("PFFFT_HIP_TILE_XCTR"); return e ? atoi(e) : 1; }();
+    static const int xctr_env = dev_env("PFFFT_HIP_TILE_XCTR", 1);
     const bool dynm = !(ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
     const bool xctr = dynm && xctr_env && grid % 8 == 0 && ntiles >= 64;
     // (per-XCD counters: nine words = five {next, done} pairs of the ring, which is allocated with that much room past its end)
     unsigned* ctr = !dynm ? nullptr : take_counters(s, st, xctr ? 5 : 1);
-    static const int xcd_env = [] { const char* e = getenv("PFFFT_HIP_TILE_XCD"); return e ? atoi(e) : 1; }();
+    static const int xcd_env = dev_env("PFFFT_HIP_TILE_XCD", 1);
     // (the XCD-contiguous tile map of the static stride is a bijection of workgroup index to tile only on a grid of whole eights: rounded
     //  up, the workgroups beyond the tiles retire at once)
     if (!ctr && xcd_env) grid = (grid + 7) / 8 * 8;
     TileDesc D2 = D;
-    D2.group = (xcd_env ? 1u : 257u) | (xctr ? 2048u : 0u);
+    D2.xmode = (xcd_env ? 1u : 0u) | (xctr ? 2u : 0u);     // (TileDesc::group keeps its one meaning: tiles per grab)
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(WG), lds, st, in, out, ntiles, D2, P, ctr);
     PF_CHECK(hipGetLastError());
     return 0;
@@ -112,7 +112,7 @@ int tile_gen_pass(bool is_double, int L, const void* in, void* out, unsigned lon
         g_last_error = "pffft_hip: internal layout on a tile length that is not a multiple of 4";
         return (int)hipErrorInvalidValue;
     }
-    static const int wg128 = [] { const char* e = getenv("PFFFT_HIP_TILE_WG128"); return e ? atoi(e) : 1; }();
+    static const int wg128 = dev_env("PFFFT_HIP_TILE_WG128", 1);
     const int wg = (wg128 && L <= TileGenGeom<float, 128>::LMAX) ? 128 : L <= TileGenGeom<float, 256>::LMAX ? 256 : L <= TileGenGeom<float, 512>::LMAX ? 512 : 1024;
 #define PF_TG(T, WG) tile_gen_launch<T, WG>(*P, (const cx<T>*)in, (cx<T>*)out, ntiles, D, dir, st, s, out_int, in_int)
     if (is_double) return wg == 128 ? PF_TG(double, 128) : wg == 256 ? PF_TG(double, 256) : wg == 512 ? PF_TG(double, 512) : PF_TG(double, 1024);

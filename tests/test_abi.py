@@ -269,3 +269,82 @@ def test_tile_planner_over_every_legal_size():
     assert pa.tile_plan(1 << 16) == [256, 256] and pa.tile_plan(1 << 22) == [128, 128, 256] and pa.tile_plan(2048) == []
     assert covered[False] > 100 and covered[True] > 150, covered
 
+
+
+def test_describe_matches_the_routing_restated_here():
+    """pffft_hip_describe() prints the Route records the planner stored in the setup at pffft_new_setup (round 5: the decisions used to be
+    re-derived on every call).  Walk over EVERY legal size up to 2^18 and every 7th up to 2^21, both precisions, real and complex: the
+    family line equals the restatement of tests/test_gpu_round3.py, and per (direction, layout): which power-of-two
+    sizes run their Stockham plan instead of the register-tiled kernel (DESIGN.md §3.4 routing, restated), launch rules, and beyond LDS
+    the core - tile lengths equal to pffft_hip_tile_plan's, the two-sweep real route for double N = 2^18 / 2^19 forward only, the
+    internal layout fused into the first / last pass exactly where the plan's lengths are multiples of 4.  No device needed."""
+    from conftest import legal_sizes
+    from test_gpu_round3 import expected_family
+
+    def prefers_stock(n, cplx, fwd, dbl):
+        if not dbl:
+            return (n <= 64 or n in (128, 8192)) if cplx else (n <= 64 or (n == 8192 and not fwd))
+        return (n <= 256 or n >= 2048) if cplx else (n <= 64 or (n == 128 and not fwd) or n == 256 or n >= 2048)
+
+    seen = {}
+    for dt in ("f32", "f64"):
+        dbl = dt == "f64"
+        dtype = np.float64 if dbl else np.float32
+        for tr in (pa.COMPLEX, pa.REAL):
+            sizes = legal_sizes(tr, 0, 1 << 18) + legal_sizes(tr, (1 << 18) + 1, 1 << 21)[::7]
+            for N in sizes:
+                s = pa.Setup(N, tr, dtype)
+                text = pa.describe(s)
+                lines = text.strip().split("\n")
+                assert len(lines) == 5, text
+                fam = expected_family(N, tr, dt)
+                assert lines[0].endswith("family " + fam) and pa.kernel_name(s) == fam, (dt, tr, N, lines[0])
+                n = N if tr == pa.COMPLEX else N // 2
+                for ln in lines[1:]:
+                    head, body = ln.strip().split(": ", 1)
+                    fwd, ordered = head.startswith("forward"), "unordered" not in head
+                    kind = body.split(":")[0]
+                    seen[kind] = seen.get(kind, 0) + 1
+                    if fam in ("tiny", "c1024_f32", "stockham"):
+                        assert kind == fam, (dt, tr, N, ln)
+                        if fam == "c1024_f32":
+                            assert "<= 4 resident sets" in body
+                    elif fam == "tiled":
+                        # (a Stockham plan exists where two exchange images fit LDS: n * sizeof(complex) <= 80 000 B)
+                        has_plan = n * (16 if dbl else 8) <= 80000
+                        want = "stockham" if has_plan and prefers_stock(n, tr == pa.COMPLEX, fwd, dbl) else "tiled"
+                        assert kind == want, (dt, tr, N, ln)
+                        if kind == "tiled":
+                            assert "in-order oneshot<=" + ("16" if (not dbl and n == 4096 and tr == pa.COMPLEX) else "4") in body, ln
+                    else:
+                        assert kind == "fourstep", (dt, tr, N, ln)
+                        two_sweep = tr == pa.REAL and dbl and N in (1 << 18, 1 << 19) and fwd
+                        assert ("real two-sweep" in body) == two_sweep, (dt, tr, N, ln)
+                        if "tiles " in body and not two_sweep:
+                            lens = [int(v) for v in body.split("tiles ")[1].split(" (mode")[0].split(" x ")]
+                            mode = int(body.split("(mode ")[1][0])
+                            assert lens == pa.tile_plan(n, dbl, mode), (dt, tr, N, ln)
+                            prod = 1
+                            for v in lens:
+                                prod *= v
+                            assert prod == n
+                            # the layout is blocks of four adjacent bins of the four spectrum quarters: the pass that reads / stores it needs
+                            # its tile length (the quarters) and its sequence count (the product of the other lengths) in multiples of 4
+                            out_ok = all(v % 4 == 0 for v in lens)
+                            in_ok = lens[0] % 4 == 0 and (n // lens[0]) % 4 == 0 and (len(lens) == 3 or lens[1] % 4 == 0)
+                            if tr == pa.COMPLEX and not ordered:
+                                assert ("fuse_out 1" in body) == (fwd and out_ok), ln
+                                assert ("fuse_in 1" in body) == ((not fwd) and in_ok), ln
+                        if tr == pa.COMPLEX and ordered:
+                            assert "pre -1" in body and "post -1" in body and any(f" {k} sweeps" in body for k in (2, 3, 5)), ln
+                s.close()
+    assert seen.get("tiled", 0) > 60 and seen.get("stockham", 0) > 800 and seen.get("fourstep", 0) > 2000 and seen.get("tiny", 0) >= 8, seen
+    # an invalid handle
+    import ctypes as C
+    buf = C.create_string_buffer(64)
+    assert pa.lib().pffft_hip_describe(None, buf, 64) == -1 and buf.value == b""
+    # truncation: snprintf convention
+    s = pa.Setup(1024, pa.COMPLEX)
+    need = pa.lib().pffft_hip_describe(s.handle, buf, 64)
+    assert need > 64 and len(buf.value) == 63 and pa.describe(s).startswith(buf.value.decode())
+    s.close()
