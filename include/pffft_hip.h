@@ -188,6 +188,10 @@ const char *pffft_hip_kernel_name(const void *setup);
  * most len - 1 characters + a terminating 0 into buf and returns the length of the whole text (snprintf convention), -1 for an
  * invalid handle.  Works for PFFFT_Setup and PFFFTD_Setup handles; no device needed. */
 int pffft_hip_describe(const void *setup, char *buf, size_t len);
+/* Resident workgroups per CU of the kernel a (direction, layout) of an LDS-resident setup runs on, as the launcher sizes its grid (the
+ * runtime's occupancy query for the route's kernel, workgroup size and LDS bytes); 0 for routes without one persistent kernel (beyond
+ * LDS, the minimum sizes), -1 on error.  Needs a device.  For tests and tools. */
+int pffft_hip_route_occupancy(const void *setup, int direction, int ordered);
 /* The tile plan of a complex core transform of n points beyond LDS (n = N for complex setups, N / 2 for real ones): returns the
  * number of tile passes over HBM — 2 or 3 — and their tile lengths in `lengths` (column pass(es) first, the row pass last), or 0
  * when the size runs on the streaming passes (or is LDS-resident: the planner is not consulted then).  `deep` = 1: the size's

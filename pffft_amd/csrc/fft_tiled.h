@@ -682,14 +682,7 @@ template <> struct TiledPick<float> {
     typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 1> C8192;
     typedef TiledCfg<float, 14, 1024, 4, 8, 16, 16, 8, 4, 8, 3, 0> C16384;
 };
-// experimental alternatives (pffft_hip_set_variant(20)): no register prefetch, 128-VGPR budget, two
-// workgroups per CU so that independent transforms overlap each other's barrier phases
-struct TiledAltF32 {
-    typedef TiledCfg<float, 11, 128, 4, 8, 4, 8, 8, 4, 8, 3, 0, 256, 4> C2048;
-    typedef TiledCfg<float, 12, 256, 4, 8, 8, 8, 8, 4, 8, 3, 0, 256, 4> C4096;
-    typedef TiledCfg<float, 13, 512, 4, 8, 8, 16, 8, 4, 8, 3, 0, 512, 4> C8192;
-};
-// Double-precision alternatives measured against TiledPick<double> (tools/c5_ab.py, variants 70 / 71 / 72):
+// Double-precision alternatives measured against TiledPick<double> (tools/c5_ab.py):
 //   A: one base twiddle per butterfly in registers, powers recomputed (no LDS twiddle table)
 //   B: LDS table + register prefetch of the next vector          C: both
 // n = 1024 (BASELINE configs[4], fraction of 8 TB/s, fwd internal / bwd internal / fwd canonical / bwd canonical):
@@ -698,7 +691,7 @@ struct TiledAltF32 {
 // n = 512: complex pick 0.73-0.77, C 0.80-0.82; real N = 1024 backward pick 0.66-0.68, C 0.81-0.83
 // n = 256 / 128: the gains are in the real backward transforms (N = 512: 0.58-0.64 -> 0.77-0.81, N = 256: 0.62-0.64 -> 0.78-0.80)
 // n = 2048 / 4096 (were on the Stockham kernel at 0.65-0.73): complex C 0.76-0.80; real N = 4096 A/C 0.70-0.76, N = 8192 forward 0.70-0.73
-// The launcher's table (pffft_hip.hip tiled_lookup) picks per size, layout and direction.
+// The planner's table (pffft_hip.hip tiled_pick) picks per size, layout and direction.
 struct TiledAltF64 {
     typedef TiledCfg<double, 10, 64, 3, 8, 16, 8, 1, 4, 0, 3, 0> A1024;
     typedef TiledCfg<double, 10, 64, 3, 8, 16, 8, 1, 4, 0, 1, 1> B1024;
@@ -742,18 +735,8 @@ struct TiledAltF32b {
     typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 2, 0, 3, 0, 512, 2> T16384np;
     typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 4, 8, 3, 1, 512, 2> T16384b;   // the paddings of the 1024-thread one
 };
-// Multi-wave skeleton (round 4): 1024 threads own one n = 8192 vector, EIGHT points per thread, five stages 4 x 8 x 8 x 8 x 4
-// (first and last radix 4 keep two adjacent butterflies per thread = 16-byte global accesses in lane order; tools/skel_probe.hip
-// puts a 64 KiB vector per 1024 threads at 0.82-0.84 of the roofline as a bare copy against 0.73-0.77 per 256 / 512 threads).
-// Paddings from tools/tiled_lds_search.py (3584 LDS cycles per transform against 3072 conflict-free).
-struct TiledMwF32 {
-    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 1, 1024, 4, 4> M8192;      // one workgroup per CU, register prefetch
-    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 0, 1024, 4, 4> M8192np;    // ... without
-    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 0, 1024, 8, 4> M8192x2;    // two workgroups per CU within 64 VGPRs
-    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 2, 0, 1024, 8, 4> M8192x2g;   // ... twiddles from the global table (L2)
-    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 3, 1, 1024, 8, 4> M8192x2p;   // ... with the register prefetch
-    typedef TiledCfg<float, 13, 1024, 5, 4, 8, 8, 8, 8, 4, 4, 1, 1024, 4, 4> M8192l;     // one workgroup per CU, LDS table, prefetch
-};
+// (round 4 built 1024-thread configurations of n = 8192 on this engine - eight points per thread, five stages 4 x 8 x 8 x 8 x 4, TiledCfg's
+//  fifth radix - and measured them slower than the adopted ones everywhere: DESIGN.md appendix A.9; the configurations are in the git history)
 
 template <> struct TiledPick<double> {
     typedef TiledCfg<double, 4, 2, 2, 4, 4, 1, 1, 1, 0, 0, 0, 256> C16;

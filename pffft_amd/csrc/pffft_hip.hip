@@ -1717,6 +1717,17 @@ PF_EXPORT const char* pffft_hip_kernel_name(const void* setup) {
     if (!s || s->magic != pf::MAGIC) return "invalid";
     return pf::setup_family(s);
 }
+// resident workgroups per CU of the LDS-resident kernel a (direction, layout) runs on, as the launcher sees it (the occupancy query of
+// the runtime for the route's kernel, threads and LDS bytes); 0 where the route has no single persistent kernel.  Needs a device.
+PF_EXPORT int pffft_hip_route_occupancy(const void* setup, int dir, int ordered) {
+    const pf::Setup* s = static_cast<const pf::Setup*>(setup);
+    if (!s || s->magic != pf::MAGIC || dir < 0 || dir > 1) return -1;
+    const pf::Route& r = s->route[dir][ordered ? 1 : 0];
+    int per_cu = 0;
+    if (r.fam == pf::FAM_TILED) { if (pf::allow_big_lds_impl(r.tiled.fn, r.tiled.lds) || pf::cached_occupancy(r.tiled.fn, r.tiled.wg, r.tiled.lds, &per_cu)) return -1; }
+    else if (r.fam == pf::FAM_STOCK && r.stock.fn) { if (pf::allow_big_lds_impl(r.stock.fn, r.stock.lds) || pf::cached_occupancy(r.stock.fn, r.stock.threads, r.stock.lds, &per_cu)) return -1; }
+    return per_cu;
+}
 PF_EXPORT int pffft_hip_describe(const void* setup, char* buf, size_t len) {
     const pf::Setup* s = static_cast<const pf::Setup*>(setup);
     if (!s || s->magic != pf::MAGIC) { if (buf && len) buf[0] = 0; return -1; }
