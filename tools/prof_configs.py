@@ -53,3 +53,5 @@ fft(1 << 20, pa.COMPLEX, np.float32, 128, ordered=True)
 fft(1 << 18, pa.REAL, np.float32, 1024, ordered=False)        # round 3: pair pass + internal layout as one block-kernel sweep
 fft(4000, pa.COMPLEX, np.float32, 1 << 15, ordered=False)     # a mixed-radix Stockham plan (workgroup kernel)
 fft(600000, pa.COMPLEX, np.float32, 223, ordered=True)        # round 4: 750 x 800 on the run-time tile passes (fft_tileg.h), 1 GiB of vectors
+fft(1024, pa.COMPLEX, np.float32, 1 << 12)                    # round 5: the short-launch kernel of the headline size (one transform per wavefront)
+fft(1024, pa.COMPLEX, np.float32, 1 << 14)
