@@ -147,11 +147,19 @@ static int tile_cost(const TileLen& t, bool columns, unsigned long long stride, 
     }
     if (stride % (line / 2)) return 240;
     if (t.r0 == 1) return columns ? 103 : 97;
+    // Register-tiled COLUMN tiles of L >= 576 (576, 640, 720, 768): a workgroup of L / 8 x 8 threads is nine to twelve wavefronts, three of them on
+    // one SIMD - 168 VGPRs at most - and the kernels spill (-Rpass-analysis=kernel-resource-usage: 12-172 B of scratch per lane in the plain passes,
+    // 152-364 B in the internal-layout input variant IINT, the first pass of a backward unordered transform, which then runs at HALF the rate:
+    // N = 82944 = 576 x 144 double 0.30 / 0.31 / 0.30 / 0.19 over the four combinations, float 0.34 / 0.33 / 0.34 / 0.23).  A quarter of that pass's
+    // extra cost, since all four combinations share one plan: N = 82944 double as 384 x 216 0.365 / 0.360 / 0.365 / 0.327, N = 294912 as 512 x 576
+    // 0.328 / 0.324 / 0.330 / 0.318 (was 0.315 / 0.315 / 0.315 / 0.205; tools/r5_force_scan.sh, profiles/r05_tile_plans_576.txt)
+    // (float 35: at 50 N = 460800 / 497664 would move from 576 x 800 / 576 x 864 to run-time column tiles - 0.31 / 0.31 / 0.31 / 0.22 -> 0.27 / 0.26 / 0.27 / 0.25)
+    const int iint_dbl = (columns && L >= 576) ? (is_double ? 50 : 35) : 0;
     if (t.r0 >= 25) {                                    // two odd stages: one more exchange
-        if (columns) return L >= 600 ? 185 : 125;
+        if (columns) return (L >= 600 ? 185 : 125) + iint_dbl;
         return L >= 600 ? 167 : L >= 256 ? 133 : 108;
     }
-    if (columns) return L >= 600 ? 172 : L <= 100 ? 125 : 115;
+    if (columns) return (L >= 600 ? 172 : L <= 100 ? 125 : 115) + iint_dbl;
     return L >= 560 ? 135 : L >= 256 ? 122 : 105;
 }
 // cost factor in percent of a pass whose sequence count `seqs` is not a multiple of the tile width
@@ -219,7 +227,11 @@ static bool forced_lengths(long long n, bool is_double, TileLen& a, TileLen& b) 
         t = TileLen{L, 0, true};
         return true;
     };
-    if (pick(F.l1, F.g1, a) && pick(F.l2, F.g2, b)) return true;
+    if (pick(F.l1, F.g1, a) && pick(F.l2, F.g2, b)) {
+        // (the planner's own legality rule: the register-tiled double kernels are built without the ragged last tile - next to one of them the
+        //  OTHER length is a multiple of 8; a forced 750 x 768 in double computed garbage before this check)
+        if (!(is_double && ((!a.gen && b.len() % 8) || (!b.gen && a.len() % 8)))) return true;
+    }
     static bool warned = false;
     if (!warned) { warned = true; fprintf(stderr, "pffft_hip: PFFFT_HIP_TILE_FORCE=%s names a tile length without a kernel: ignored\n", env().tile_force); }
     return false;
