@@ -200,6 +200,12 @@ int pffft_hip_route_occupancy(const void *setup, int direction, int ordered);
  * that pay only for complex transforms).  Pure host arithmetic, no device needed: for tests and for callers that want to know what
  * a size costs. */
 int pffft_hip_tile_plan(long long n, int is_double, int deep, int lengths[3]);
+/* The planner's tuning interface (tools/tune_tile_plans.py writes pffft_amd/csrc/tile_plan_gen.h with it).  pffft_hip_tile_candidates: every
+ * legal pair of tile lengths of n, out[5 i ..] = {L1, gen1, L2, gen2, cost of the model}, returns the count (may exceed max).
+ * pffft_hip_tile_override: from now on setups of n are planned with this pair (l1 > 0; -1 when it is not a legal pair), with no tile plan
+ * (l1 == 0: the streaming passes) or by the tables again (l1 < 0).  Process-wide; affects setups created afterwards. */
+int pffft_hip_tile_candidates(long long n, int is_double, int *out, int max);
+int pffft_hip_tile_override(long long n, int is_double, int l1, int g1, int l2, int g2);
 const char *pffft_hip_last_error(void);
 /* Number of legacy (void) entries that failed in this process so far.  The legacy entries have no error channel
  * (include/pffft/pffft.h:159); a failed call — no device, HIP error — prints one line on stderr, fills its output

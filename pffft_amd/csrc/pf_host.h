@@ -141,6 +141,8 @@ int launch_fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y
 int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, long long n, int dir, hipStream_t st, int layout = 0, int mode = 0);
 bool tile_has_plan(long long n, bool is_double, int mode = 0);   // mode: 0 complex / three streaming sweeps, 1 five (deep), 2 real core / three
 int tile_plan_lengths(long long n, bool is_double, int mode, int lengths[3]);
+int tile_plan_candidates(long long n, bool is_double, int* out, int max);   // every legal pair {L1, gen1, L2, gen2, model cost}
+int tile_plan_override(long long n, bool is_double, int l1, int g1, int l2, int g2);   // the tuner's hook (tools/tune_tile_plans.py)
 int tile_plan_layouts(long long n, bool is_double, int mode);   // bit 0: internal layout out of the last pass, bit 1: into the first   // 0 / 2 / 3 passes (pffft_hip_tile_plan)
 
 }  // namespace pf

@@ -1737,6 +1737,12 @@ PF_EXPORT int pffft_hip_tile_plan(long long n, int is_double, int deep, int leng
     if (!lengths) return 0;
     return pf::tile_plan_lengths(n, is_double != 0, deep < 0 || deep > 2 ? 1 : deep, lengths);
 }
+PF_EXPORT int pffft_hip_tile_candidates(long long n, int is_double, int* out, int max) {
+    return (out && max > 0) ? pf::tile_plan_candidates(n, is_double != 0, out, max) : 0;
+}
+PF_EXPORT int pffft_hip_tile_override(long long n, int is_double, int l1, int g1, int l2, int g2) {
+    return pf::tile_plan_override(n, is_double != 0, l1, g1, l2, g2);
+}
 PF_EXPORT const char* pffft_hip_last_error(void) { return pf::g_last_error.c_str(); }
 PF_EXPORT unsigned pffft_hip_error_count(void) { return pf::g_error_count.load(); }
 PF_EXPORT int pffft_hip_device_count(void) {

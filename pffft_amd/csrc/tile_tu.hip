@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "tile_host.h"
+#include "tile_plan_gen.h"
 
 namespace pf {
 
@@ -237,12 +238,63 @@ static bool forced_lengths(long long n, bool is_double, TileLen& a, TileLen& b) 
     return false;
 }
 
+// is (columns ta, rows tb) a pair of tile lengths the kernels can run for n = ta tb?  (the rules of the search below, in one place: the
+// measured plan table and the tuner's candidates obey them too)
+static bool tile_pair_legal(long long n, bool is_double, const TileLen& ta, const TileLen& tb) {
+    if (!tile_len_ok(ta) || !tile_len_ok(tb) || (long long)ta.len() * (long long)tb.len() != n) return false;
+    // (double: the register-tiled kernels are built without the ragged last tile - the OTHER length must be a multiple of 8)
+    if (is_double && ((!ta.gen && tb.len() % 8) || (!tb.gen && ta.len() % 8))) return false;
+    // (a length with a register-tiled kernel runs on the run-time plan only where the strided 128-byte runs of that kernel would not be
+    //  half lines - 475-550 us per pass against 250-330, tools/r4_gen_force.sh: N = 12000 = 100 x 120, 21600 = 108 x 200 ...)
+    const unsigned long long half = is_double ? 4 : 8;
+    if ((ta.alt && tb.len() % half == 0) || (tb.alt && ta.len() % half == 0)) return false;
+    return true;
+}
+static int tile_pair_cost(bool is_double, const TileLen& ta, const TileLen& tb) {
+    // (float: a length that is 8 mod 16 leaves the OTHER pass a half-empty last tile of 8 sequences)
+    int c = tile_cost(ta, true, tb.len(), is_double) * ragged_pct(tb.len(), is_double) / 100 +
+            tile_cost(tb, false, ta.len(), is_double) * ragged_pct(ta.len(), is_double) / 100;
+    // (lengths that are not multiples of 4 cannot carry the internal layout: a reorder sweep, ~130, on the unordered half of the calls)
+    if (ta.len() % 4 || tb.len() % 4) c += 40;
+    return c;
+}
+
+// Plans that were MEASURED to beat the cost model's choice (tile_plan_gen.h, written by tools/tune_tile_plans.py on MI355X: every legal pair
+// of every legal size beyond LDS timed in the four direction x layout combinations), and the tuner's run-time override of one size.
+static std::mutex g_override_mu;
+static std::map<long long, std::pair<TileLen, TileLen>> g_override;     // key n * 2 + is_double; first.r0 == 0: no tile plan
+static bool find_len(bool is_double, int L, bool gen, TileLen& t) {
+    for (const TileLen& v : tile_lengths(is_double)) if ((long long)v.len() == L && v.gen == gen) { t = v; return true; }
+    return false;
+}
+// 1: a measured / overriding plan exists (a, b set), 0: that entry says "no tile plan", -1: no entry
+static int measured_plan(long long n, bool is_double, TileLen& a, TileLen& b) {
+    {
+        std::lock_guard<std::mutex> lk(g_override_mu);
+        auto it = g_override.find(n * 2 + (is_double ? 1 : 0));
+        if (it != g_override.end()) {
+            if (it->second.first.r0 == 0) return 0;
+            a = it->second.first; b = it->second.second;
+            return 1;
+        }
+    }
+    for (const TilePlanEnt& e : kTilePlans)
+        if (e.n == n && (e.is_double != 0) == is_double) {
+            if (e.l1 == 0) return 0;
+            if (find_len(is_double, e.l1, e.g1 != 0, a) && find_len(is_double, e.l2, e.g2 != 0, b) && tile_pair_legal(n, is_double, a, b)) return 1;
+            return -1;       // (a table written for other tile lengths than this build has: the model decides)
+        }
+    return -1;
+}
+
 // mode: 0 = the streaming route of this size is three sweeps, complex transform; 1 = it is five (deep); 2 = three sweeps, the core of a REAL
 // transform (no wide threshold: real N = 2n measured 1-4 % slower on those plans - the pair sweep dominates either way)
 static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, TileLen& b) {
     const bool deep = mode == 1;
     if (forced_lengths(n, is_double, a, b)) return true;
     const std::vector<TileLen>& V = tile_lengths(is_double);
+    TileLen ma{1, 0}, mb{1, 0};
+    const int measured = measured_plan(n, is_double, ma, mb);
     static const int maxcost_env = dev_env("PFFFT_HIP_TILE_MAXCOST", 286);   // A/B
     // one round over the pairs of tile lengths; with_alt: lengths that have a register-tiled kernel also on their run-time plan
     auto search = [&](bool with_alt) -> bool {
@@ -254,19 +306,9 @@ static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, 
             if (!tile_len_ok(ta) || n % (long long)ta.len()) continue;
             const long long L2 = n / (long long)ta.len();
             for (const TileLen& tb : V) {
-                if ((long long)tb.len() != L2 || !tile_len_ok(tb)) continue;
-                // (double: the register-tiled kernels are built without the ragged last tile - the OTHER length must be a multiple of 8)
-                if (is_double && ((!ta.gen && tb.len() % 8) || (!tb.gen && ta.len() % 8))) continue;
-                // (a length with a register-tiled kernel runs on the run-time plan only where the strided 128-byte runs of that kernel would
-                //  not be half lines - 475-550 us per pass against 250-330, tools/r4_gen_force.sh: N = 12000 = 100 x 120, 21600 = 108 x 200 ...)
-                const unsigned long long half = is_double ? 4 : 8;
+                if ((long long)tb.len() != L2 || !tile_pair_legal(n, is_double, ta, tb)) continue;
                 if ((ta.alt || tb.alt) && !with_alt) continue;
-                if ((ta.alt && tb.len() % half == 0) || (tb.alt && ta.len() % half == 0)) continue;
-                // (float: a length that is 8 mod 16 leaves the OTHER pass a half-empty last tile of 8 sequences)
-                int c = tile_cost(ta, true, tb.len(), is_double) * ragged_pct(tb.len(), is_double) / 100 +
-                        tile_cost(tb, false, ta.len(), is_double) * ragged_pct(ta.len(), is_double) / 100;
-                // (lengths that are not multiples of 4 cannot carry the internal layout: a reorder sweep, ~130, on the unordered half of the calls)
-                if (ta.len() % 4 || tb.len() % 4) c += 40;
+                const int c = tile_pair_cost(is_double, ta, tb);
                 // (float, not deep: a plan with a run-time length that carries the internal layout is taken up to 340 - the sizes with 2^4 / 2^5
                 //  and a large odd part, whose streaming route cannot read the internal layout in its column pass (R odd): four combinations
                 //  0.23 / 0.24 / 0.25 / 0.18 -> 0.21 / 0.24 / 0.24 / 0.24, tools/r4_gen_scan.sh wide; double: the run-time passes are 5-17 % behind)
@@ -280,7 +322,12 @@ static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, 
     };
     // the plans without `alt` lengths first; those with them only where that finds nothing (N = 12000 = 100 x 120 ... 200000: the minimum
     // over the four combinations 0.18 -> 0.25, mean +10 ... +17 %; as equal competitors they displaced better plans: N = 108000 -7 %)
-    return search(false) || search(true);
+    const bool found = search(false) || search(true);
+    // a measured plan replaces the model's: for the complex transforms always (mode 0: including "the streaming passes win"), for the core of a
+    // real transform (mode 2: the plans were timed on complex transforms) only WHICH tile lengths run where the model plans tiles at all
+    if (measured == 1 && (mode != 2 || found)) { a = ma; b = mb; return true; }
+    if (measured == 0 && mode == 0) return false;
+    return found;
 }
 
 // Three tile passes n = L1 (L2 L3) (the shape of the power-of-two sizes beyond 2^20) for the sizes without a two-pass plan whose
@@ -311,10 +358,16 @@ static bool tile_plan3_search(long long n, bool is_double, TileLen& a, TileLen& 
 // The plan of a size is a pure function of (n, precision, deep): searched once, then served from a table (launch_big asked
 // twice per transform, under the setup's lock; the three-pass search walks ~26^3 length triples)
 struct PlanEntry { int passes = 0; TileLen t[3] = {{1, 0}, {1, 0}, {1, 0}}; };
-static const PlanEntry& plan_of(long long n, bool is_double, int mode) {
+static std::mutex g_plan_mu;
+static std::map<long long, PlanEntry> g_plan_tab;
+static void drop_cached_plans(long long n, bool is_double) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    for (int mode = 0; mode < 3; ++mode) g_plan_tab.erase(n * 8 + (is_double ? 4 : 0) + mode);
+}
+static PlanEntry plan_of(long long n, bool is_double, int mode) {
     const bool deep = mode == 1;
-    static std::mutex mu;
-    static std::map<long long, PlanEntry> tab;
+    std::mutex& mu = g_plan_mu;
+    std::map<long long, PlanEntry>& tab = g_plan_tab;
     const long long key = n * 8 + (is_double ? 4 : 0) + mode;
     std::lock_guard<std::mutex> lk(mu);
     auto it = tab.find(key);
@@ -327,13 +380,13 @@ static const PlanEntry& plan_of(long long n, bool is_double, int mode) {
     return it->second;
 }
 static bool tile_plan(long long n, bool is_double, int mode, TileLen& a, TileLen& b) {
-    const PlanEntry& e = plan_of(n, is_double, mode);
+    const PlanEntry e = plan_of(n, is_double, mode);
     if (e.passes != 2) return false;
     a = e.t[0]; b = e.t[1];
     return true;
 }
 static bool tile_plan3(long long n, bool is_double, TileLen& a, TileLen& b, TileLen& c) {
-    const PlanEntry& e = plan_of(n, is_double, 1);
+    const PlanEntry e = plan_of(n, is_double, 1);
     if (e.passes != 3) return false;
     a = e.t[0]; b = e.t[1]; c = e.t[2];
     return true;
@@ -352,10 +405,10 @@ bool tile_has_plan(long long n, bool is_double, int mode) {
 int tile_plan_layouts(long long n, bool is_double, int mode) {
     const bool deep = mode == 1;
     if (n > 0 && (n & (n - 1)) == 0) return 3;
-    const PlanEntry& e = plan_of(n, is_double, mode);
+    const PlanEntry e = plan_of(n, is_double, mode);
     if (e.passes == 2) return ((e.t[1].len() % 4 || e.t[0].len() % 4) ? 0 : 1) | ((e.t[0].len() % 4 || e.t[1].len() % 4) ? 0 : 2);
     if (deep) {
-        const PlanEntry& e3 = plan_of(n, is_double, 1);
+        const PlanEntry e3 = plan_of(n, is_double, 1);
         if (e3.passes == 3)
             return ((e3.t[2].len() % 4 || e3.t[0].len() % 4 || e3.t[1].len() % 4) ? 0 : 1) | ((e3.t[0].len() % 4 || (e3.t[1].len() * e3.t[2].len()) % 4) ? 0 : 2);
     }
@@ -420,6 +473,38 @@ static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t b
     if ((rc = pass_columns<T>(s, in, work, batch, TileLen{1, l1}, 1ull << rem, dir, st, in_int))) return rc;
     if ((rc = pass_columns<T>(s, work, work, batch << l1, TileLen{1, l2}, 1ull << l3, dir, st))) return rc;
     return pass_rows<T>(s, work, out, batch, TileLen{1, l3}, 1ull << l1, 1ull << l2, dir, st, out_int);
+}
+
+// every legal pair of tile lengths of n (columns, rows) with the model's cost: out[5 i ..] = {L1, gen1, L2, gen2, cost}; returns the count
+int tile_plan_candidates(long long n, bool is_double, int* out, int max) {
+    const std::vector<TileLen>& V = tile_lengths(is_double);
+    int cnt = 0;
+    for (const TileLen& ta : V) {
+        if (n % (long long)ta.len()) continue;
+        for (const TileLen& tb : V) {
+            if (!tile_pair_legal(n, is_double, ta, tb)) continue;
+            if (cnt < max) {
+                out[5 * cnt] = (int)ta.len(); out[5 * cnt + 1] = ta.gen ? 1 : 0; out[5 * cnt + 2] = (int)tb.len(); out[5 * cnt + 3] = tb.gen ? 1 : 0;
+                out[5 * cnt + 4] = tile_pair_cost(is_double, ta, tb);
+            }
+            ++cnt;
+        }
+    }
+    return cnt;
+}
+// the tuner's hook: l1 > 0 - the plan of n from now on (0 = accepted, -1 = not a legal pair); l1 == 0 - "no tile plan"; l1 < 0 - remove the
+// override.  Setups created afterwards see it (routes are planned at pffft_new_setup); the cached model plans of n are dropped.
+int tile_plan_override(long long n, bool is_double, int l1, int g1, int l2, int g2) {
+    const long long key = n * 2 + (is_double ? 1 : 0);
+    TileLen a{0, 0}, b{0, 0};
+    if (l1 > 0 && !(find_len(is_double, l1, g1 != 0, a) && find_len(is_double, l2, g2 != 0, b) && tile_pair_legal(n, is_double, a, b))) return -1;
+    {
+        std::lock_guard<std::mutex> lk(g_override_mu);
+        if (l1 < 0) g_override.erase(key);
+        else g_override[key] = std::make_pair(a, b);
+    }
+    drop_cached_plans(n, is_double);
+    return 0;
 }
 
 // layout: 1 = forward, spectrum out in the internal layout; 2 = backward, spectrum in from the internal layout
