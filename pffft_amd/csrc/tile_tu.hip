@@ -424,7 +424,12 @@ int tile_plan_lengths(long long n, bool is_double, int mode, int lengths[3]) {
         int logn = 0;
         while ((1ll << logn) < n) ++logn;
         if (logn < 12 || logn > 27) return 0;
-        if (logn <= 20) { lengths[0] = 1 << (logn / 2); lengths[1] = 1 << (logn - logn / 2); return 2; }
+        if (logn <= 20) {
+            TileLen ma{1, 0}, mb{1, 0};
+            if (measured_plan(n, is_double, ma, mb) == 1) { lengths[0] = (int)ma.len(); lengths[1] = (int)mb.len(); return 2; }   // (a measured split)
+            lengths[0] = 1 << (logn / 2); lengths[1] = 1 << (logn - logn / 2);
+            return 2;
+        }
         const int l1 = logn / 3, rem = logn - l1;
         lengths[0] = 1 << l1; lengths[1] = 1 << (rem / 2); lengths[2] = 1 << (rem - rem / 2);
         return 3;
@@ -463,9 +468,12 @@ static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t b
     const int minlog = 12;
     if (logn < minlog || logn > 27) return -1;
     if (logn <= 20) {
-        const int l1 = logn / 2, l2 = logn - l1;
-        if ((rc = pass_columns<T>(s, in, work, batch, TileLen{1, l1}, 1ull << l2, dir, st, in_int))) return rc;
-        return pass_rows<T>(s, work, out, batch, TileLen{1, l2}, 1ull << l1, 1, dir, st, out_int);
+        // the balanced split 2^(logn / 2) x 2^(logn - logn / 2), unless another split measured faster (tile_plan_gen.h: round 5)
+        TileLen ta{1, logn / 2}, tb{1, logn - logn / 2};
+        TileLen ma{1, 0}, mb{1, 0};
+        if (measured_plan(n, sizeof(T) == 8, ma, mb) == 1) { ta = ma; tb = mb; }
+        if ((rc = pass_columns<T>(s, in, work, batch, ta, tb.len(), dir, st, in_int))) return rc;
+        return pass_rows<T>(s, work, out, batch, tb, ta.len(), 1, dir, st, out_int);
     }
     const int l1 = logn / 3, rem = logn - l1, l2 = rem / 2, l3 = rem - l2;
     // n = L1 n', n' = L2 L3:  A over L1 (columns n'), then per row of length n': A over L2 (in place), B over L3 with the

@@ -269,7 +269,7 @@ def test_tile_planner_over_every_legal_size():
     # (0.242 / 0.253 / 0.245 / 0.186 -> 0.220 / 0.236 / 0.243 / 0.242: the backward unordered transform no longer pays a layout sweep)
     assert pa.tile_plan(10800) == [180, 60] and pa.tile_plan(10800, False, 2) == [] and pa.tile_plan(10800, True) == [180, 60]
     assert pa.tile_plan(600000) == [] and pa.tile_plan(600000, False, True) == [750, 800] and pa.tile_plan(314928, True, True) == [486, 648]
-    assert pa.tile_plan(1 << 16) == [256, 256] and pa.tile_plan(1 << 22) == [128, 128, 256] and pa.tile_plan(2048) == []
+    assert pa.tile_plan(1 << 16) == [512, 128] and pa.tile_plan(1 << 18) == [512, 512] and pa.tile_plan(1 << 22) == [128, 128, 256] and pa.tile_plan(2048) == []
     # round 5: column tiles of L >= 576 spill (168 VGPRs for nine and more wavefronts): priced, N = 82944 no longer 576 x 144
     assert pa.tile_plan(82944, True)[0] < 576 and pa.tile_plan(294912, True) == [512, 576]
     assert covered[False] > 100 and covered[True] > 150, covered

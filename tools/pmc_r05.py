@@ -11,7 +11,8 @@ shutil.copy(os.path.join(G, "cfg", "trace_kernel_stats.csv"), os.path.join(P, "r
 # (the same kernel also runs once on a single vector when a pffastconv setup transforms its filter)
 trace = list(csv.DictReader(open(os.path.join(G, "cfg", "trace_kernel_trace.csv"))))
 def big_dispatches(rows, sub, name_key, grid_key="Grid_Size", part=None, wgs=None):
-    m = [r for r in rows if sub in r[name_key]]
+    import re
+    m = [r for r in rows if (re.search(sub[3:], r[name_key]) if sub.startswith("re:") else sub in r[name_key])]
     if not m:
         return []
     g = max(int(r[grid_key]) for r in m)
@@ -37,8 +38,8 @@ CASES = [
     ("fir_wave200", "fastconv_wave_kernel", 8 * ((1 << 26) - 199), "FIR 200 taps on 2^26 samples: one wavefront per 2048-sample block (round 3)"),
     ("conv1024", "fft_conv_kernel<pf::TiledCfg<float, 10, 64", (1 << 20) * 16384, "pffft_hip_convolve_batch N=1024 cplx f32, batch 2^20: forward x H backward in one kernel (round 4)"),
     ("stock3888", "SKP_f_3888_c_0", 2 * 34521 * 3888 * 8, "N=3888 cplx f32 forward unordered: Stockham plan 3 x 9 x 9 x 16 (round 4), 1 GiB of vectors"),
-    ("big16_A", "tile_fft_kernel<float, 8, 8, 0, 1", 2 * (1 << 30), "N=2^16 cplx f32, pass A (column tiles), 1 GiB of vectors"),
-    ("big16_Bi", "tile_fft_kernel<float, 8, 8, 0, 0, 1, 1", 2 * (1 << 30), "N=2^16 cplx f32, pass B storing the internal layout"),
+    ("big16_A", "tile_fft_kernel<float, 9, 8, 0, 1", 2 * (1 << 30), "N=2^16 cplx f32 = 512 x 128 (measured split, round 5), pass A (column tiles of 512 points), 1 GiB of vectors"),
+    ("big16_Bi", "re:tile_fft_kernel<float, 7, 8, 0, 0, \\d, 1,", 2 * (1 << 30), "N=2^16 cplx f32, pass B (row tiles of 128 points) storing the internal layout"),
     ("blk_real", "big_block_kernel<float, 2>", 2 * (1 << 30), "real N=2^18 forward: pair pass + internal layout, one sweep"),
     ("stock4000", "SKP_f_4000_c_0", 2 * (1 << 15) * 4000 * 8, "N=4000 cplx f32 forward unordered (Stockham workgroup kernel), batch 2^15"),
     ("big20_A", "tile_fft_kernel<float, 10, 4, 0, 1", 2 * (1 << 30), "N=2^20 cplx f32, pass A"),

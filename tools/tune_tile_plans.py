@@ -1,4 +1,4 @@
-"""Measure, for every legal complex size beyond LDS that is not a power of two, EVERY legal pair of tile lengths (pffft_hip_tile_candidates)
+"""Measure, for every legal complex size beyond LDS (powers of two up to 2^18 included), EVERY legal pair of tile lengths (pffft_hip_tile_candidates)
 and the streaming route, in the four direction x layout combinations, and write the plans that beat the cost model's choice to
 pffft_amd/csrc/tile_plan_gen.h (development tool, runs on the GPU):
 
@@ -68,15 +68,28 @@ def measure(n, dt, mib):
 
 
 def main():
+    explicit = None
+    if len(sys.argv) > 1 and sys.argv[1] == "sizes":              # tune these sizes only; the other entries of the table are kept
+        explicit = [int(v) for v in sys.argv[2].split(",")]
+        del sys.argv[1]
+        sys.argv[1] = str(max(explicit))
     hi = int(sys.argv[1]) if len(sys.argv) > 1 else 600000
     which = sys.argv[2] if len(sys.argv) > 2 else "both"
     mib = int(sys.argv[3]) if len(sys.argv) > 3 else 512
     table, log = [], []
+    kept = []
+    if explicit is not None:
+        import re
+        src = open(os.path.join(ROOT, "pffft_amd", "csrc", "tile_plan_gen.h")).read()
+        for m in re.finditer(r"\{(\d+), (\d), (\d+), (\d), (\d+), (\d)\},", src):
+            e = tuple(int(v) for v in m.groups())
+            if e[0] and e[0] not in explicit:
+                kept.append(e)
     for dt in ([np.float32, np.float64] if which == "both" else [np.float64 if which == "f64" else np.float32]):
         dbl = dt == np.float64
-        for n in legal_sizes(pa.COMPLEX, 2048, hi):
-            if n & (n - 1) == 0:
-                continue
+        for n in (sorted(explicit) if explicit is not None else legal_sizes(pa.COMPLEX, 2048, hi)):
+            if n & (n - 1) == 0 and n > (1 << 18):
+                continue                                            # (2^19, 2^20: a 1024-point tile on one side, no candidates; beyond: three passes)
             s = pa.Setup(n, pa.COMPLEX, dt)
             fam = pa.kernel_name(s); s.close()
             if fam != "fourstep":
@@ -137,7 +150,7 @@ def main():
                 f"{mib} MiB per launch.\n// {{n, is_double, L1, gen1, L2, gen2}}: columns L1 then rows L2, gen = the run-time kernel of fft_tileg.h; L1 = 0: no tile plan, the\n"
                 "// streaming passes of fft_big.h win.  Log of the run: profiles/r05_tile_plan_tuning.txt\n#pragma once\nnamespace pf {\n"
                 "struct TilePlanEnt { long long n; int is_double, l1, g1, l2, g2; };\nstatic const TilePlanEnt kTilePlans[] = {\n")
-        for e in table:
+        for e in sorted(kept + table, key=lambda e: (e[1], e[0])):
             f.write("    {%d, %d, %d, %d, %d, %d},\n" % e)
         f.write("    {0, 0, 0, 0, 0, 0}};\n}  // namespace pf\n")
     with open(os.path.join(ROOT, "gpurun_out", "tile_plan_tuning.txt"), "w") as f:
