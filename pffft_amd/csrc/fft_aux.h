@@ -9,7 +9,7 @@
 //   * zconvolve issues all loads of two pairs per thread before the first product, remainders in 32 bits -> 0.69-0.70;
 //   * both can pull chunks in order from the work counter (SkSched, fft_stock.h) - measured SLOWER here
 //     (0.47-0.62 / 0.57-0.60; with one 16 KiB group per atomic even 0.16: one counter address serves ~80 M atomics/s),
-//     so the launchers assign statically and keep the in-order path for A/B (variant 42).
+//     so the launchers assign statically and keep the in-order path as the alternative route of the tests (AB_INORDER_SMALL, pf_route.h).
 #pragma once
 #include "fft_stock.h"
 #include "fft_tiled.h"  // ChunkOps

@@ -713,24 +713,24 @@ struct TiledAltF64 {
     typedef TiledCfg<double, 7, 8, 3, 8, 2, 8, 1, 1, 0, 3, 1, 256> C128;
 };
 // float n = 64 real forward (N = 128): base twiddle + recomputed powers measured 0.70-0.71 against 0.62-0.65 for the
-// all-in-registers table; for every other float size <= 512 the TiledPick entries won the A/B (variants 73 / 74 of r01:
-// recomputed powers 0.55-0.83, no prefetch 0.59-0.76, pick 0.62-0.83)
+// all-in-registers table; for every other float size <= 512 the TiledPick entries won the A/B of round 1
+// (recomputed powers 0.55-0.83, no prefetch 0.59-0.76, pick 0.62-0.83)
 struct TiledAltF32b {
     typedef TiledCfg<float, 6, 4, 2, 8, 8, 1, 1, 1, 0, 3, 1> A64;
     // n = 8192 in THREE stages, 16 x 32 x 16 with 32 points per thread: one exchange less than 8 x 8 x 16 x 8 (LDS cycles
-    // of the exchanges 2304 -> 1536, conflict-free with PAD0 = 2, PADN = 0: tools/tiled_lds_search.py); variants 75 / 76
+    // of the exchanges 2304 -> 1536, conflict-free with PAD0 = 2, PADN = 0: tools/tiled_lds_search.py)
     typedef TiledCfg<float, 13, 256, 3, 16, 32, 16, 1, 2, 0, 3, 1, 256, 2> T8192;
     typedef TiledCfg<float, 13, 256, 3, 16, 32, 16, 1, 2, 0, 3, 0, 256, 2> T8192np;
     // every twiddle resident in registers (two workgroups of 256 threads per CU leave 256 VGPRs per lane): no power
-    // recomputation in the loop (variant 79)
+    // recomputation in the loop
     typedef TiledCfg<float, 13, 256, 3, 16, 32, 16, 1, 2, 0, 0, 0, 256, 2> T8192np0;
-    // the same idea one and two sizes down: 32 points per thread, three stages (variants 77 prefetch / 78 none)
+    // the same idea one and two sizes down: 32 points per thread, three stages (with / without prefetch)
     typedef TiledCfg<float, 11, 64, 3, 16, 8, 16, 1, 2, 0, 3, 1> T2048;            // ONE wavefront per transform
     typedef TiledCfg<float, 11, 64, 3, 16, 8, 16, 1, 2, 0, 3, 0> T2048np;
     typedef TiledCfg<float, 12, 128, 3, 16, 16, 16, 1, 2, 0, 3, 1, 256, 2> T4096;
     typedef TiledCfg<float, 12, 128, 3, 16, 16, 16, 1, 2, 0, 3, 0, 256, 2> T4096np;
     // n = 16384 (one 128 KiB image, one workgroup per CU): 32 points per thread, 512 threads -> 256 VGPRs per lane, room for
-    // the register prefetch of the next vector that the 1024-thread configuration (128 VGPRs) cannot hold (variants 83 / 84)
+    // the register prefetch of the next vector that the 1024-thread configuration (128 VGPRs) cannot hold
     typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 2, 0, 3, 1, 512, 2> T16384;
     typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 2, 0, 3, 0, 512, 2> T16384np;
     typedef TiledCfg<float, 14, 512, 4, 16, 8, 8, 16, 4, 8, 3, 1, 512, 2> T16384b;   // the paddings of the 1024-thread one

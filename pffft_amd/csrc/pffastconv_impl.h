@@ -410,7 +410,7 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
     if (mode == 0 && s->cplxFactor == 1 && s->filterLen > TD_MAX_TAPS / 4 && s->filterLen <= PART_B * PART_MAXP &&
         sel.is(AB_FIR_PARTITIONED) && produced > 0) {
         // development build: the uniformly partitioned one-wavefront-per-block kernel (fft_fir.h fastconv_part_kernel, round 2;
-        // variant 88 / PFFASTCONV_HIP_PART=1 force it).  Measured (fraction of the 8 B / sample roofline, 2^26 samples / 256
+        // AB_FIR_PARTITIONED forces it).  Measured (fraction of the 8 B / sample roofline, 2^26 samples / 256
         // signals of 2^20): one partition 0.30 / 0.37 - superseded by the wave kernel above, which advances by the samples the
         // filter leaves valid instead of 1024; two partitions (2048 taps) 0.25 / 0.26 lose to the long-block DMA kernel; three
         // and four keep their ring in > 256 registers and run one wavefront per SIMD (0.12-0.23).

@@ -1285,11 +1285,11 @@ template <typename T>
 static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, hipStream_t st) {
     if (!s || s->magic != MAGIC) return (int)hipErrorInvalidHandle;
     if (batch == 0) return 0;
-    // through an LDS image of the internal layout when a vector fits (fft_aux.h); variant 60 = the direct kernel
+    // through an LDS image of the internal layout when a vector fits (fft_aux.h); AB_AUX_DIRECT = the direct kernel
     constexpr int CH = 16 / (int)sizeof(T), BCH = SkIbs<T>::v / CH;
     const size_t vimg = ((size_t)(s->n / 16) * BCH + 1) * 16;   // block image of one vector, bytes
     const size_t vbytes = s->vec_scalars * sizeof(T);
-    // long batches of vectors <= 64 KiB: in-order streaming kernel with next-group prefetch (fft_aux.h); variant 61 = off
+    // long batches of vectors <= 64 KiB: in-order streaming kernel with next-group prefetch (fft_aux.h); AB_AUX_NO_STREAM = off
     const AbSel sel = ab();
     const bool direct = sel.is(AB_AUX_DIRECT), inorder_small = sel.is(AB_INORDER_SMALL);
     if (vbytes <= ZRD_GROUP_BYTES && batch * vbytes >= ((size_t)64 << 20) && !direct && !sel.is(AB_AUX_NO_STREAM) && !inorder_small && in != out) {
@@ -1335,7 +1335,7 @@ static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, 
         size_t kc = (131072 + G * vimg - 1) / (G * vimg), cap = groups / (8 * grid);
         if (kc > cap) kc = cap;
         if (kc > 64) kc = 64;
-        // static by default: 0.61-0.70 of the roofline against 0.47-0.62 with in-order chunks (variant 42) and
+        // static by default: 0.61-0.70 of the roofline against 0.47-0.62 with in-order chunks (AB_INORDER_SMALL) and
         // 0.41-0.61 for the direct kernel (tools/aux_bench.py)
         unsigned* ctr = (kc < 1 || !inorder_small) ? nullptr : take_counters(s, st);
         if (kc < 1) kc = 1;
@@ -1364,9 +1364,9 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
     const bool direct = sel.is(AB_AUX_DIRECT), inorder_small = sel.is(AB_INORDER_SMALL);
     size_t total = batch * (size_t)(s->n / 4);
     // float: streaming kernel, two pairs per thread with all loads issued first (fft_aux.h): 0.69-0.70 against 0.65-0.70
-    // for the grid-stride kernel, which stays for double (0.65 vs 0.41) and as variant 60; in-order chunks (variant 42)
+    // for the grid-stride kernel, which stays for double (0.65 vs 0.41) and as AB_AUX_DIRECT; in-order chunks (AB_INORDER_SMALL)
     // measured 0.57-0.60
-    // long batches (>= 64 MiB per stream): in-order streaming kernel with DPP pair exchange (fft_aux.h); variant 61 = off
+    // long batches (>= 64 MiB per stream): in-order streaming kernel with DPP pair exchange (fft_aux.h); AB_AUX_NO_STREAM = off
     {
         const unsigned long long Q = 2ull * total * Zd<T>::UPG;   // 16-byte units in the batch
         if (!direct && !sel.is(AB_AUX_NO_STREAM) && !inorder_small && Q / Zd<T>::CHUNK >= 8192u &&
@@ -1438,7 +1438,7 @@ __global__ void vec_add_kernel(const T* __restrict__ x, T* __restrict__ out, siz
 }
 
 // pffft_hip_convolve_batch: out (+)= backward(forward(in) . H) scaling.  One kernel where fft_conv.h has one (conv_tu.hip);
-// otherwise the three batched entries through a per-stream spectrum image (variant 120 forces the composition, A/B).
+// otherwise the three batched entries through a per-stream spectrum image (AB_CONV_COMPOSED forces the composition: the second route of the tests).
 template <typename T>
 static int convolve_batch(Setup* s, const T* in, const T* H, T* out, T scaling, size_t batch, int accumulate, int h_broadcast,
                           hipStream_t st) {

@@ -293,6 +293,9 @@ dt = {dt!r}
 dtype = np.float32 if dt == "f32" else np.float64
 tol = 1e-5 if dt == "f32" else 2e-7            # (double with factors 3 / 5: the reference's own float-suffixed constants, conftest.tol_for)
 N = {N}
+import os
+want_plan = [int(v.rstrip("g")) for v in os.environ["PFFFT_HIP_TILE_FORCE"].split(",")]
+assert pa.tile_plan(N, dt == "f64", 1) == want_plan, (pa.tile_plan(N, dt == "f64", 1), want_plan)   # (ADVICE r04: a plan with a leading "g" length was dropped silently)
 s = pa.Setup(N, pa.COMPLEX, dtype); rs = R.setup(N, pa.COMPLEX, dtype)
 g = torch.Generator(device="cuda"); g.manual_seed(7)
 x = torch.empty((5, 2 * N), device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64).uniform_(-1, 1, generator=g)
