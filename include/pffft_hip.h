@@ -140,6 +140,18 @@ int pffftd_hip_zreorder_batch(PFFFTD_Setup *, const double *in, double *out, siz
 int pffftd_hip_zconvolve_batch(PFFFTD_Setup *, const double *a, const double *b, double *ab, double scaling,
                                size_t batch, int accumulate, int b_broadcast, void *stream);
 
+/* Batch shards over several devices from ONE host thread (round 5; SURVEY.md 8(e): the batch shards with no exchange step).  Part p -
+ * batches[p] vectors at in[p] / out[p], device memory of devices[p] - is transformed by setups[p] on devices[p]: hipSetDevice, then the
+ * batched entry on streams[p] (streams == NULL or streams[p] == NULL: that device's default stream).  Every launch is asynchronous, so the
+ * devices work concurrently; the caller's current device is restored before the call returns.  A setup binds to the device of its first
+ * transform (above): pass ONE SETUP PER DEVICE (the plan is a few KiB; creating a setup needs no device).  Returns the first error, 0
+ * when every part is enqueued.  The reference has no counterpart: one of its setups serves any number of threads of one CPU
+ * (include/pffft/pffft.h:102-105). */
+int pffft_hip_transform_batch_multi(int nparts, const int *devices, PFFFT_Setup *const *setups, const float *const *in, float *const *out,
+                                    const size_t *batches, pffft_direction_t direction, int ordered, void *const *streams);
+int pffftd_hip_transform_batch_multi(int nparts, const int *devices, PFFFTD_Setup *const *setups, const double *const *in, double *const *out,
+                                     const size_t *batches, pffft_direction_t direction, int ordered, void *const *streams);
+
 /* Spectral convolution in one call (round 4):   out[i] (+)= backward( forward(in[i]) . H[i or 0] ) * scaling
  * - the sequence pffft_transform(FORWARD), pffft_zconvolve_no_accu, pffft_transform(BACKWARD) of every FFT convolution
  * (src/pffft_priv_impl.h:1465-1532, :1632-1684; src/pffastconv.c:235-254 is one instance), with `in` / `out` in the TIME domain

@@ -1703,6 +1703,37 @@ struct PFFFTD_Setup : pf::Setup {};
         return pf::convolve_batch<T>(s, in, H, out, sc, batch, accumulate, h_broadcast, (hipStream_t)stream);       \
     }
 
+// Batch shards over several devices from ONE host thread (independent units, no exchange step): part p is transformed by
+// setups[p] on devices[p] - hipSetDevice, then the batched entry on streams[p] (NULL: that device's default stream); every launch is
+// asynchronous, so the devices run concurrently.  The caller's current device is restored.  A setup binds to the device of its first
+// transform: setups[p] must be a setup of its own per device.  Returns the first error (0 = all enqueued).
+template <typename T, typename SETUP>
+static int transform_batch_multi(int nparts, const int* devices, SETUP* const* setups, const T* const* in, T* const* out, const size_t* batches,
+                                 int dir, int ordered, void* const* streams) {
+    if (nparts < 0 || (nparts > 0 && (!devices || !setups || !in || !out || !batches))) {
+        pf::g_last_error = "pffft_hip: transform_batch_multi needs devices, setups, in, out and batches";
+        return (int)hipErrorInvalidValue;
+    }
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    int rc = 0;
+    for (int p = 0; p < nparts && !rc; ++p) {
+        hipError_t e = hipSetDevice(devices[p]);
+        if (e != hipSuccess) { rc = pf::fail(e, "hipSetDevice"); break; }
+        rc = pf::transform_batch<T>(setups[p], in[p], out[p], batches[p], dir, ordered, (hipStream_t)(streams ? streams[p] : nullptr));
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
+PF_EXPORT int pffft_hip_transform_batch_multi(int nparts, const int* devices, PFFFT_Setup* const* setups, const float* const* in, float* const* out,
+                                              const size_t* batches, pffft_direction_t d, int ordered, void* const* streams) {
+    return transform_batch_multi<float, PFFFT_Setup>(nparts, devices, setups, in, out, batches, (int)d, ordered, streams);
+}
+PF_EXPORT int pffftd_hip_transform_batch_multi(int nparts, const int* devices, PFFFTD_Setup* const* setups, const double* const* in, double* const* out,
+                                               const size_t* batches, pffft_direction_t d, int ordered, void* const* streams) {
+    return transform_batch_multi<double, PFFFTD_Setup>(nparts, devices, setups, in, out, batches, (int)d, ordered, streams);
+}
+
 PF_DEFINE_API(pffft, PFFFT_Setup, float, 0, "HIP-gfx950")
 PF_DEFINE_API(pffftd, PFFFTD_Setup, double, 1, "HIP-gfx950")
 

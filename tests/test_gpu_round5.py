@@ -273,3 +273,44 @@ def test_fastconv_first_use_from_two_streams(ref):
         assert na == nw and nb == nw
         assert np.abs(ya.cpu().numpy() - yw).max() <= lim and np.abs(yb.cpu().numpy() - yw).max() <= lim, rep
         fc.close()
+
+
+# ------------------------------------------------------------------ one host thread, several parts / devices (C-level sharding)
+def test_transform_batch_multi_from_one_thread(ref):
+    """pffft_hip_transform_batch_multi: batch shards driven from ONE host thread - per part hipSetDevice + the batched entry on its own
+    setup and stream.  A 1-GPU box has one device: three parts on device 0 (three setups, three streams, ragged shard sizes) must equal the
+    one-call result bit for bit and meet the reference; a device that does not exist is an error, not a fault; the current device is
+    restored."""
+    import ctypes as C
+    from conftest import relerr
+    L = pa.lib()
+    L.pffft_hip_transform_batch_multi.restype = C.c_int
+    N, B = 1024, 3000
+    x = _uniform((B, 2 * N), 21)
+    whole = pa.Setup(N, pa.COMPLEX)
+    want = whole.transform_batch(x, None, pa.FORWARD, False)
+    torch.cuda.synchronize()
+    cuts = [0, 1000, 1001, B]
+    setups = [pa.Setup(N, pa.COMPLEX) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    y = torch.zeros_like(x)
+    devs = (C.c_int * 3)(0, 0, 0)
+    hs = (C.c_void_p * 3)(*[s.handle for s in setups])
+    ins = (C.c_void_p * 3)(*[x[cuts[i]:].data_ptr() for i in range(3)])
+    outs = (C.c_void_p * 3)(*[y[cuts[i]:].data_ptr() for i in range(3)])
+    bs = (C.c_size_t * 3)(*[cuts[i + 1] - cuts[i] for i in range(3)])
+    sts = (C.c_void_p * 3)(*[s.cuda_stream for s in streams])
+    rc = L.pffft_hip_transform_batch_multi(3, devs, hs, ins, outs, bs, pa.FORWARD, 0, sts)
+    assert rc == 0, pa.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
+    rs = ref.setup(N, pa.COMPLEX, np.float32)
+    assert relerr(y[[0, 1000, B - 1]].cpu().numpy(), rs.batch(x[[0, 1000, B - 1]].cpu().numpy(), pa.FORWARD, False)) <= 1e-5
+    bad = (C.c_int * 1)(97)
+    assert L.pffft_hip_transform_batch_multi(1, bad, hs, ins, outs, bs, pa.FORWARD, 0, None) != 0
+    assert torch.cuda.current_device() == 0
+    whole.transform_batch(x[:4].contiguous(), None, pa.FORWARD, True)     # the library still works on the restored device
+    torch.cuda.synchronize()
+    for s in setups + [whole]:
+        s.close()
+    rs.close()
