@@ -1719,7 +1719,7 @@ static int transform_batch_multi(int nparts, const int* devices, SETUP* const* s
     int rc = 0;
     for (int p = 0; p < nparts && !rc; ++p) {
         hipError_t e = hipSetDevice(devices[p]);
-        if (e != hipSuccess) { rc = pf::fail(e, "hipSetDevice"); break; }
+        if (e != hipSuccess) { (void)hipGetLastError(); rc = pf::fail(e, "hipSetDevice"); break; }   // (the runtime's sticky error is consumed here: the next launch checks it)
         rc = pf::transform_batch<T>(setups[p], in[p], out[p], batches[p], dir, ordered, (hipStream_t)(streams ? streams[p] : nullptr));
     }
     if (prev >= 0) (void)hipSetDevice(prev);

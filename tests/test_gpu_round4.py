@@ -315,7 +315,7 @@ print("FORCED-OK")
 
 
 @pytest.mark.parametrize("dt,N,plan", [("f32", 10800, "108,100"), ("f32", 10800, "60,180"), ("f32", 10800, "270,40"), ("f32", 10800, "120,90"),
-                                       ("f32", 11664, "162g,72g"), ("f64", 10800, "135,80"), ("f64", 10800, "40,270"), ("f64", 50000, "125,400"),
+                                       ("f32", 11664, "162g,72g"), ("f64", 10800, "135g,80g"), ("f64", 10800, "40,270"), ("f64", 50000, "125g,400g"),
                                        ("f64", 18000, "225,80g")])
 def test_runtime_tile_plans_forced_lengths(dt, N, plan):
     """The short tile lengths (128 / 256 / 512-thread workgroups, radices 2 .. 12, ragged last tiles of 2 .. 14 sequences, odd lengths in
