@@ -59,7 +59,9 @@ struct StockPlan {
                      // products deep); 1: base twiddle from the global W_n^j table, powers recomputed
     int ctab;        // entries of the compact table
     int ibs;         // scalars per padded 32-scalar block of the internal-layout image (36 float / 34 double; 32 when LDS is tight)
-    int twr_lds;     // W_N^k table of the real pair pass in LDS
+    int twr_lds;     // W_N^k of the real pair pass: 1 = the whole table (n/2 + 1 entries) in LDS; 2 = two small tables in LDS,
+                     // W_N^k = W_N^(k mod 64) W_N^(k - k mod 64) (64 + n/128 + 1 entries, one product per pair: where the whole
+                     // table does not fit next to the images); 0 = read from the global table (L2) per pair
     int C, P;        // compute threads, producer wavefronts (blockDim = C + 64 P)
     unsigned m_n4, m_per, m_nchk;  // magic multipliers for n/4, n/2 + 1, 16-byte chunks per vector
     int sym, sym_items; unsigned m_sym; // real transforms: symmetric spectrum-side stage (pairs in registers) with (nb + 1) / 2
@@ -74,7 +76,8 @@ template <typename T> __host__ __device__ constexpr StockLds<T> stock_lds(const 
     l.buf = o; o += (size_t)2 * p.G * p.img * sizeof(cx<T>);
     l.tab = o; if (p.twmode == 0) o += ((size_t)p.n + (p.n >> 5) + 1) * sizeof(cx<T>);
     if (p.twmode == 2) o += (size_t)(p.ctab + 1) * sizeof(cx<T>);
-    l.twr = o; if (p.twr_lds) o += ((size_t)p.n / 2 + 1) * sizeof(cx<T>);
+    l.twr = o; if (p.twr_lds == 1) o += ((size_t)p.n / 2 + 1) * sizeof(cx<T>);
+    if (p.twr_lds == 2) o += ((size_t)64 + p.n / 128 + 2) * sizeof(cx<T>);
     l.next = o; o += 16;
     l.total = o;
     return l;
@@ -103,7 +106,7 @@ template <typename T> struct SkArgs {
     cx<T>* gdst;                 // vector 0 of the group (stride n)
     const cx<T>* twg;            // global W_n^j table (twmode 1; in twmode 2 the kernel is handed the compact table)
     // real transforms: W_N^k of the pair pass (LDS copy at twr_off, or the global table), work items of the symmetric stage
-    const cx<T>* twrg; int twr_off; bool twr_lds; int sym_items; unsigned m_sym; int cnt, maxcnt;
+    const cx<T>* twrg; int twr_off; int twr_lds; int sym_items; unsigned m_sym; int cnt, maxcnt;
 };
 
 __device__ __forceinline__ int tpad(int i) { return i + (i >> 5); }
@@ -262,11 +265,26 @@ __device__ __forceinline__ void sk_bfly(const StockStage& st, const SkArgs<T>& a
     dftR<R, FWD>(v);
 }
 
+// W_N^k of the pair pass, 0 <= k <= n/2 (StockPlan::twr_lds).  Mode 2: the sizes whose whole table does not fit next to the two
+// images (real N >= 15360 float, 7776 double) read it from L2 once per pair until round 5 - a dependent global load in the middle of
+// an LDS phase, the latency of which nothing covers: N = 17280 float real 0.46-0.52 against 0.76-0.78 for its complex core.
+template <typename T> __device__ __forceinline__ cx<T> sk_twr(const cx<T>* lds, int twr_off, int mode, const cx<T>* twrg, int k) {
+    if (mode == 1) return lds[twr_off + k];
+    if (mode == 2) return cmul(lds[twr_off + (k & 63)], lds[twr_off + 64 + (k >> 6)]);
+    cx<T> w = twrg[k];
+    asm volatile("");
+    return w;
+}
+template <typename T> __device__ __forceinline__ void sk_twr_fill(cx<T>* lds, int twr_off, int mode, const cx<T>* twrg, int n, int tid, int nthreads) {
+    if (mode == 1)
+        for (int i = tid; i <= n / 2; i += nthreads) lds[twr_off + i] = twrg[i];
+    if (mode == 2)
+        for (int i = tid; i < 64 + (n >> 7) + 1; i += nthreads) lds[twr_off + i] = twrg[i < 64 ? i : (i - 64) << 6];
+}
+
 template <typename T> __device__ __forceinline__ cx<T> sk_wN(const SkArgs<T>& a, int k) {   // W_N^k, 0 < k < n, N = 2n
     const int kk = 2 * k <= a.n ? k : a.n - k;
-    cx<T> w;
-    if (a.twr_lds) w = a.lds[a.twr_off + kk];
-    else { w = a.twrg[kk]; asm volatile(""); }
+    const cx<T> w = sk_twr<T>(a.lds, a.twr_off, a.twr_lds, a.twrg, kk);
     return 2 * k <= a.n ? w : mk<T>(-w.x, w.y);   // W_N^k = -conj(W_N^(n-k))
 }
 
@@ -487,7 +505,8 @@ template <bool WL> __device__ __forceinline__ void sk_sync() {
 template <typename T> struct SkCtx {
     cx<T>* lds;
     int bufsz, tab_off, twr_off;
-    bool in_int, out_int, bwd, real, twr_lds;
+    bool in_int, out_int, bwd, real;
+    int twr_lds;
     const cx<T>* twg;
     const cx<T>* twrg;
 };
@@ -558,9 +577,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
             } else if (k == half) {
                 pd[half] = mk<T>((T)2 * A.x, (T)2 * A.y);  // conj(2 conj(A))
             } else {
-                CX wk;
-                if (c.twr_lds) wk = lds[c.twr_off + k];
-                else { wk = c.twrg[k]; asm volatile(""); }
+                const CX wk = sk_twr<T>(lds, c.twr_off, c.twr_lds, c.twrg, k);
                 const CX S = add_conj(A, Bn), Dm = cmulc(sub_conj(A, Bn), wk);   // B = conj(Bn); D = i Dm rides on the add
                 pd[k] = conj(add_rot<BWD>(S, Dm));
                 pd[n - k] = sub_rot<BWD>(S, Dm);  // conj(conj(S - D))
@@ -638,9 +655,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
                 Xb = Xa;
             } else {
                 const CX A = ps[k], Bn = ps[n - k];
-                CX wk;
-                if (c.twr_lds) wk = lds[c.twr_off + k];
-                else { wk = c.twrg[k]; asm volatile(""); }
+                const CX wk = sk_twr<T>(lds, c.twr_off, c.twr_lds, c.twrg, k);
                 const CX S = add_conj(A, Bn) * (T)0.5, Dm = cmul(sub_conj(A, Bn) * (T)0.5, wk);   // B = conj(Bn); D = -i Dm rides on the add
                 Xa = add_rot<FWD>(S, Dm);
                 Xb = conj(sub_rot<FWD>(S, Dm));
@@ -764,7 +779,7 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
     c.tab_off = (int)(L.tab / sizeof(CX)); c.twr_off = (int)(L.twr / sizeof(CX));
     c.in_int = flags & 1; c.out_int = flags & 2; c.bwd = flags & 4; c.real = flags & 8;
     c.twg = twg; c.twrg = twrg;
-    c.twr_lds = p.twr_lds && c.real;
+    c.twr_lds = c.real ? p.twr_lds : 0;
     unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + L.next);
     const int n = p.n, G = p.G, ns = p.ns, C = p.C;
     const int tid = threadIdx.x, nthreads = p.C + 64 * p.P;
@@ -772,8 +787,7 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
         for (int i = tid; i < n; i += nthreads) lds[c.tab_off + tpad(i)] = twg[i];
     if (p.twmode == 2)
         for (int i = tid; i < p.ctab; i += nthreads) lds[c.tab_off + i] = twg[i];
-    if (c.twr_lds)
-        for (int i = tid; i <= n / 2; i += nthreads) lds[c.twr_off + i] = twrg[i];
+    sk_twr_fill<T>(lds, c.twr_off, c.twr_lds, twrg, n, tid, nthreads);
     const int nchk = (int)((size_t)n * sizeof(CX) / 16);
     const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);
     // LDS-writing compute phases per iteration (each followed by one barrier); + the closing barrier
@@ -875,7 +889,7 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
     c.tab_off = (int)(L.tab / sizeof(CX)); c.twr_off = (int)(L.twr / sizeof(CX));
     c.in_int = flags & 1; c.out_int = flags & 2; c.bwd = flags & 4; c.real = flags & 8;
     c.twg = twg; c.twrg = twrg;
-    c.twr_lds = p.twr_lds && c.real;
+    c.twr_lds = c.real ? p.twr_lds : 0;
     unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + L.next);
     const int n = p.n, G = p.G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -884,8 +898,7 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
         for (int i = tid; i < n; i += 64 * SK_WL_WAVES) lds[c.tab_off + tpad(i)] = twg[i];
     if (p.twmode == 2)
         for (int i = tid; i < p.ctab; i += 64 * SK_WL_WAVES) lds[c.tab_off + i] = twg[i];
-    if (c.twr_lds)
-        for (int i = tid; i <= n / 2; i += 64 * SK_WL_WAVES) lds[c.twr_off + i] = twrg[i];
+    sk_twr_fill<T>(lds, c.twr_off, c.twr_lds, twrg, n, tid, 64 * SK_WL_WAVES);
     const int nchk = (int)((size_t)n * sizeof(CX) / 16);
     const int img16 = (int)((size_t)p.img * sizeof(CX) / 16);
     const StockStage st0 = p.st[0], st1 = p.st[1], st2 = p.st[2], st3 = p.st[3];
@@ -988,7 +1001,7 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, co
     c.tab_off = (int)(L.tab / sizeof(CX)); c.twr_off = (int)(L.twr / sizeof(CX));
     c.in_int = false; c.out_int = flags & 2; c.bwd = flags & 4; c.real = flags & 8;
     c.twg = twg; c.twrg = twrg;
-    c.twr_lds = p.twr_lds && c.real;
+    c.twr_lds = c.real ? p.twr_lds : 0;
     constexpr int n = p.n, G = p.G, R0 = p.st[0].R, nb0 = p.st[0].nb, wblk0 = p.st[0].wblk;
     constexpr int NT = sk_df_threads(p, flags, WL);         // threads of the workgroup
     constexpr int W = WL ? 64 : NT;                        // threads of one worker (a wavefront / the workgroup)
@@ -1008,8 +1021,7 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, co
         for (int i = tid; i < n; i += NT) lds[c.tab_off + tpad(i)] = twg[i];
     if (p.twmode == 2)
         for (int i = tid; i < p.ctab; i += NT) lds[c.tab_off + i] = twg[i];
-    if (c.twr_lds)
-        for (int i = tid; i <= n / 2; i += NT) lds[c.twr_off + i] = twrg[i];
+    sk_twr_fill<T>(lds, c.twr_off, c.twr_lds, twrg, n, tid, NT);
     const StockStage st0 = p.st[0], st1 = p.st[1], st2 = p.st[2], st3 = p.st[3];
     const CX* gin = reinterpret_cast<const CX*>(in);
     const bool cj = c.bwd && !c.real;
@@ -1053,9 +1065,7 @@ __device__ __forceinline__ void sk_df_body(const T* in, T* out, size_t batch, co
                     } else if (k == half) {
                         pd[half] = mk<T>((T)2 * A.x, (T)2 * A.y);
                     } else {
-                        CX wk;
-                        if (c.twr_lds) wk = lds[c.twr_off + k];
-                        else { wk = twrg[k]; asm volatile(""); }
+                        const CX wk = sk_twr<T>(lds, c.twr_off, c.twr_lds, twrg, k);
                         const CX S = add_conj(A, pb[r]), Dm = cmulc(sub_conj(A, pb[r]), wk);   // B = conj(pb); D = i Dm rides on the add
                         pd[k] = conj(add_rot<BWD>(S, Dm));
                         pd[n - k] = sub_rot<BWD>(S, Dm);

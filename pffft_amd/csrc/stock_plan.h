@@ -196,7 +196,16 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         // symmetric spectrum-side stage (mirror pairs in registers instead of a pair phase): pays only for the largest
         // real transforms (N = 16384 float: 0.57 -> 0.67; below, the two butterflies per work item cost occupancy and,
         // for small n/R, the coalescing of the stores: N = 96 .. 12000 measured 0.06 - 0.58 against 0.52 - 0.67)
-        const bool sym = real && (size_t)n * esz >= 64 * 1024;
+        // ... and only where that stage's radix (sk_order: the smallest multiple of 4 from 8) is 8: a work item holds TWO butterflies, and with
+        // radix 12 the kernels spill (-Rpass-analysis=kernel-resource-usage: n = 8640 float 72-96 B of scratch per lane at 128 VGPRs, n = 4320
+        // double 160-276 B at 168) - N = 17280 float 0.56 / 0.52 / 0.64 / 0.50 -> 0.62 / 0.63 / 0.66 / 0.65 on the separate pair phase, N = 8640
+        // double 0.50 / 0.45 / 0.68 / 0.47 -> 0.70 / 0.65 / 0.72 / 0.72 (round 5; a plan with a radix 8 for that stage, 15 12 6 8: 0.61 / 0.43 / 0.64 / 0.65)
+        bool sym = real && (size_t)n * esz >= 64 * 1024;
+        if (sym) {
+            int symr = 0;
+            for (int q : best) if (q % 4 == 0 && q >= 8 && (!symr || q < symr)) symr = q;
+            sym = symr == 8;
+        }
         const std::vector<int> r = sk_order(best, dir == 1, sym);
         p.n = n; p.ns = (int)r.size(); p.G = G; p.C = threads; p.P = P;
         int Ns = 1, img = n, prevpad = 0, ctab = 0;
@@ -243,10 +252,13 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         // (mode 1 - base twiddles from the global table - is kept for A/B only: the L2 latency per stage cost
         //  n = 4000 float 0.60 -> 0.50 although it doubled the resident workgroups)
         p.twmode = n < 512 ? 0 : 2;
-        p.twr_lds = (want_twr && p.twmode != 1) ? 1 : 0;
+        // pair-pass twiddles W_N^k (real): the whole table in LDS where it fits, else two small tables and one product per pair
+        // (fft_stock.h sk_twr; round 5 - from L2 until then), from L2 only if not even those fit
+        p.twr_lds = !real ? 0 : (want_twr && p.twmode != 1) ? 1 : n >= 256 ? 2 : 0;
         auto total = [&]() { return is_double ? stock_lds<double>(p).total : stock_lds<float>(p).total; };
         size_t tot = total();
-        if (tot > lds_max && p.twr_lds) { p.twr_lds = 0; tot = total(); }   // pair-pass twiddles from L2 instead
+        if (tot > lds_max && p.twr_lds == 1) { p.twr_lds = n >= 256 ? 2 : 0; tot = total(); }
+        if (tot > lds_max && p.twr_lds == 2) { p.twr_lds = 0; tot = total(); }
         if (tot > lds_max && p.twmode != 1) { p.twmode = 1; tot = total(); }
         if (tot > lds_max) return false;
     }
