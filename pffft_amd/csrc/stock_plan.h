@@ -200,7 +200,11 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
         // radix 12 the kernels spill (-Rpass-analysis=kernel-resource-usage: n = 8640 float 72-96 B of scratch per lane at 128 VGPRs, n = 4320
         // double 160-276 B at 168) - N = 17280 float 0.56 / 0.52 / 0.64 / 0.50 -> 0.62 / 0.63 / 0.66 / 0.65 on the separate pair phase, N = 8640
         // double 0.50 / 0.45 / 0.68 / 0.47 -> 0.70 / 0.65 / 0.72 / 0.72 (round 5; a plan with a radix 8 for that stage, 15 12 6 8: 0.61 / 0.43 / 0.64 / 0.65)
-        bool sym = real && (size_t)n * esz >= 64 * 1024;
+        // (round 5, once the spills were out of the way - every real plan with a radix 8 built with the symmetric stage and measured, A/B on one box:
+        //  float backward - the stage is the FIRST one there and replaces the pair pre-pass - gains from 31 KiB vectors on (N = 7776 +0.04 / +0.01,
+        //  15360 0.61 / 0.69 -> 0.74 / 0.74, 16000 0.60 / 0.64 -> 0.71 / 0.69), float forward from 50 KiB (N = 13824 +0.03, else +-0.01; below:
+        //  N = 2304 ... 6912 -0.03 ... -0.17); double loses below 64 KiB in both directions, N = 7680 / 7776 -0.11)
+        bool sym = real && !wl && (size_t)n * esz >= (is_double ? 64 * 1024 : dir == 1 ? 31000 : 50 * 1024);
         if (sym) {
             int symr = 0;
             for (int q : best) if (q % 4 == 0 && q >= 8 && (!symr || q < symr)) symr = q;
