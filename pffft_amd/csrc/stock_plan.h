@@ -173,6 +173,17 @@ static bool sk_build(int n, bool is_double, bool real, StockPlan out[2], int* th
     int G, P = 0, threads;
     if (wl) {
         const int Gw = std::max(1, 4096 / (n * esz));
+        // a stage's work items per wavefront are Gw n / R: double n = 144 as 12 x 12 kept 12 of 64 lanes busy (complex 0.58 / 0.59 / 0.68 / 0.66, real
+        // N = 288 0.52 / 0.51 / 0.61 / 0.57 - the one LDS-resident double entry below 0.55, round 5): below 16 items, the plan with the fewest stages
+        // whose radices leave at least 16 (4 x 6 x 6: 36 / 24 / 24)
+        int maxr = 0;
+        for (int r : best) maxr = std::max(maxr, r);
+        if (Gw * (n / maxr) < 16) {
+            std::vector<int> set2, cur2, best2;
+            for (int r : (is_double ? setd : setf)) if (Gw * (n / r) >= 16) set2.push_back(r);
+            sk_search(n, 0, set2, cur2, best2);
+            if (best2.size() >= 2 && best2.size() <= (size_t)SK_MAX_STAGES) best = best2;
+        }
         G = 4 * Gw;
         threads = 256;
     } else {
