@@ -98,6 +98,7 @@ template <typename T> struct SkArgs {
     unsigned m_n4;
     int img;                     // slot stride of the LDS images (complex points)
     int twmode, ibs;
+    bool iswz;                   // internal-layout image: unpadded blocks with swizzled groups (sk_igrp)
     bool cj_in, cj_out;          // conjugate on the way in (first stage) / out (HBM store): backward transform
     // LDS is addressed as (one base pointer) + integer offsets: a pointer selected between the two images or
     // between an LDS and a global table becomes a generic pointer and every access a FLAT instruction
@@ -110,6 +111,24 @@ template <typename T> struct SkArgs {
 };
 
 __device__ __forceinline__ int tpad(int i) { return i + (i >> 5); }
+
+// The internal-layout image: blocks of 32 scalars = eight groups of 4 [quarter qq of the spectrum: real parts in group 2 qq, imaginary parts in
+// 2 qq + 1], a block padded to ibs scalars (36 float / 34 double) so that the scalar scatter - four lanes per block, sixteen blocks per wavefront -
+// walks the banks.  Where LDS has no room for the padding (ibs == 32: n = 7200 ... 10000 float, 4608 double; sk_iswz) every lane of such an access met the
+// same four banks until round 5 (complex n = 9216 float forward 0.75 ordered, 0.65 unordered); there the groups of block b now sit at group ^ (b & 7).
+__device__ __forceinline__ int sk_igrp(int ibs, bool swz, int blk, int grp) { return ibs * blk + 4 * (swz ? (grp ^ (blk & 7)) : grp); }
+// ... and the imaginary part of a scalar whose real part sits at ire: the next group - under the swizzle the group index with bit 0 flipped
+__device__ __forceinline__ int sk_iim(bool swz, int ire) { return swz ? (ire ^ 4) : ire + 4; }
+// (not for the one double plan that also reads its stage twiddles from L2 - n = 4800, LDS filled to the last KiB, 168 VGPRs: the index arithmetic of the
+//  swizzle costs it 40 B more scratch per lane and 0.04-0.05, measured)
+template <typename T> __host__ __device__ constexpr bool sk_iswz(const StockPlan& p) { return p.ibs == 32 && !(sizeof(T) == 8 && p.twmode == 1); }
+// linear 16-byte chunk cc of the layout -> chunk offset inside the block image
+template <typename T> __device__ __forceinline__ int sk_ichunk(int cc, int ibs, bool swz) {
+    constexpr int CH = 16 / (int)sizeof(T), CPB = 32 / CH, GPC = 4 / CH;   // scalars per chunk, chunks per block, chunks per group of 4 scalars
+    const int b = cc / CPB, c = cc % CPB;
+    const int cs = swz ? (((c / GPC) ^ (b & 7)) * GPC + c % GPC) : c;
+    return b * (ibs / CH) + cs;
+}
 
 template <typename T, int R, int SRC, int DST>
 __device__ __forceinline__ void sk_stage(const StockStage& st, const SkArgs<T>& a) {
@@ -136,8 +155,8 @@ __device__ __forceinline__ void sk_stage(const StockStage& st, const SkArgs<T>& 
                 int qq, r;
                 if constexpr (R % 4 == 0) { qq = q / (R / 4); r = j + (q % (R / 4)) * st.nb; }
                 else { const int P = j + q * st.nb; qq = udiv(P, a.m_n4); r = P - qq * n4; }
-                const int ip = IBS * (r >> 2) + 8 * qq + (r & 3);
-                v[q] = mk<T>(p[ip], p[ip + 4]);
+                const int ip = sk_igrp(IBS, a.iswz, r >> 2, 2 * qq) + (r & 3);
+                v[q] = mk<T>(p[ip], p[sk_iim(a.iswz, ip)]);
             }
         }
         if (a.cj_in) {
@@ -212,9 +231,9 @@ __device__ __forceinline__ void sk_stage(const StockStage& st, const SkArgs<T>& 
                 int qq, r;
                 if constexpr (R % 4 == 0) { qq = d / (R / 4); r = j + (d % (R / 4)) * st.nb; }
                 else { const int P = j + d * st.nb; qq = udiv(P, a.m_n4); r = P - qq * n4; }
-                const int ip = IBS * (r >> 2) + 8 * qq + (r & 3);
+                const int ip = sk_igrp(IBS, a.iswz, r >> 2, 2 * qq) + (r & 3);
                 p[ip] = v[d].x;
-                p[ip + 4] = v[d].y;
+                p[sk_iim(a.iswz, ip)] = v[d].y;
             }
         }
     }
@@ -222,10 +241,17 @@ __device__ __forceinline__ void sk_stage(const StockStage& st, const SkArgs<T>& 
 
 // scalar index (real part; imaginary part + 4) of half-complex bin k of a REAL transform inside the
 // internal-layout image: odd quarters run backwards (bin_of, fft_generic.h)
+// (padded block images only, ibs != 32 - fft_aux.h: the imaginary part sits 4 scalars behind the real part)
 template <typename T> __device__ __forceinline__ int sk_iposr(int k, int n4, unsigned m_n4, int ibs) {
     const int qq = udiv(k, m_n4), r = k - qq * n4;
     const int tt = (qq & 1) ? (r ? n4 - r : 0) : r;
     return ibs * (tt >> 2) + 8 * qq + (tt & 3);
+}
+template <typename T> __device__ __forceinline__ void sk_iposr(int k, int n4, unsigned m_n4, int ibs, bool swz, int& ire, int& iim) {
+    const int qq = udiv(k, m_n4), r = k - qq * n4;
+    const int tt = (qq & 1) ? (r ? n4 - r : 0) : r;
+    ire = sk_igrp(ibs, swz, tt >> 2, 2 * qq) + (tt & 3);
+    iim = sk_iim(swz, ire);
 }
 
 // operands of butterfly j of a stage whose source is an LDS image, twiddled and transformed (the body of sk_stage)
@@ -318,8 +344,9 @@ __device__ __forceinline__ void sk_last_real(const StockStage& st, const SkArgs<
                 __builtin_nontemporal_store(X, a.gdst + (size_t)g * n + k);
             } else {
                 T* pd = reinterpret_cast<T*>(a.lds + a.dst_off + g * a.img);
-                const int ip = sk_iposr<T>(k, n4, a.m_n4, a.ibs);
-                pd[ip] = X.x; pd[ip + 4] = X.y;
+                int ire, iim;
+                sk_iposr<T>(k, n4, a.m_n4, a.ibs, a.iswz, ire, iim);
+                pd[ire] = X.x; pd[iim] = X.y;
             }
         };
         if (it) {
@@ -376,8 +403,9 @@ __device__ __forceinline__ void sk_first_real(const StockStage& st, const SkArgs
                 return a.lds[a.src_off + g * a.img + k];
             } else {
                 const T* ps = reinterpret_cast<const T*>(a.lds + a.src_off + g * a.img);
-                const int ip = sk_iposr<T>(k, n4, a.m_n4, a.ibs);
-                return mk<T>(ps[ip], ps[ip + 4]);
+                int ire, iim;
+                sk_iposr<T>(k, n4, a.m_n4, a.ibs, a.iswz, ire, iim);
+                return mk<T>(ps[ire], ps[iim]);
             }
         };
         // conj Z'[k] -> za, conj Z'[n-k] -> zb
@@ -527,11 +555,9 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
                                              int stid = -1, int sn = 0) {
     typedef cx<T> CX;
     typedef vec4<float> chunk16;
-    constexpr int CH = 16 / (int)sizeof(T), CPB = 32 / CH;
     // worker index / count of the phases that STORE TO HBM (sk_df_body: the wavefronts that hold prefetched loads never
     // store, so their s_waitcnt vmcnt for the loads does not wait for store acknowledgements); default: all of them
     if (sn == 0) { stid = wtid; sn = wn; }
-    const int BCH = p.ibs / CH;
     CX* const lds = c.lds;
     const int n = p.n, ns = p.ns, bufsz = c.bufsz;
     const int n4 = n >> 2, half = n >> 1, per = half + 1;
@@ -560,11 +586,12 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
             CX A, Bn;
             if (in_int) {
                 const T* ps = reinterpret_cast<const T*>(lds + (w ^ 1) * bufsz + g * p.img);
-                const int ia = sk_iposr<T>(k, n4, p.m_n4, p.ibs);
-                A = mk<T>(ps[ia], ps[ia + 4]);
+                int ire, iim;
+                sk_iposr<T>(k, n4, p.m_n4, p.ibs, sk_iswz<T>(p), ire, iim);
+                A = mk<T>(ps[ire], ps[iim]);
                 if (k != 0 && k != half) {
-                    const int ib = sk_iposr<T>(n - k, n4, p.m_n4, p.ibs);
-                    Bn = mk<T>(ps[ib], ps[ib + 4]);
+                    sk_iposr<T>(n - k, n4, p.m_n4, p.ibs, sk_iswz<T>(p), ire, iim);
+                    Bn = mk<T>(ps[ire], ps[iim]);
                 } else Bn = A;
             } else {
                 const CX* ps = lds + (w ^ 1) * bufsz + g * p.img;
@@ -589,7 +616,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
     // ---- stages (unrolled over the at most SK_MAX_STAGES stage structs held in SGPRs)
     {
         SkArgs<T> a;
-        a.tid = wtid; a.nthr = wn; a.slot0 = slot0; a.n = n; a.m_n4 = p.m_n4; a.img = p.img; a.twmode = p.twmode; a.ibs = p.ibs;
+        a.tid = wtid; a.nthr = wn; a.slot0 = slot0; a.n = n; a.m_n4 = p.m_n4; a.img = p.img; a.twmode = p.twmode; a.ibs = p.ibs; a.iswz = sk_iswz<T>(p);
         a.lds = lds; a.tab_off = c.tab_off; a.gdst = gout; a.twg = c.twg;
         a.cj_out = bwd;
         a.twrg = c.twrg; a.twr_off = c.twr_off; a.twr_lds = c.twr_lds; a.sym_items = p.sym_items; a.m_sym = p.m_sym;
@@ -662,11 +689,12 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
             }
             if (out_int) {
                 T* pd = reinterpret_cast<T*>(lds + w * bufsz + g * p.img);
-                const int ia = sk_iposr<T>(k, n4, p.m_n4, p.ibs);
-                pd[ia] = Xa.x; pd[ia + 4] = Xa.y;
+                int ire, iim;
+                sk_iposr<T>(k, n4, p.m_n4, p.ibs, sk_iswz<T>(p), ire, iim);
+                pd[ire] = Xa.x; pd[iim] = Xa.y;
                 if (k != 0 && k != half) {
-                    const int ib = sk_iposr<T>(n - k, n4, p.m_n4, p.ibs);
-                    pd[ib] = Xb.x; pd[ib + 4] = Xb.y;
+                    sk_iposr<T>(n - k, n4, p.m_n4, p.ibs, sk_iswz<T>(p), ire, iim);
+                    pd[ire] = Xb.x; pd[iim] = Xb.y;
                 }
             } else if (via_img) {
                 CX* pd = lds + w * bufsz + g * p.img;
@@ -690,7 +718,7 @@ __device__ __forceinline__ void sk_iteration(const StockPlan& p, const StockStag
             const int cc0 = cb + stid;
             if (cc0 >= cnt * nchk) continue;
             const int gl = udiv(cc0, p.m_nchk), cc = cc0 - gl * nchk, g = slot0 + gl;
-            chunk16 v = s16[g * img16 + (out_int ? (cc / CPB) * BCH + (cc % CPB) : cc)];
+            chunk16 v = s16[g * img16 + (out_int ? sk_ichunk<T>(cc, p.ibs, sk_iswz<T>(p)) : cc)];
             if (via_img && bwd) {
                 if constexpr (sizeof(T) == 4) { v.y = -v.y; v.w = -v.w; }
                 else {
@@ -754,10 +782,8 @@ struct SkSched {
 };
 
 // linear 16-byte chunk c of a group -> chunk offset inside the images (natural image, or internal-layout block image)
-template <typename T> __device__ __forceinline__ int sk_chunk_off(int g, int cc, int img16, bool in_int, int ibs) {
-    constexpr int CH = 16 / (int)sizeof(T), CPB = 32 / CH;
-    const int BCH = ibs / CH;
-    return g * img16 + (in_int ? (cc / CPB) * BCH + (cc % CPB) : cc);
+template <typename T> __device__ __forceinline__ int sk_chunk_off(int g, int cc, int img16, bool in_int, int ibs, bool swz) {
+    return g * img16 + (in_int ? sk_ichunk<T>(cc, ibs, swz) : cc);
 }
 
 // flags: bit0 input in internal layout, bit1 output in internal layout, bit2 backward, bit3 real
@@ -829,7 +855,7 @@ __device__ __forceinline__ void sk_wg_body(const T* in, T* out, size_t batch, co
                 const int cix = pl + NPT * i;
                 if (cix < tot) {
                     const int g = udiv(cix, p.m_nchk), cc = cix - g * nchk;
-                    d16[sk_chunk_off<T>(g, cc, img16, c.in_int, p.ibs)] = raw[i];
+                    d16[sk_chunk_off<T>(g, cc, img16, c.in_int, p.ibs, sk_iswz<T>(p))] = raw[i];
                 }
             }
         };
@@ -935,7 +961,7 @@ __device__ __forceinline__ void sk_wl_body(const T* in, T* out, size_t batch, co
             const int cix = lane + 64 * i;
             if (cix < tot) {
                 const int gl = udiv(cix, p.m_nchk), cc = cix - gl * nchk;
-                d16[sk_chunk_off<T>(slot0 + gl, cc, img16, c.in_int, p.ibs)] = raw[i];
+                d16[sk_chunk_off<T>(slot0 + gl, cc, img16, c.in_int, p.ibs, sk_iswz<T>(p))] = raw[i];
             }
         }
     };
