@@ -276,22 +276,25 @@ def test_fastconv_first_use_from_two_streams(ref):
 
 
 # ------------------------------------------------------------------ one host thread, several parts / devices (C-level sharding)
-def test_transform_batch_multi_from_one_thread(ref):
-    """pffft_hip_transform_batch_multi: batch shards driven from ONE host thread - per part hipSetDevice + the batched entry on its own
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_transform_batch_multi_from_one_thread(ref, dt):
+    """pffft[d]_hip_transform_batch_multi: batch shards driven from ONE host thread - per part hipSetDevice + the batched entry on its own
     setup and stream.  A 1-GPU box has one device: three parts on device 0 (three setups, three streams, ragged shard sizes) must equal the
     one-call result bit for bit and meet the reference; a device that does not exist is an error, not a fault; the current device is
     restored."""
     import ctypes as C
     from conftest import relerr
     L = pa.lib()
-    L.pffft_hip_transform_batch_multi.restype = C.c_int
+    dtype = np.float64 if dt == "f64" else np.float32
+    multi = L.pffftd_hip_transform_batch_multi if dt == "f64" else L.pffft_hip_transform_batch_multi
+    multi.restype = C.c_int
     N, B = 1024, 3000
-    x = _uniform((B, 2 * N), 21)
-    whole = pa.Setup(N, pa.COMPLEX)
+    x = _uniform((B, 2 * N), 21, torch.float64 if dt == "f64" else torch.float32)
+    whole = pa.Setup(N, pa.COMPLEX, dtype)
     want = whole.transform_batch(x, None, pa.FORWARD, False)
     torch.cuda.synchronize()
     cuts = [0, 1000, 1001, B]
-    setups = [pa.Setup(N, pa.COMPLEX) for _ in range(3)]
+    setups = [pa.Setup(N, pa.COMPLEX, dtype) for _ in range(3)]
     streams = [torch.cuda.Stream() for _ in range(3)]
     y = torch.zeros_like(x)
     devs = (C.c_int * 3)(0, 0, 0)
@@ -300,14 +303,14 @@ def test_transform_batch_multi_from_one_thread(ref):
     outs = (C.c_void_p * 3)(*[y[cuts[i]:].data_ptr() for i in range(3)])
     bs = (C.c_size_t * 3)(*[cuts[i + 1] - cuts[i] for i in range(3)])
     sts = (C.c_void_p * 3)(*[s.cuda_stream for s in streams])
-    rc = L.pffft_hip_transform_batch_multi(3, devs, hs, ins, outs, bs, pa.FORWARD, 0, sts)
+    rc = multi(3, devs, hs, ins, outs, bs, pa.FORWARD, 0, sts)
     assert rc == 0, pa.last_error()
     torch.cuda.synchronize()
     assert torch.equal(y, want)
-    rs = ref.setup(N, pa.COMPLEX, np.float32)
-    assert relerr(y[[0, 1000, B - 1]].cpu().numpy(), rs.batch(x[[0, 1000, B - 1]].cpu().numpy(), pa.FORWARD, False)) <= 1e-5
+    rs = ref.setup(N, pa.COMPLEX, dtype)
+    assert relerr(y[[0, 1000, B - 1]].cpu().numpy(), rs.batch(x[[0, 1000, B - 1]].cpu().numpy(), pa.FORWARD, False)) <= (1e-13 if dt == "f64" else 1e-5)
     bad = (C.c_int * 1)(97)
-    assert L.pffft_hip_transform_batch_multi(1, bad, hs, ins, outs, bs, pa.FORWARD, 0, None) != 0
+    assert multi(1, bad, hs, ins, outs, bs, pa.FORWARD, 0, None) != 0
     assert torch.cuda.current_device() == 0
     whole.transform_batch(x[:4].contiguous(), None, pa.FORWARD, True)     # the library still works on the restored device
     torch.cuda.synchronize()
