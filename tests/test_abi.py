@@ -182,6 +182,19 @@ def test_legacy_entries_fail_soft_without_a_device():
     assert p.returncode < 0 and "FAILSOFT-OK" not in p.stdout     # killed by SIGABRT: fail-fast on request only
 
 
+def test_transform_batch_multi_validates_its_arguments(L):
+    """pffft[d]_hip_transform_batch_multi (include/pffft_hip.h; round 5): no parts is a no-op, missing arrays are an error code with a
+    message - before any device is touched, so this runs without a GPU.  (The transforms themselves: tests/test_gpu_round5.py.)"""
+    for name in ("pffft_hip_transform_batch_multi", "pffftd_hip_transform_batch_multi"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        assert f(0, None, None, None, None, None, 0, 0, None) == 0
+        assert f(1, None, None, None, None, None, 0, 0, None) != 0
+        assert b"transform_batch_multi" in L.pffft_hip_last_error()
+        assert f(-1, None, None, None, None, None, 0, 0, None) != 0
+
+
 def test_legal_size_enumeration_matches_the_library():
     """tests/test_gpu_round3.py walks conftest.legal_sizes(): exactly what the drop-in's is_valid_size accepts, which is
     the reference's set (tests/test_fft_factors.c:36-61; the reference program itself runs in test_reference_programs)."""
