@@ -5,6 +5,7 @@
 #include "pf_host.h"
 #include "fft_dma.h"
 #include "fft_split.h"
+#include "fft_fir32.h"
 #include <cmath>
 
 namespace pf {
@@ -111,13 +112,53 @@ static int fir_split(Setup* ps, const float* d_Hc, const float* d_x, float* d_y,
     const size_t groups = (size_t)nblk * fb.nsig;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
-    const int xmode = (env().fir_xcd && groups < 0xfffffff0ull) ? 1 : 0;
+    // (the per-XCD ranges of the in-order case are pulled by the workgroups of that XCD only: every XCD needs one - ADVICE r05)
+    const int xmode = (env().fir_xcd && grid >= 8 && groups < 0xfffffff0ull) ? 1 : 0;
     unsigned* ctr = groups <= grid ? nullptr : take_counters(ps, st, xmode ? 5 : 1);   // (per-XCD counters: nine words)
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(S::WG), S::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
                        nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, tw1024, (const cx<float>*)ps->d_twr, ctr,
                        fb.nsig, fb.xstride, fb.ystride, xmode);
     PF_CHECK(hipGetLastError());
     return 0;
+}
+
+// 16384-sample blocks on 256 threads, 32 points per thread (fft_fir32.h).  hp_cache: the thread-major copy of the filter spectrum, built
+// once per filter - on the null stream and COMPLETE before the pointer is published, like every lazily built table - and owned by
+// the caller's pffastconv setup (hipFree)
+template <int PREF>
+static int fir32(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
+                 hipStream_t st, const FcBatch& fb, void** hp_cache) {
+    auto k = fastconv_fused32_kernel<PREF>;
+    int rc = allow_big_lds(k, Fir32::LDS_BYTES);
+    if (rc) return rc;
+    if (!*hp_cache) {
+        void* hp = nullptr;
+        PF_CHECK(hipMalloc(&hp, sizeof(float) * 2 * (size_t)Fir32::n));
+        hipLaunchKernelGGL(fir32_coef_kernel, dim3(1), dim3(Fir32::WG), 0, nullptr, (const cx<float>*)d_Hc, (vec4<float>*)hp);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) { (void)hipFree(hp); return fail(e, "fir32_coef_kernel"); }
+        *hp_cache = hp;
+    }
+    int per_cu = 0;
+    if ((rc = cached_occupancy(reinterpret_cast<const void*>(k), Fir32::WG, Fir32::LDS_BYTES, &per_cu))) return rc;
+    const size_t groups = (size_t)nblk * fb.nsig;
+    size_t grid = (size_t)num_cus() * per_cu;
+    if (grid > groups) grid = groups;
+    // (the per-XCD ranges need every XCD to have a workgroup: ADVICE r05)
+    const int xmode = (env().fir_xcd && grid >= 8 && groups < 0xfffffff0ull) ? 1 : 0;
+    unsigned* ctr = groups <= grid ? nullptr : take_counters(ps, st, xmode ? 5 : 1);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(Fir32::WG), Fir32::LDS_BYTES, st, d_x, d_y, (const vec4<float>*)*hp_cache,
+                       nblk, step, inputLen, lastOut, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, ctr,
+                       fb.nsig, fb.xstride, fb.ystride, xmode);
+    PF_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_fir32(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
+                 hipStream_t st, const FcBatch& fb, void** hp_cache, int pref) {
+    if (ps->n != Fir32::n) return -1;
+    return pref ? fir32<1>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, hp_cache)
+                : fir32<0>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, hp_cache);
 }
 
 // the overlap-save block kernel on a real setup of length Nfft = 2 ps->n; -1 when the size has no DMA kernel

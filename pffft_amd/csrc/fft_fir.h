@@ -107,7 +107,7 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     typename KF::Tw wf;
     typename KB::Tw wb;
     KF::load_tw(wf, t, twg, twrg);
-    KB::load_tw(wb, t, twg, twrg);
+    if constexpr (KB::REGTW) KB::template load_tw_stage<1>(wb, t, twg);   // (the pair twiddles W_N^k are those of the forward transform: one set, wf.p)
     // filter spectrum of the bins this thread owns after the forward transform: k = jm(t,u) + d n/R
     CX h[E];
 #pragma unroll
@@ -159,7 +159,7 @@ fastconv_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const 
             }
         }
         PF_STAMP(5);
-        KB::pair_regs(v, t, wb);                       // half-complex spectrum -> packed spectrum of the inverse
+        KB::pair_regs_p(v, t, wf.p);                   // half-complex spectrum -> packed spectrum of the inverse
         PF_STAMP(6);
         // ---- backward transform (first-stage operands are already in place) ----
         KB::template butterflies<0>(v, t, wb, twg);

@@ -118,6 +118,10 @@ struct FcBatch { int nsig; size_t xstride, ystride; };   // signals of one pffas
 int launch_fir_dma(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
                    hipStream_t st, const FcBatch& fb);
 
+// dma_tu.hip: 16384-sample FIR blocks on 256 threads with 32 points per thread (fft_fir32.h); -1: not this block length
+int launch_fir32(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
+                 hipStream_t st, const FcBatch& fb, void** hp_cache, int pref);
+
 // tile_real_tu.hip: REAL transforms beyond LDS in two sweeps (fft_tile.h RMODE): N real points -> canonical half spectrum through a
 // work buffer of tile_rfft_work_elems(N) complex elements per vector; -1: no plan for this length / direction
 int launch_tile_rfft(Setup* s, const void* in, void* work, void* out, size_t batch, long long N, int dir, hipStream_t st);

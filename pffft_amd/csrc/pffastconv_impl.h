@@ -30,6 +30,7 @@ struct FastConv {
     PFFFT_Setup* st_part = nullptr; float* d_Hp = nullptr; int part_P = 0;
     std::vector<float> h_td;  // y[m] = sum_i h_td[i] x[m + i]: the filter as the time-domain kernel applies it (zero padded to 8)
     float* d_td = nullptr;
+    void* d_fir32_hp = nullptr;    // thread-major filter spectrum of the 32-points-per-thread block kernel (fft_fir32.h), of d_Hc_big
     void* d_split1_ab = nullptr;   // folded per-bin coefficients of the few-block split kernel (fft_split.h), built on first use
     // work image of the composed path: one per stream (two streams running one setup must not share scratch)
     struct Work { float* p = nullptr; size_t floats = 0; unsigned long long last_use = 0; bool captured = false; };   // captured: pf_host.h Scratch
@@ -235,6 +236,7 @@ static int fc_ensure_big(FastConv* s, int Nfft_big) {
     if (s->Nfft_big == Nfft_big) return 0;
     if (s->st_big) { pffft_destroy_setup(s->st_big); s->st_big = nullptr; }
     if (s->d_Hc_big) { (void)hipFree(s->d_Hc_big); s->d_Hc_big = nullptr; }
+    if (s->d_fir32_hp) { (void)hipFree(s->d_fir32_hp); s->d_fir32_hp = nullptr; }
     s->Nfft_big = 0;
     s->st_big = pffft_new_setup(Nfft_big, PFFFT_REAL);
     if (!s->st_big) { g_last_error = "pffastconv: internal setup failed"; return (int)hipErrorInvalidValue; }
@@ -433,6 +435,10 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
             const int blast = (int)(produced - (long)(bblk - 1) * bstep);
             // 16384-sample blocks: the LDS-DMA staged split kernel (fft_split.h; the lock-step one it replaced: development build).  Shorter
             // internal blocks: the register-staged fused kernel (tools/dma_ab.py: a tie with the DMA kernel at Nfft 8192, 0.22-0.29 both)
+            if (nbig == 16384 && (sel.is(AB_FIR_FUSED32) || sel.is(AB_FIR_FUSED32_NOPF))) {
+                rc = launch_fir32(s->st_big, s->d_Hc_big, d_x, d_y, bblk, bstep, inputLen, blast, st, fb, &s->d_fir32_hp, sel.is(AB_FIR_FUSED32));
+                if (rc != -1) return rc;
+            }
             if (nbig == 16384) {
                 rc = launch_fir_dma(s->st_big, s->d_Hc_big, d_x, d_y, bblk, bstep, inputLen, blast, st, fb);
                 if (rc != -1) return rc;
@@ -580,6 +586,7 @@ PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
     for (auto& kv : s->work) if (kv.second.p) (void)hipFree(kv.second.p);
     for (float* p : s->retired) if (p) (void)hipFree(p);
     if (s->d_split1_ab) (void)hipFree(s->d_split1_ab);
+    if (s->d_fir32_hp) (void)hipFree(s->d_fir32_hp);
     for (float* p : {s->h_x, s->h_y}) if (p) (void)hipHostFree(p);
     s->magic = 0;
     delete s;

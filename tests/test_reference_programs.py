@@ -69,10 +69,24 @@ def test_pffastconv_program(args):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog", ["example_c_real_flt_fwd", "example_c_cplx_dbl_fwd", "example_cpp98_real_flt_fwd",
-                                  "example_cpp11_cplx_dbl_fwd"])
+                                  "example_cpp11_cplx_dbl_fwd", "example_cpp98_cplx_flt_fwd", "example_cpp11_real_dbl_fwd"])
 def test_examples(prog):
+    """All six programs of the reference's examples/ directory (examples/CMakeLists.txt)."""
     rc, out = _run(prog)
     assert rc == 0, out[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,args", [("test_pffastconv", ("--no-len", "--quick", "--sym")),       # ctest bench_pfconv_symetric
+                                       ("test_pffastconv", ("--no-len", "--quick")),                # ctest bench_pfconv_non_sym
+                                       ("bench_pffft_float", ("--max-len", "128", "--quick")),      # ctest bench_pffft_pow2
+                                       ("bench_pffft_float", ("--non-pow2", "--max-len", "192", "--quick"))])   # ctest bench_pffft_non2
+def test_reference_bench_mode_ctest_lines(prog, args):
+    """The four bench-mode lines of the reference's ctest list (tests/CMakeLists.txt:144-161): the programs time themselves with
+    clock() and assert nothing upstream beyond their exit code; here they run the legacy host-pointer entries of the drop-in
+    (one launch + one synchronisation per call: the rates they print are the PCIe / launch-inclusive ones of include/pffft_hip.h)."""
+    rc, out = _run(prog, *args, timeout=1800)
+    assert rc == 0, out[-3000:]
 
 
 @pytest.mark.gpu
