@@ -157,8 +157,12 @@ static int fir32(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int
 int launch_fir32(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
                  hipStream_t st, const FcBatch& fb, void** hp_cache, int pref) {
     if (ps->n != Fir32::n) return -1;
-    return pref ? fir32<1>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, hp_cache)
-                : fir32<0>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, hp_cache);
+    if (pref == 2) return fir32<2>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, hp_cache);
+#ifdef PFFFT_HIP_VARIANTS
+    if (pref == 1) return fir32<1>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, hp_cache);
+    if (pref == 0) return fir32<0>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, hp_cache);
+#endif
+    return fir32<2>(ps, d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, hp_cache);
 }
 
 // the overlap-save block kernel on a real setup of length Nfft = 2 ps->n; -1 when the size has no DMA kernel

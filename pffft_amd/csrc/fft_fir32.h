@@ -39,7 +39,7 @@ struct Fir32 {
         if (t == 0) return bin0(perm(i));
         return i < 16 ? t + i * NB : (NB - t) + (i - 16) * NB;
     }
-    // W_32^d, and thread 0's W_N^k per slot (W_64^(2d+1) for d < 8, W_32^(d-7) for 8 <= d < 15; slot 15 has none), rounded from double
+    // W_32^d, rounded from double
     static constexpr float W32[16][2] = {
         {1.0f, -0.0f}, {0.9807852506637573f, -0.19509032368659973f}, {0.9238795042037964f, -0.3826834261417389f},
         {0.8314695954322815f, -0.5555702447891235f}, {0.7071067690849304f, -0.7071067690849304f}, {0.5555702447891235f, -0.8314695954322815f},
@@ -47,13 +47,6 @@ struct Fir32 {
         {-0.19509032368659973f, -0.9807852506637573f}, {-0.3826834261417389f, -0.9238795042037964f}, {-0.5555702447891235f, -0.8314695954322815f},
         {-0.7071067690849304f, -0.7071067690849304f}, {-0.8314695954322815f, -0.5555702447891235f}, {-0.9238795042037964f, -0.3826834261417389f},
         {-0.9807852506637573f, -0.19509032368659973f}};
-    static constexpr float T0[16][2] = {
-        {0.9951847195625305f, -0.0980171412229538f}, {0.9569403529167175f, -0.290284663438797f}, {0.8819212913513184f, -0.4713967442512512f},
-        {0.7730104327201843f, -0.6343932747840881f}, {0.6343932747840881f, -0.7730104327201843f}, {0.4713967442512512f, -0.8819212913513184f},
-        {0.290284663438797f, -0.9569403529167175f}, {0.0980171412229538f, -0.9951847195625305f}, {0.9807852506637573f, -0.19509032368659973f},
-        {0.9238795042037964f, -0.3826834261417389f}, {0.8314695954322815f, -0.5555702447891235f}, {0.7071067690849304f, -0.7071067690849304f},
-        {0.5555702447891235f, -0.8314695954322815f}, {0.3826834261417389f, -0.9238795042037964f}, {0.19509032368659973f, -0.9807852506637573f},
-        {0.0f, -1.0f}};
 };
 
 // Thread-major copy of the filter spectrum (canonical half-complex spectrum x 1 / Nfft, bin 0 = (DC, Nyquist)), once per filter like
@@ -61,7 +54,10 @@ struct Fir32 {
 __global__ void __launch_bounds__(Fir32::WG) fir32_coef_kernel(const cx<float>* __restrict__ Hc, vec4<float>* __restrict__ HP) {
     const int t = threadIdx.x;
     for (int c = 0; c < 16; ++c) {
-        const cx<float> a = Hc[Fir32::bin(t, 2 * c)], b = Hc[Fir32::bin(t, 2 * c + 1)];
+        // x 1/2: the real finalize X[k] = ((A + conj B) -+ i W (A - conj B)) / 2 leaves its factor here (not for thread 0's self-mirrored
+        // bins 0 and n/2, slots 15 and 16, which take no such step)
+        const float ha = (t == 0 && 2 * c == 16) ? 1.f : 0.5f, hb = (t == 0 && 2 * c + 1 == 15) ? 1.f : 0.5f;
+        const cx<float> a = Hc[Fir32::bin(t, 2 * c)] * ha, b = Hc[Fir32::bin(t, 2 * c + 1)] * hb;
         vec4<float> o; o.x = a.x; o.y = a.y; o.z = b.x; o.w = b.y;
         HP[c * Fir32::WG + t] = o;
     }
@@ -77,7 +73,7 @@ __device__ long long pf_f32dbg[64];
 #endif
 
 // PREF: the next block's samples are requested right after the product (else after the output stores)
-template <int PREF>
+template <int PREF>   // 0: after the stores; 1: all at once after the product; 2: in four pieces between the phases of the inverse transform
 __global__ void __launch_bounds__(Fir32::WG, 2)
 fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, const vec4<float>* __restrict__ HP,
                         int nblk, int step, int inputLen, int lastOut,
@@ -117,7 +113,9 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
     // ---- gather of block grp: stage-0 operand order, zero beyond the end of the signal (src/pffastconv.c:231-233)
     typedef vec4<float> F4;
     F4 raw[R];
-    auto gather = [&](unsigned grp, int t) {   // (t: an opaque copy of the thread index per call - addresses hoisted out of the block loop spill)
+    // (t: an opaque copy of the thread index per call - addresses hoisted out of the block loop spill; q0 .. q1: the rows of 1024 samples to
+    //  request - a wavefront that issues all 16 loads at once sits at the issue of the last ones until the memory pipeline has taken them)
+    auto gather = [&](unsigned grp, int t, int q0 = 0, int q1 = R) {
         long long ba = (long long)grp;
         if (ba >= nblk_all) ba = nblk_all - 1;
         int sg, bk;
@@ -127,6 +125,7 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
         if (avail >= 2 * n) {                                     // every block but the last ones of a signal: no predicates
 #pragma unroll
             for (int q = 0; q < R; ++q) {
+                if (q < q0 || q >= q1) continue;
                 const F4u q4 = *reinterpret_cast<const F4u*>(src + 4 * (t + q * (n / (2 * R))));  // 16 bytes, 4-byte aligned
                 F4 r; r.x = q4.a; r.y = q4.b; r.z = q4.c; r.w = q4.d;
                 raw[q] = r;
@@ -134,6 +133,7 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
         } else {
 #pragma unroll
             for (int q = 0; q < R; ++q) {
+                if (q < q0 || q >= q1) continue;
                 const int e0 = 4 * (t + q * (n / (2 * R)));      // first of 4 consecutive samples
                 F4 r;
                 if (e0 + 3 < avail) {
@@ -154,13 +154,15 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
     typename KB::Tw wb;
     KF::template load_tw_stage<1>(wf, t, twg);
     KB::template load_tw_stage<1>(wb, t, twg);
-    const CX pbase = twrg[t];                                     // W_N^t, N = 2 n (t <= n/2)
-    // W_N^k of slot d: every thread but 0: k = t + d n/16, i.e. W_N^t W_32^d;  thread 0 (permuted slots): d < 8: k = (2 d + 1) n/32, i.e.
-    // W_64^(2d+1); 8 <= d < 15: k = (d - 7) n/16, i.e. W_32^(d-7) (slot 15 is the self-mirrored pair, no twiddle)
+    // W_N^k of slot d (N = 2 n): every thread but 0: k = t + d n/16, i.e. W_N^t W_32^d.  Thread 0 (permuted slots): d < 8: k = (2 d + 1) n/32,
+    // i.e. W_64 W_32^d; 8 <= d < 15: k = (d - 7) n/16, i.e. W_32^(-7) W_32^d (slot 15 is the self-mirrored pair, no twiddle): the same
+    // constants W_32^d on two bases, no select per slot
+    const CX pb = twrg[t];                                        // W_N^t (t <= n/2)
+    const CX pbase_lo = KF::sel(first, mk<T>(0.9951847195625305f, -0.0980171412229538f), pb);
+    const CX pbase_hi = KF::sel(first, mk<T>(0.19509032368659973f, 0.9807852506637573f), pb);
     auto pair_tw = [&](int d) -> CX {
         const CX c = mk<T>(Fir32::W32[d][0], Fir32::W32[d][1]);
-        const CX w = d == 0 ? pbase : cmul(pbase, c);
-        return KF::sel(first, mk<T>(Fir32::T0[d][0], Fir32::T0[d][1]), w);
+        return d == 0 ? pbase_lo : cmul(d < 8 ? pbase_lo : pbase_hi, c);
     };
     if (dyn && t == 0) { s_next[0] = 0u; s_next[1] = 0u; }
     __syncthreads();
@@ -221,7 +223,13 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
         for (int d = 0; d < R; ++d) {
             const CX w = pair_tw(d);
             const CX A = v[d], B = v[31 - d];
-            typename KF::Pair f = KF::pair1(A, B, w);
+            // real finalize without its factor 1/2 (folded into HP): X[k] = S + D, X[n - k] = conj(S - D), S = A + conj B, D = -i W (A - conj B)
+            typename KF::Pair f;
+            {
+                const CX su = add_conj(A, B), m = cmul(sub_conj(A, B), w);
+                f.a = add_rot<FWD>(su, m);
+                f.b = conj(sub_rot<FWD>(su, m));
+            }
             const F4 ha4 = hh[d >> 1], hb4 = hh[(31 - d) >> 1];
             const CX ha = (d & 1) ? mk<T>(ha4.z, ha4.w) : mk<T>(ha4.x, ha4.y);
             const CX hb = ((31 - d) & 1) ? mk<T>(hb4.z, hb4.w) : mk<T>(hb4.x, hb4.y);
@@ -241,7 +249,8 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
             v[d] = r.a; v[31 - d] = r.b;
         }
         PF_FSTAMP(6);
-        if constexpr (PREF) gather(gn, tl);                         // the spectrum registers are free: the next block lands during the inverse
+        if constexpr (PREF == 1) gather(gn, tl);
+        if constexpr (PREF == 2) gather(gn, tl, 0, 4);                         // the spectrum registers are free: the next block lands during the inverse
         if (wave0) {
             if (first) {
 #pragma unroll
@@ -256,14 +265,17 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
         // ================= backward transform (its first-stage operands are in place)
         KB::template butterflies<0>(v, t, wb, twg);
         PF_FSTAMP(7);
+        if constexpr (PREF == 2) gather(gn, tl, 4, 8);
         KB::template xwrite<0>(v, t, img); wg_sync_raw();
         KB::template xread<0>(v, t, img); wg_sync_raw();
         PF_FSTAMP(8);
         KB::template butterflies<1>(v, t, wb, twg);
         PF_FSTAMP(9);
+        if constexpr (PREF == 2) gather(gn, tl, 8, 12);
         KB::template xwrite<1>(v, t, img); wg_sync_raw();
         KB::template xread<1>(v, t, img); wg_sync_raw();
         PF_FSTAMP(10);
+        if constexpr (PREF == 2) gather(gn, tl, 12, 16);
         KB::template butterflies<2>(v, t, wb, twg);
         PF_FSTAMP(11);
         // ================= the first numOut samples of the block (src/pffastconv.c:255)

@@ -59,8 +59,9 @@ enum AbValue : int {
     AB_FIR_FEW_16PT = 114,      // (development build) few-block FIR: 16 points per thread
     AB_FIR_FEW_LOCKSTEP = 115,  // few-block FIR: the lock-step kernel on 512 / 256 threads instead of the split one
     AB_FIR_SPLIT_PLAIN = 116,   // (development build) split FIR kernel with plain barriers / pieces at once
-    AB_FIR_FUSED32 = 117,       // 16384-sample FIR blocks: fft_fir32.h (256 threads, 32 points per thread, four exchanges per block)
-    AB_FIR_FUSED32_NOPF = 118,  // the same without the early request of the next block
+    AB_FIR_FUSED32_PF1 = 117,   // (development build) 16384-sample FIR blocks, fft_fir32.h: the next block requested at once after the product
+    AB_FIR_FUSED32_NOPF = 118,  // (development build) ... after the output stores
+    AB_FIR_SPLIT = 119,         // 16384-sample FIR blocks on the split kernel (fft_split.h) that fft_fir32.h replaced in round 6
     AB_CONV_COMPOSED = 120,     // pffft_hip_convolve_batch as the three batched entries
     AB_RFFT_THREE = 121,        // real transforms beyond LDS: always complex core + pair sweep
     AB_RFFT_TWO = 122,          // real transforms beyond LDS: two sweeps wherever the length splits

@@ -31,6 +31,7 @@ struct FastConv {
     std::vector<float> h_td;  // y[m] = sum_i h_td[i] x[m + i]: the filter as the time-domain kernel applies it (zero padded to 8)
     float* d_td = nullptr;
     void* d_fir32_hp = nullptr;    // thread-major filter spectrum of the 32-points-per-thread block kernel (fft_fir32.h), of d_Hc_big
+    void* d_fir32_hp_ref = nullptr;   // ... of d_Hc (filters whose reference block length is 16384 samples itself)
     void* d_split1_ab = nullptr;   // folded per-bin coefficients of the few-block split kernel (fft_split.h), built on first use
     // work image of the composed path: one per stream (two streams running one setup must not share scratch)
     struct Work { float* p = nullptr; size_t floats = 0; unsigned long long last_use = 0; bool captured = false; };   // captured: pf_host.h Scratch
@@ -435,8 +436,11 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
             const int blast = (int)(produced - (long)(bblk - 1) * bstep);
             // 16384-sample blocks: the LDS-DMA staged split kernel (fft_split.h; the lock-step one it replaced: development build).  Shorter
             // internal blocks: the register-staged fused kernel (tools/dma_ab.py: a tie with the DMA kernel at Nfft 8192, 0.22-0.29 both)
-            if (nbig == 16384 && (sel.is(AB_FIR_FUSED32) || sel.is(AB_FIR_FUSED32_NOPF))) {
-                rc = launch_fir32(s->st_big, s->d_Hc_big, d_x, d_y, bblk, bstep, inputLen, blast, st, fb, &s->d_fir32_hp, sel.is(AB_FIR_FUSED32));
+            // 16384-sample blocks: 256 threads, 32 points per thread, four exchanges per block (fft_fir32.h, round 6); AB_FIR_SPLIT: the split
+            // kernel it replaced (fft_split.h: the second route of tests/test_gpu_round6.py), development build: AB_FIR_LOCKSTEP / AB_FIR_SPLIT_PLAIN
+            if (nbig == 16384 && !sel.is(AB_FIR_SPLIT) && !sel.is(AB_FIR_LOCKSTEP) && !sel.is(AB_FIR_SPLIT_PLAIN)) {
+                rc = launch_fir32(s->st_big, s->d_Hc_big, d_x, d_y, bblk, bstep, inputLen, blast, st, fb, &s->d_fir32_hp,
+                                  sel.is(AB_FIR_FUSED32_PF1) ? 1 : sel.is(AB_FIR_FUSED32_NOPF) ? 0 : 2);
                 if (rc != -1) return rc;
             }
             if (nbig == 16384) {
@@ -476,6 +480,10 @@ static int fc_apply_device(FastConv* s, const float* d_x, int cplxInputLen, floa
         return 0;
     }
     if (mode == 0 && Nfft == 16384 && (long)nblk * fb.nsig >= 2L * num_cus()) {
+        if (!sel.is(AB_FIR_SPLIT) && !sel.is(AB_FIR_LOCKSTEP) && !sel.is(AB_FIR_SPLIT_PLAIN)) {
+            rc = launch_fir32(s->st, s->d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb, &s->d_fir32_hp_ref, 2);
+            if (rc != -1) return rc;
+        }
         rc = launch_fir_dma(s->st, s->d_Hc, d_x, d_y, nblk, step, inputLen, lastOut, st, fb);   // many reference-sized blocks
         if (rc != -1) return rc;
     }
@@ -587,6 +595,7 @@ PF_EXPORT void pffastconv_destroy_setup(PFFASTCONV_Setup* s) {
     for (float* p : s->retired) if (p) (void)hipFree(p);
     if (s->d_split1_ab) (void)hipFree(s->d_split1_ab);
     if (s->d_fir32_hp) (void)hipFree(s->d_fir32_hp);
+    if (s->d_fir32_hp_ref) (void)hipFree(s->d_fir32_hp_ref);
     for (float* p : {s->h_x, s->h_y}) if (p) (void)hipHostFree(p);
     s->magic = 0;
     delete s;
