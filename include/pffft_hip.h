@@ -109,8 +109,13 @@ void pffastconv_free(void *);
 int pffastconv_simd_size(void);
 
 /* ------------------------------------------------- PART 2: batched / device extension -------- */
-/* Concurrency bounds of the batched entries.  (i) A setup binds to the HIP device that is current at its first
- * transform; calls from a thread whose current device differs return hipErrorInvalidDevice.  (ii) Kernels that
+/* Concurrency bounds of the batched entries.  (i) ONE SETUP, ANY DEVICE (round 6): a PFFFT_Setup / PFFFTD_Setup is immutable and may
+ * be shared by concurrent threads like the reference's (include/pffft/pffft.h:102-105) - also by threads whose current HIP devices
+ * differ: the twiddle tables, work counters, per-stream scratch and staging buffers are kept per device (built on a device's first
+ * call under the setup's mutex, released by destroy_setup; pffft_hip_setup_devices lists them).  The pointers of a call must be usable on
+ * the calling thread's current device.  A PFFASTCONV_Setup - not shareable between threads in the reference either
+ * (include/pffft/pffastconv.h:77-80) - holds its filter tables on ONE device and rebuilds them when its user's device changes.
+ * (ii) Kernels that
  * pull their work in order draw a {next, done} counter pair from a ring of 4096 pairs per setup and re-arm it
  * when they retire: at most 4096 launches of ONE setup may be in flight at the same time (summed over all
  * streams).  Launches on one stream serialise, so only > 4096 concurrently RUNNING launches could collide.
@@ -143,10 +148,10 @@ int pffftd_hip_zconvolve_batch(PFFFTD_Setup *, const double *a, const double *b,
 /* Batch shards over several devices from ONE host thread (round 5; SURVEY.md 8(e): the batch shards with no exchange step).  Part p -
  * batches[p] vectors at in[p] / out[p], device memory of devices[p] - is transformed by setups[p] on devices[p]: hipSetDevice, then the
  * batched entry on streams[p] (streams == NULL or streams[p] == NULL: that device's default stream).  Every launch is asynchronous, so the
- * devices work concurrently; the caller's current device is restored before the call returns.  A setup binds to the device of its first
- * transform (above): pass ONE SETUP PER DEVICE (the plan is a few KiB; creating a setup needs no device).  Returns the first error, 0
- * when every part is enqueued.  The reference has no counterpart: one of its setups serves any number of threads of one CPU
- * (include/pffft/pffft.h:102-105). */
+ * devices work concurrently; the caller's current device is restored before the call returns.  setups[p] may be THE SAME SETUP in every
+ * slot (round 6: a setup keeps its device state per device, above) or a setup per part.  Returns the first error, 0 when every part is
+ * enqueued.  The reference has no counterpart: one of its setups serves any number of threads of one CPU
+ * (include/pffft/pffft.h:102-105) - which is what one setup for all devices restores. */
 int pffft_hip_transform_batch_multi(int nparts, const int *devices, PFFFT_Setup *const *setups, const float *const *in, float *const *out,
                                     const size_t *batches, pffft_direction_t direction, int ordered, void *const *streams);
 int pffftd_hip_transform_batch_multi(int nparts, const int *devices, PFFFTD_Setup *const *setups, const double *const *in, double *const *out,
@@ -200,6 +205,10 @@ const char *pffft_hip_kernel_name(const void *setup);
  * most len - 1 characters + a terminating 0 into buf and returns the length of the whole text (snprintf convention), -1 for an
  * invalid handle.  Works for PFFFT_Setup and PFFFTD_Setup handles; no device needed. */
 int pffft_hip_describe(const void *setup, char *buf, size_t len);
+/* The devices a setup holds tables / counters / scratch on right now: the device it was first used on, then one entry per further
+ * device (HIP device indices; values >= 64 belong to the test hook pffft_hip_set_variant(130)).  Fills devices[0 .. max) and returns the
+ * count (which may exceed max); 0 for a setup no transform has run on, or an invalid handle.  PFFFT_Setup and PFFFTD_Setup handles. */
+int pffft_hip_setup_devices(const void *setup, int *devices, int max);
 /* Resident workgroups per CU of the kernel a (direction, layout) of an LDS-resident setup runs on, as the launcher sizes its grid (the
  * runtime's occupancy query for the route's kernel, workgroup size and LDS bytes); 0 for routes without one persistent kernel (beyond
  * LDS, the minimum sizes), -1 on error.  Needs a device.  For tests and tools. */

@@ -6,9 +6,9 @@ the reference API (include/pffft/pffft.h:124-250 in the reference tree).  There 
 importing works anywhere, but every transform needs the HIP library and a GPU and raises otherwise.
 """
 from .api import (BACKWARD, COMPLEX, FORWARD, REAL, FastConv, Setup, device_count, error_count, is_valid_size, last_error,
-                  kernel_name, describe, tile_plan, lib, lib_path, min_fft_size, nearest_transform_size, set_variant, has_variants,
+                  kernel_name, describe, setup_devices, tile_plan, lib, lib_path, min_fft_size, nearest_transform_size, set_variant, has_variants,
                   simd_arch, simd_size)
 
 __all__ = ["Setup", "FastConv", "FORWARD", "BACKWARD", "REAL", "COMPLEX", "lib", "lib_path",
            "device_count", "simd_size", "simd_arch", "min_fft_size", "is_valid_size",
-           "nearest_transform_size", "kernel_name", "describe", "tile_plan", "set_variant", "has_variants", "error_count", "last_error"]
+           "nearest_transform_size", "kernel_name", "describe", "setup_devices", "tile_plan", "set_variant", "has_variants", "error_count", "last_error"]

@@ -97,6 +97,7 @@ def lib():
                                                   C.c_double, C.c_void_p]
     L.pffft_hip_kernel_name.restype = C.c_char_p; L.pffft_hip_kernel_name.argtypes = [C.c_void_p]
     L.pffft_hip_describe.restype = C.c_int; L.pffft_hip_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.pffft_hip_setup_devices.restype = C.c_int; L.pffft_hip_setup_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.pffft_hip_last_error.restype = C.c_char_p
     L.pffft_hip_device_count.restype = C.c_int
     L.pffft_hip_set_variant.restype = None; L.pffft_hip_set_variant.argtypes = [C.c_int]
@@ -172,6 +173,13 @@ def describe(setup: "Setup") -> str:
     if n < 0:
         raise ValueError("pffft_hip_describe: invalid handle")
     return buf.value.decode()
+
+
+def setup_devices(setup: "Setup"):
+    """pffft_hip_setup_devices: the devices this setup holds tables / counters / scratch on (first-use device first)."""
+    buf = (C.c_int * 80)()
+    n = lib().pffft_hip_setup_devices(setup.handle, buf, 80)
+    return [buf[i] for i in range(min(n, 80))]
 
 
 def _is_torch(x) -> bool:

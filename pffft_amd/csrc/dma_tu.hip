@@ -14,6 +14,7 @@ namespace pf {
 template <class C>
 static int fir_dma_cfg(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen,
                        int lastOut, hipStream_t st, const FcBatch& fb) {
+    ps = for_device(ps);
     typedef DmaGeom<C> G;
     auto k = fastconv_dma_kernel<C>;
     int rc = allow_big_lds(k, G::LDS_BYTES);
@@ -58,6 +59,7 @@ template <int W>
 static int fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
                       hipStream_t st, const FcBatch& fb, void** ab_cache) {
     typedef SplitOneT<W> S;
+    ps = for_device(ps);
     auto k = fastconv_split1_kernel<W>;
     int rc = allow_big_lds(k, S::LDS_BYTES);
     if (rc) return rc;
@@ -102,6 +104,7 @@ template <int PSYNC, int SPREAD, int W = 8>
 static int fir_split(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen,
                      int lastOut, hipStream_t st, const FcBatch& fb) {
     typedef SplitFirT<W> S;
+    ps = for_device(ps);
     auto k = fastconv_split_kernel<PSYNC, SPREAD, W>;
     int rc = allow_big_lds(k, S::LDS_BYTES);
     if (rc) return rc;
@@ -128,6 +131,7 @@ static int fir_split(Setup* ps, const float* d_Hc, const float* d_x, float* d_y,
 template <int PREF>
 static int fir32(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int nblk, int step, int inputLen, int lastOut,
                  hipStream_t st, const FcBatch& fb, void** hp_cache) {
+    ps = for_device(ps);
     auto k = fastconv_fused32_kernel<PREF>;
     int rc = allow_big_lds(k, Fir32::LDS_BYTES);
     if (rc) return rc;

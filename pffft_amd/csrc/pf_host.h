@@ -70,7 +70,12 @@ struct Setup {
     std::mutex mu;        // guards the lazy device initialisation
     std::mutex stage_mu;  // guards the staging buffers of the legacy host-pointer entries
     bool dev_ready = false;
-    int device = -1;        // the device the tables / counters / scratch of this setup live on (bound at first use)
+    // The device the tables / counters / scratch of THIS object live on: bound at first use.  A call from a thread whose current device is
+    // another one is served by a replica of the plan with device state of its own (for_device; round 6): one PFFFT_Setup may be shared by
+    // threads on different devices like the reference's immutable setup (include/pffft/pffft.h:102-105)
+    std::atomic<int> device{-1};
+    std::map<int, Setup*> replicas;   // (under mu) device key -> replica; owned, destroyed with the setup
+    bool is_replica = false;
     void* d_tw = nullptr;   // W_n^j, j < n
     void* d_twr = nullptr;  // W_N^k, k <= n/2 (real only)
     void* d_twc[2] = {nullptr, nullptr};  // compact per-stage base twiddles of the Stockham plans (forward / backward order)
@@ -111,6 +116,13 @@ constexpr uint32_t MAGIC = 0x50464654u;  // "PFFT"
 // is safe as long as the launches that share a slot do not run concurrently (nodes of one graph on one stream never do).
 struct Setup;
 unsigned* take_counters(Setup* s, hipStream_t st, unsigned pairs = 1);
+
+// The object that holds `s`'s device state for the calling thread's CURRENT device: `s` itself on the device it is bound to (or binds to
+// now), else the replica of that device, created on first use.  Every entry that takes a setup resolves it first; the launchers that read
+// device pointers of a setup (d_tw, counters) are handed the resolved object.  NULL / foreign handles pass through (the entry reports them).
+Setup* for_device(Setup* s);
+// devices `s` holds state on right now (its own binding first): fills out[0 .. max), returns the count (pffft_hip_setup_devices)
+int setup_devices(Setup* s, int* out, int max);
 
 struct FcBatch { int nsig; size_t xstride, ystride; };   // signals of one pffastconv call (1 for the reference entries)
 

@@ -65,6 +65,8 @@ enum AbValue : int {
     AB_CONV_COMPOSED = 120,     // pffft_hip_convolve_batch as the three batched entries
     AB_RFFT_THREE = 121,        // real transforms beyond LDS: always complex core + pair sweep
     AB_RFFT_TWO = 122,          // real transforms beyond LDS: two sweeps wherever the length splits
+    AB_FAKE_DEVICE = 130,       // the calling thread counts as being on ANOTHER device than its current one (key + 64): exercises the per-device
+                                // replicas of a shared setup on a box with one GPU (tests/test_gpu_round6.py)
 };
 struct AbSel {
     int raw = 0;

@@ -152,6 +152,20 @@ static void fc_free_device(FastConv* s) {
     for (float** p : {&s->d_Hf, &s->d_Hc}) if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 
+// everything this setup holds on its device: the filter tables of every route, per-stream work images, staging (not the pinned host
+// images, not the inner pffft setups - those keep state per device themselves, for_device)
+static void fc_release_device(FastConv* s) {
+    fc_free_device(s);
+    for (float** p : {&s->d_Hc_big, &s->d_Hp, &s->d_td, &s->d_x, &s->d_y}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    for (void** p : {&s->d_split1_ab, &s->d_fir32_hp, &s->d_fir32_hp_ref}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    for (auto& kv : s->work) if (kv.second.p) (void)hipFree(kv.second.p);
+    s->work.clear();
+    for (float* p : s->retired) if (p) (void)hipFree(p);
+    s->retired.clear();
+    s->Nfft_big = 0; s->part_P = 0; s->x_floats = 0; s->y_floats = 0;
+    s->ready = false;
+}
+
 static int fc_init_device(FastConv* s) {
     PF_CHECK(hipMalloc((void**)&s->d_Hf, sizeof(float) * s->Nfft));
     PF_CHECK(hipMemcpy(s->d_Hf, s->h_filter_image.data(), sizeof(float) * s->Nfft, hipMemcpyHostToDevice));
@@ -167,15 +181,19 @@ static int fc_init_device(FastConv* s) {
     return 0;
 }
 
+// A PFFASTCONV_Setup is used by one thread at a time (the reference's is "not shareable", include/pffft/pffastconv.h:77-80,142-143) and
+// holds the filter's tables on ONE device: the calling thread's current one.  Round 6: a call from another device no longer fails - the
+// tables are released and rebuilt there (the filter is kept on the host), i.e. the setup follows its user from device to device; a caller
+// that alternates between devices call by call should hold one setup per device.
 static int fc_ensure_device(FastConv* s) {
     int dev = -1;
-    PF_CHECK(hipGetDevice(&dev));
+    int rc = current_device_key(&dev);
+    if (rc) return rc;
     if (s->ready) {
         if (dev == s->device) return 0;
-        g_last_error = "pffastconv: setup is bound to another device than the calling thread's current one";
-        return (int)hipErrorInvalidDevice;
+        fc_release_device(s);
     }
-    const int rc = fc_init_device(s);
+    rc = fc_init_device(s);
     if (rc) { fc_free_device(s); return rc; }   // a later call starts over instead of launching on half-built tables
     s->device = dev;
     s->ready = true;
@@ -193,7 +211,7 @@ static int fc_launch_fused(FastConv* s, const float* d_x, float* d_y, int nblk, 
     size_t groups = ((size_t)nblk * fb.nsig + C::T_PER_WG - 1) / C::T_PER_WG;
     size_t grid = (size_t)num_cus() * per_cu;
     if (grid > groups) grid = groups;
-    Setup* ps = pst ? pst : s->st;
+    Setup* ps = for_device(pst ? pst : s->st);
     if (!d_Hc) d_Hc = s->d_Hc;
     unsigned* ctr = groups <= grid ? nullptr : take_counters(ps, st);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), C::LDS_BYTES, st, d_x, d_y, (const cx<float>*)d_Hc,
@@ -313,7 +331,7 @@ static int fc_launch_part(FastConv* s, const float* d_x, float* d_y, long produc
     const long ntask = ((nblk + kchunk - 1) / kchunk) * fb.nsig;
     long grid = (ntask + C::T_PER_WG - 1) / C::T_PER_WG;
     if (grid > (long)num_cus() * per_cu) grid = (long)num_cus() * per_cu;
-    Setup* ps = s->st_part;
+    Setup* ps = for_device(s->st_part);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), lds, st, d_x, d_y, (const cx<float>*)s->d_Hp, nblk, inputLen,
                        lastOut, (int)kchunk, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, fb.nsig, fb.xstride, fb.ystride);
     PF_CHECK(hipGetLastError());
@@ -340,7 +358,7 @@ static int fc_launch_wave(FastConv* s, const float* d_x, float* d_y, long produc
     const long ntask = ((nblk + kchunk - 1) / kchunk) * fb.nsig;
     long grid = (ntask + C::T_PER_WG - 1) / C::T_PER_WG;
     if (grid > (long)num_cus() * per_cu) grid = (long)num_cus() * per_cu;
-    Setup* ps = s->st_part;
+    Setup* ps = for_device(s->st_part);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(C::WG_THREADS), lds, st, d_x, d_y, (const cx<float>*)s->d_Hp, nblk, step, inputLen,
                        lastOut, (int)kchunk, (const cx<float>*)ps->d_tw, (const cx<float>*)ps->d_twr, fb.nsig, fb.xstride, fb.ystride);
     PF_CHECK(hipGetLastError());

@@ -300,6 +300,7 @@ static Setup* new_setup(int N, int transform, int is_double) {
 
 static void destroy_setup(Setup* s) {
     if (!s) return;
+    for (auto& kv : s->replicas) destroy_setup(kv.second);   // (hipFree takes a pointer of any device, whatever the current one is)
     if (s->dev_ready) {
         if (s->d_tw) (void)hipFree(s->d_tw);
         if (s->d_twr) (void)hipFree(s->d_twr);
@@ -317,17 +318,60 @@ static void destroy_setup(Setup* s) {
     delete s;
 }
 
-// A setup binds to the device that is current at its first transform: tables, counters and scratch live there.  Later
-// calls from a thread whose current device differs are an error (the pointers they pass could not be used by kernels
-// launched there anyway) rather than a fault inside a kernel.
-static int check_device(Setup* s) {
+// The key a thread's current device goes by: the HIP device index; AB_FAKE_DEVICE moves the calling thread to a key of its own (the
+// replica path on a one-GPU box).
+static int current_device_key(int* key) {
     int dev = -1;
     PF_CHECK(hipGetDevice(&dev));
-    if (s->device < 0) s->device = dev;
-    if (s->device != dev) {
+    *key = ab().is(AB_FAKE_DEVICE) ? dev + 64 : dev;
+    return 0;
+}
+
+// One setup, any device (round 6; the reference's setup is immutable and shareable, include/pffft/pffft.h:102-105).  The object binds
+// to the device of its first use; every other device gets a replica of the plan - the same (N, transform, precision), hence the same
+// routes - with tables, counter ring, per-stream scratch and staging of its own, built lazily under the setup's mutex and destroyed with it.
+Setup* for_device(Setup* s) {
+    if (!s || s->magic != MAGIC || s->is_replica) return s;
+    int key = -1;
+    if (current_device_key(&key)) { (void)hipGetLastError(); return s; }   // no usable device: the entry's own checks report it
+    if (s->device.load(std::memory_order_acquire) == key) return s;
+    std::lock_guard<std::mutex> lk(s->mu);
+    int bound = s->device.load(std::memory_order_relaxed);
+    if (bound < 0) { s->device.store(key, std::memory_order_release); return s; }
+    if (bound == key) return s;
+    auto it = s->replicas.find(key);
+    if (it != s->replicas.end()) return it->second;
+    Setup* r = new_setup(s->N, s->transform, s->is_double);
+    if (!r) return s;                                                       // (cannot happen: the same arguments made `s`)
+    r->is_replica = true;
+    r->device.store(key, std::memory_order_release);
+    s->replicas[key] = r;
+    return r;
+}
+
+int setup_devices(Setup* s, int* out, int max) {
+    if (!s || s->magic != MAGIC) return 0;
+    std::lock_guard<std::mutex> lk(s->mu);
+    int n = 0;
+    const int bound = s->device.load();
+    if (bound >= 0) { if (out && n < max) out[n] = bound; ++n; }
+    for (auto& kv : s->replicas) { if (out && n < max) out[n] = kv.first; ++n; }
+    return n;
+}
+
+// The device state of an object lives on ONE device; for_device() hands every entry the object of the calling thread's device, so a
+// mismatch here means the caller switched devices between resolving and launching (or handed a replica around): an error, not a fault
+// inside a kernel.
+static int check_device(Setup* s) {
+    int key = -1;
+    int rc = current_device_key(&key);
+    if (rc) return rc;
+    int bound = s->device.load();
+    if (bound < 0) { s->device.store(key); bound = key; }
+    if (bound != key) {
         char buf[160];
-        snprintf(buf, sizeof buf, "pffft_hip: setup is bound to device %d but the calling thread's current device is %d",
-                 s->device, dev);
+        snprintf(buf, sizeof buf, "pffft_hip: setup state is bound to device %d but the calling thread's current device is %d",
+                 bound, key);
         g_last_error = buf;
         return (int)hipErrorInvalidDevice;
     }
@@ -1137,6 +1181,7 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
     }
     if ((dir != PFFFT_FORWARD && dir != PFFFT_BACKWARD)) { g_last_error = "pffft_hip: bad direction"; return (int)hipErrorInvalidValue; }
     if (batch == 0) return 0;
+    s = for_device(s);        // the object that holds this setup's tables on the calling thread's device
     int rc = ensure_device<T>(s);
     if (rc) return rc;
     const AbSel sel = ab();
@@ -1269,6 +1314,7 @@ static int shift_transform_batch(Setup* s, const float* in, float* out, size_t b
         return (int)hipErrorInvalidHandle;
     }
     if (batch == 0) return 0;
+    s = for_device(s);
     int rc = ensure_device<float>(s);
     if (rc) return rc;
     const double phase_turns = phase_rad / pfmix::MIX_TWO_PI;
@@ -1285,6 +1331,7 @@ template <typename T>
 static int zreorder_batch(Setup* s, const T* in, T* out, size_t batch, int dir, hipStream_t st) {
     if (!s || s->magic != MAGIC) return (int)hipErrorInvalidHandle;
     if (batch == 0) return 0;
+    s = for_device(s);
     // through an LDS image of the internal layout when a vector fits (fft_aux.h); AB_AUX_DIRECT = the direct kernel
     constexpr int CH = 16 / (int)sizeof(T), BCH = SkIbs<T>::v / CH;
     const size_t vimg = ((size_t)(s->n / 16) * BCH + 1) * 16;   // block image of one vector, bytes
@@ -1360,6 +1407,7 @@ static int zconvolve_batch(Setup* s, const T* a, const T* b, T* ab, T scaling, s
                            int b_broadcast, hipStream_t st) {
     if (!s || s->magic != MAGIC) return (int)hipErrorInvalidHandle;
     if (batch == 0) return 0;
+    s = for_device(s);
     const AbSel sel = ::pf::ab();      // (`ab` is also this function's output vector)
     const bool direct = sel.is(AB_AUX_DIRECT), inorder_small = sel.is(AB_INORDER_SMALL);
     size_t total = batch * (size_t)(s->n / 4);
@@ -1447,6 +1495,7 @@ static int convolve_batch(Setup* s, const T* in, const T* H, T* out, T scaling, 
         return (int)hipErrorInvalidHandle;
     }
     if (batch == 0) return 0;
+    s = for_device(s);
     int rc = ensure_device<T>(s);
     if (rc) return rc;
     if (h_broadcast && !ab().is(AB_CONV_COMPOSED)) {
@@ -1518,6 +1567,7 @@ static int legacy_run(Setup* s, const T* const* ins, int nin, T* out, bool out_i
         g_last_error = "pffft_hip: bad setup handle";
         return (int)hipErrorInvalidHandle;
     }
+    s = for_device(s);        // (the staging buffers of the calling thread's device)
     const size_t bytes = s->vec_scalars * sizeof(T);
     // the staging buffers belong to the setup; the mutex keeps concurrent callers correct
     // (the reference allows a setup to be shared between threads, include/pffft/pffft.h:102-105)
@@ -1705,8 +1755,9 @@ struct PFFFTD_Setup : pf::Setup {};
 
 // Batch shards over several devices from ONE host thread (independent units, no exchange step): part p is transformed by
 // setups[p] on devices[p] - hipSetDevice, then the batched entry on streams[p] (NULL: that device's default stream); every launch is
-// asynchronous, so the devices run concurrently.  The caller's current device is restored.  A setup binds to the device of its first
-// transform: setups[p] must be a setup of its own per device.  Returns the first error (0 = all enqueued).
+// asynchronous, so the devices run concurrently.  The caller's current device is restored.  Round 6: setups[p] may be the SAME setup in
+// every slot (for_device: a setup holds device state per device it is used on) or a setup of its own per part, as before.  Returns the
+// first error (0 = all enqueued).
 template <typename T, typename SETUP>
 static int transform_batch_multi(int nparts, const int* devices, SETUP* const* setups, const T* const* in, T* const* out, const size_t* batches,
                                  int dir, int ordered, void* const* streams) {
@@ -1776,6 +1827,11 @@ PF_EXPORT int pffft_hip_tile_override(long long n, int is_double, int l1, int g1
 }
 PF_EXPORT const char* pffft_hip_last_error(void) { return pf::g_last_error.c_str(); }
 PF_EXPORT unsigned pffft_hip_error_count(void) { return pf::g_error_count.load(); }
+// devices the setup holds tables / counters / scratch on right now (the device it bound to first, then its replicas; a key >= 64 is the
+// test hook AB_FAKE_DEVICE); fills out[0 .. max), returns the count
+PF_EXPORT int pffft_hip_setup_devices(const void* setup, int* out, int max) {
+    return pf::setup_devices(const_cast<pf::Setup*>(static_cast<const pf::Setup*>(setup)), out, max < 0 ? 0 : max);
+}
 PF_EXPORT int pffft_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -366,3 +366,28 @@ def test_describe_matches_the_routing_restated_here():
     need = pa.lib().pffft_hip_describe(s.handle, buf, 64)
     assert need > 64 and len(buf.value) == 63 and pa.describe(s).startswith(buf.value.decode())
     s.close()
+
+
+def test_setup_devices_without_a_device(L):
+    """pffft_hip_setup_devices (round 6: one setup, any device - the device state of a setup is kept per device and listed here): no state
+    before the first transform, an invalid handle lists nothing, and a legacy call that fails soft for want of a GPU leaves the list empty
+    (nothing was built, nothing to release) - destroy_setup afterwards is clean."""
+    buf = (C.c_int * 4)(9, 9, 9, 9)
+    assert L.pffft_hip_setup_devices(None, buf, 4) == 0 and list(buf) == [9, 9, 9, 9]
+    for dtype in (np.float32, np.float64):
+        s = pa.Setup(1024, pa.COMPLEX, dtype)
+        assert pa.setup_devices(s) == []
+        assert L.pffft_hip_setup_devices(s.handle, None, 0) == 0
+        s.close()
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        e0 = pa.error_count()
+        s = pa.Setup(64, pa.REAL)
+        y = s.transform(np.ones(64, np.float32), pa.FORWARD)     # fails soft: NaN output + counter (include/pffft_hip.h)
+        assert np.isnan(y).all() and pa.error_count() == e0 + 1
+        assert pa.setup_devices(s) == []
+        s.close()
