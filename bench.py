@@ -562,14 +562,18 @@ def fir_config(torch, pa, dev, timer, warmup):
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         tr_ms = rec.get("c4_long_kernel_ms_trace")
-        if tr_ms:
-            rf = out["roofline"]
+        rf = out["roofline"]
+        if tr_ms and rec.get("source_hash") == source_hash():
             rf["frac_events"], rf["kernel_ms_events"] = rf["frac"], rf["kernel_ms"]
             rf["kernel_ms_trace"] = round(float(tr_ms), 4)
             rf["frac"] = round(min(rf["frac"], 8 * nl / (float(tr_ms) * 1e-3) / HBM_PEAK), 4)
             rf["achieved"] = round(rf["frac"] * HBM_PEAK / 1e9, 1)
-            rf["frac_note"] = ("frac = min(HIP-event step time, rocprofv3 kernel duration of the last capture of this kernel) - overlapping "
-                               f"back-to-back launches make the step time the shorter one; capture source hash {rec.get('source_hash')}, this build {source_hash()}")
+            rf["frac_note"] = ("frac = min(HIP-event step time, rocprofv3 kernel duration of the capture of THIS build) - overlapping "
+                               f"back-to-back launches make the step time the shorter one; source hash {source_hash()}")
+        elif tr_ms:
+            # (a trace of another build must not pin the figure - it would hide a real change of the kernel)
+            rf["frac_note"] = (f"frac from HIP events; the rocprofv3 trace in profiles/pmc_traffic.json ({float(tr_ms):.4f} ms) belongs to source hash "
+                               f"{rec.get('source_hash')}, this build is {source_hash()}: stale, not used")
     except Exception:
         pass
     nfft_used = 16384 if taps >= 1024 else 8192    # internal block of the throughput regime (pffastconv_impl.h fc_big_nfft)
@@ -579,8 +583,25 @@ def fir_config(torch, pa, dev, timer, warmup):
                             "frac_spec": round(fl / t / VALU_PEAK_SPEC, 4), "flops_per_output_sample": round(fl / nl, 1),
                             "note": f"SURVEY.md 8(d) C4 flop count at the internal block length {nfft_used}; peak = 108 float results "
                                     "per clock and CU measured (profiles/r02_probes.md) x 256 CUs x 2.4 GHz, one flop per result; "
-                                    "peak_spec = the data sheet's 157.3 TFLOP/s.  Neither binds: the block kernel is bound by LDS stores "
-                                    "(448 KiB per 16384-sample block at 79 B/clk and CU) and its barriers (tools/dma_timeline.hip, DESIGN.md 3.6)"}
+                                    "peak_spec = the data sheet's 157.3 TFLOP/s"}
+    # LDS roof from the block kernel's own structure (round 6, fft_fir32.h: FOUR exchanges of the 64 KiB image per 16384-sample block, each
+    # one store sweep and one load sweep; round 5's split kernel: 448 KiB of stores + 512 KiB of loads) at the guide's rates
+    # (MI355X_MICROARCH.md, LDS table: ds_write_b128 ~79 B/clk and CU, ds_read2_b64 128 B/clk and CU), all 256 CUs at 2.4 GHz
+    if nfft_used == 16384:
+        step_b = nfft_used - taps + 1
+        nblk = (nl + step_b - 1) // step_b
+        st_b, ld_b = 4 * 65536, 4 * 65536
+        t_lds = nblk * (st_b / 79.0 + ld_b / 128.0) / (256 * 2.4e9)
+        out["roofline_lds"] = {"bound": "lds", "store_bytes_per_block": st_b, "load_bytes_per_block": ld_b, "blocks": int(nblk),
+                               "floor_ms": round(t_lds * 1e3, 4), "frac": round(t_lds / t, 4),
+                               "note": "fraction of the step time the LDS pipe alone needs: exchanges per block x 64 KiB each way at 79 (stores) / "
+                                       "128 (loads) B per clock and CU, 256 CUs, 2.4 GHz"}
+        roofs = {"hbm": out["roofline"]["frac"], "valu": out["roofline_valu"]["frac"], "lds": out["roofline_lds"]["frac"]}
+        binding = max(roofs, key=roofs.get)
+        out["roofline"]["bound"] = binding
+        out["roofline"]["bound_note"] = ("the roof that binds this kernel (largest of the three fractions " + json.dumps(roofs) + "): `achieved` / `peak` / `frac` "
+                                         "of this dict stay the HBM figures of the contract (8 B per output sample); the binding roof's own figures are in "
+                                         f"roofline_{binding}" if binding != "hbm" else "HBM binds")
     fc.close()
     del xl, yl, sig, y
     torch.cuda.empty_cache()
@@ -836,6 +857,7 @@ def main():
                               "long_kernel_ms": c4["roofline"]["kernel_ms"], "long_kernel_ms_trace": c4["roofline"].get("kernel_ms_trace"),
                               "batch_frac": c4.get("batch_frac"), "single_call_us": c4.get("single_call_us"),
                               "single_call_frac": c4.get("single_call_frac"),
+                              "bound": c4["roofline"].get("bound"), "lds_frac": (c4.get("roofline_lds") or {}).get("frac"),
                               "valu_frac_measured_peak": c4["roofline_valu"]["frac"], "valu_frac_spec_peak": c4["roofline_valu"]["frac_spec"],
                               "parity_err_over_range": c4.get("parity_max_err_over_range"),
                               "cpu_Gsps": (c4.get("cpu_baseline") or {}).get("value")}
