@@ -224,7 +224,9 @@ int pffft_hip_tile_plan(long long n, int is_double, int deep, int lengths[3]);
 /* The planner's tuning interface (tools/tune_tile_plans.py writes pffft_amd/csrc/tile_plan_gen.h with it).  pffft_hip_tile_candidates: every
  * legal pair of tile lengths of n, out[5 i ..] = {L1, gen1, L2, gen2, cost of the model}, returns the count (may exceed max).
  * pffft_hip_tile_override: from now on setups of n are planned with this pair (l1 > 0; -1 when it is not a legal pair), with no tile plan
- * (l1 == 0: the streaming passes) or by the tables again (l1 < 0).  Process-wide; affects setups created afterwards. */
+ * (l1 == 0: the streaming passes) or by the tables again (l1 < 0).  Process-wide.  Call it while NO setup of n exists and destroy the setups
+ * of n before changing it again: a setup's route is fixed at pffft_new_setup for the lengths of that moment, the passes read the lengths
+ * per launch. */
 int pffft_hip_tile_candidates(long long n, int is_double, int *out, int max);
 int pffft_hip_tile_override(long long n, int is_double, int l1, int g1, int l2, int g2);
 const char *pffft_hip_last_error(void);

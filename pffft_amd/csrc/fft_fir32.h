@@ -19,7 +19,9 @@
 //   * thread 0 (both of its butterflies are self-mirrored) used to evaluate a second pairing and select (3 x 64 live registers):
 //     now lane 0 permutes its 24 affected registers through 192 bytes of LDS so that the regular pairing applies to it too,
 //     and back after the second pair pass; only slot 15 (bins 0 and n/2) keeps a select;
-//   * with the spectrum dead, the NEXT block's samples are requested right after the product and land during the inverse transform.
+//   * with the spectrum dead, the NEXT block's samples are requested in four pieces between the phases of the inverse transform.
+// Measured and dropped (tools/fir32_timeline.hip, min of 12 launches, 256 x 2^20 samples, 4096 taps): the 31 twiddles of the radix-32 stage
+// from a 4 KiB LDS table instead of 30 products per transform: 0.428 against 0.441 - the LDS pipe is the scarcer resource here.
 #pragma once
 #include "fft_dma.h"
 
@@ -62,6 +64,23 @@ __global__ void __launch_bounds__(Fir32::WG) fir32_coef_kernel(const cx<float>* 
         HP[c * Fir32::WG + t] = o;
     }
 }
+
+// One 8-byte LDS read that the compiler cannot merge with its neighbour into ds_read2_b64: the pairs cost 8 LDS cycles per KiB where two
+// ds_read_b64 cost 2 + 2 (MI355X_MICROARCH.md, LDS table: 128 against 256 B per clock and CU).  The compiler does not count these in
+// lgkmcnt: every caller waits (wg_sync_raw) before it uses the values.
+template <int OFF> __device__ __forceinline__ cx<float> lds_ld64_asm(const cx<float>* p) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    vec2<float> r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const char*)p), "n"(OFF) : "memory");
+    return mk<float>(r.x, r.y);
+}
+
+template <int Q, int NQ, int STRIDE, int VOFF> struct Fir32Rd {
+    static __device__ __forceinline__ void run(cx<float> (&v)[32], const cx<float>* p) {
+        v[VOFF + Q] = lds_ld64_asm<Q * STRIDE>(p);
+        if constexpr (Q + 1 < NQ) Fir32Rd<Q + 1, NQ, STRIDE, VOFF>::run(v, p);
+    }
+};
 
 #ifdef PF_FIR32_DEBUG
 __device__ long long pf_f32dbg[64];
@@ -167,6 +186,29 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
     if (dyn && t == 0) { s_next[0] = 0u; s_next[1] = 0u; }
     __syncthreads();
 
+    // the 8-byte exchange reads (fft_tiled.h xread, the stages whose butterflies are not adjacent pairs) as single ds_read_b64:
+    //   after stage 0 (both directions): butterfly j = t of the radix-32 stage, operand q at row j mod 16, column j div 16 + 16 q
+    //   forward, after stage 1: butterflies jm<2>(t, u) of the symmetric radix-16 stage, operand q at j + 512 q
+    constexpr int ROW0 = n / 16 + C::PAD0;
+    static_assert(C::PADN == 0, "natural image without padding");
+    const CX* rd0 = img + (t & 15) * ROW0 + (t >> 4);
+    const CX* rd1a = img + KF::template jm<2>(t, 0);
+    const CX* rd1b = img + KF::template jm<2>(t, 1);
+    auto xread0 = [&](CX (&v)[E]) {
+#ifdef PF_FIR32_NO_ASMRD
+        KF::template xread<0>(v, t, img);
+#else
+        Fir32Rd<0, 32, 16 * 8, 0>::run(v, rd0);
+#endif
+    };
+    auto xread1f = [&](CX (&v)[E]) {
+#ifdef PF_FIR32_NO_ASMRD
+        KF::template xread<1>(v, t, img);
+#else
+        Fir32Rd<0, 16, 512 * 8, 0>::run(v, rd1a);
+        Fir32Rd<0, 16, 512 * 8, 16>::run(v, rd1b);
+#endif
+    };
     for (unsigned it = 0; (long long)g < nblk_all; ++it) {
         if (dyn && t == 0) {
             s_next[(it + 1) & 1] = pend;
@@ -192,12 +234,12 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
         KF::template xwrite<0>(v, t, img);
         wg_sync_raw();                                            // (publishes s_next)
         const unsigned gn = __builtin_amdgcn_readfirstlane(dyn ? s_next[(it + 1) & 1] : g + gridDim.x);   // (wave-uniform: the block's offsets and bounds live in SGPRs)
-        KF::template xread<0>(v, t, img); wg_sync_raw();
+        xread0(v); wg_sync_raw();
         PF_FSTAMP(2);
         KF::template butterflies<1>(v, t, wf, twg);
         PF_FSTAMP(3);
         KF::template xwrite<1>(v, t, img); wg_sync_raw();
-        KF::template xread<1>(v, t, img); wg_sync_raw();
+        xread1f(v); wg_sync_raw();
         PF_FSTAMP(4);
         // the filter spectrum of this thread's bins: in flight during the last stage and the pair pass
         F4 hh[16];
@@ -267,7 +309,7 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
         PF_FSTAMP(7);
         if constexpr (PREF == 2) gather(gn, tl, 4, 8);
         KB::template xwrite<0>(v, t, img); wg_sync_raw();
-        KB::template xread<0>(v, t, img); wg_sync_raw();
+        xread0(v); wg_sync_raw();
         PF_FSTAMP(8);
         KB::template butterflies<1>(v, t, wb, twg);
         PF_FSTAMP(9);
@@ -285,8 +327,14 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
             const CX a = v[d], b = v[R + d];
             const int lim = numOut - 4 * d * (n / (2 * R));       // samples of this row of 1024 that are output (wave-uniform)
             if (lim >= 4 * (n / (2 * R))) {
+#ifndef PF_FIR32_NO_NT
+                typedef float F4nt __attribute__((ext_vector_type(4), aligned(4)));
+                F4nt q4; q4.x = a.x; q4.y = a.y; q4.z = b.x; q4.w = b.y;
+                __builtin_nontemporal_store(q4, reinterpret_cast<F4nt*>(dst + e0));   // (outputs are written once and not read back: streaming)
+#else
                 F4u q4; q4.a = a.x; q4.b = a.y; q4.c = b.x; q4.d = b.y;
                 *reinterpret_cast<F4u*>(dst + e0) = q4;
+#endif
             } else if (lim > 0) {
                 if (e0 + 3 < numOut) {
                     F4u q4; q4.a = a.x; q4.b = a.y; q4.c = b.x; q4.d = b.y;

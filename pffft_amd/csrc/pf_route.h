@@ -44,7 +44,7 @@ enum AbValue : int {
     AB_STOCK_FOR_TILED = 50,    // the Stockham plan also for the sizes that have a register-tiled kernel (and N = 1024 float)
     AB_STOCK_WORKGROUP = 52,    // (development build) workgroup-phase Stockham kernel where the wave-local one applies
     AB_STOCK_RUNTIME = 53,      // (development build) run-time-plan Stockham kernels
-    AB_STOCK_DF_ON = 54,        // (development build) direct-first-stage twin of every plan / always the register-tiled kernel for 2^k
+    AB_STOCK_DF_ON = 54,        // (development build) direct-first-stage twin of every Stockham plan
     AB_STOCK_DF_OFF = 55,       // (development build) deposit twin of every plan
     AB_AUX_DIRECT = 60,         // zreorder / zconvolve: the direct grid-stride kernels; shift + FFT as two passes
     AB_AUX_NO_STREAM = 61,      // zreorder / zconvolve: no in-order streaming kernel

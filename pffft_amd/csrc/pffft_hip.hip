@@ -1167,10 +1167,16 @@ static Route plan_route(const Setup* s, int dir, int ordered, const AbSel& sel) 
 }
 
 static void plan_routes(Setup* s) {
+    // The stored routes are the DEFAULT ones whatever selector the creating thread has set: the tile planner's helpers
+    // (tile_has_plan, tile_plan_lengths) read the calling thread's selector themselves (AB_BIG_NO_MR_TILES), so it is cleared for the
+    // planning and restored (a setup created under set_variant(83) had the streaming route baked in as its default)
+    const int keep = g_ab_raw;
+    g_ab_raw = 0;
     const AbSel none;
     for (int d = 0; d < 2; ++d)
         for (int o = 0; o < 2; ++o)
             s->route[d][o] = s->is_double ? plan_route<double>(s, d, o, none) : plan_route<float>(s, d, o, none);
+    g_ab_raw = keep;
 }
 
 template <typename T>

@@ -501,7 +501,10 @@ int tile_plan_candidates(long long n, bool is_double, int* out, int max) {
     return cnt;
 }
 // the tuner's hook: l1 > 0 - the plan of n from now on (0 = accepted, -1 = not a legal pair); l1 == 0 - "no tile plan"; l1 < 0 - remove the
-// override.  Setups created afterwards see it (routes are planned at pffft_new_setup); the cached model plans of n are dropped.
+// override.  Set it BEFORE any setup of n exists (the tuner creates a fresh setup per candidate): a live setup's route - which pass reads /
+// stores the internal layout, the sweeps - was frozen at pffft_new_setup for the lengths of that time, while the tile passes look the
+// lengths up on every launch; a live setup of n would run the new lengths under its old route.  The cached model plans of n
+// are dropped.
 int tile_plan_override(long long n, bool is_double, int l1, int g1, int l2, int g2) {
     const long long key = n * 2 + (is_double ? 1 : 0);
     TileLen a{0, 0}, b{0, 0};

@@ -20,13 +20,16 @@ static int run(const float* x, float* y, const vec4<float>* HP, const cx<float>*
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Fir32::LDS_BYTES));
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, Fir32::WG, Fir32::LDS_BYTES));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int rep = 0; rep < 4; ++rep) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 12; ++rep) {
         CK(hipMemset(ctr, 0, 64));
         CK(hipEventRecord(a));
         hipLaunchKernelGGL(k, dim3(cus * per_cu), dim3(Fir32::WG), Fir32::LDS_BYTES, 0, x, y, HP, (int)nblk, step, (int)L, lastOut, dtw, dtwr, ctr, nsig, (size_t)L, (size_t)L, 1);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
-        if (rep == 3) {
+        if (ms < best) best = ms;
+        if (rep == 11) {
+            ms = best;
             long long d[64];
             CK(hipMemcpyFromSymbol(d, HIP_SYMBOL(pf_f32dbg), sizeof d));
             printf("PREF %d, %d taps, %d x 2^%d: %.1f us, fraction of the 8 B / sample roofline %.3f, %d workgroups per CU, %.0f ns per block and CU\n  stamps (cycles since the top of the iteration; 100 MHz counter x clock ratio):",
@@ -55,10 +58,8 @@ int main() {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("clock rate %d kHz, %d CUs\n", prop.clockRate, cus);
-    for (int taps : {4096, 2048}) {
+    for (int taps : {4096}) {
         if (run<2>(x, y, HP, dtw, dtwr, ctr, L, taps, cus, nsig)) return 1;
-        if (run<1>(x, y, HP, dtw, dtwr, ctr, L, taps, cus, nsig)) return 1;
-        if (run<0>(x, y, HP, dtw, dtwr, ctr, L, taps, cus, nsig)) return 1;
     }
     return 0;
 }
