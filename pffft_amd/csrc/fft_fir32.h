@@ -70,9 +70,7 @@ __global__ void __launch_bounds__(Fir32::WG) fir32_coef_kernel(const cx<float>* 
 // lgkmcnt: every caller waits (wg_sync_raw) before it uses the values.
 template <int OFF> __device__ __forceinline__ cx<float> lds_ld64_asm(const cx<float>* p) {
     static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
-    vec2<float> r;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const char*)p), "n"(OFF) : "memory");
-    return mk<float>(r.x, r.y);
+    return lds_ld_c<OFF>(p);
 }
 
 template <int Q, int NQ, int STRIDE, int VOFF> struct Fir32Rd {
