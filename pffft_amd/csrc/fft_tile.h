@@ -83,11 +83,15 @@ template <typename T, int LOGL, int PP, int R0 = 1> struct TileGeom {
     // block-gather of the store loop reads conflict-free (+ 3 QSKEW units at the end of the image)
     static constexpr int QSKEW = S == 2 ? 4 : 1;
     static constexpr size_t IMG_BYTES = (size_t)L * PITCH * 16 + 256;
+    // a plain column pass (SEQC && !IINT) keeps its image WITHOUT the padding unit (the kernel's PITCH = PP): round 6 gives it the LDS of
+    // that image only - L = 1024 on 64-byte runs: 64 KiB + tables = 75 KiB instead of 100, L = 512 on 128-byte runs 76 instead of 84:
+    // TWO workgroups per CU where one ran alone with nothing to overlap its barrier-separated phases
+    static constexpr size_t IMG_BYTES_PLAIN = (size_t)L * PP * 16 + 256;
     // + W_L^k (L entries) + `levels` x 2^WB entries of the four-step twiddle table.  WB = 9 (two levels reach M = 2^18, three
     // 2^27); the one tile that fills LDS - L = 1024 with 128-byte runs (PP = 8): 147 KiB of image - takes three levels of 2^7
     // (M <= 2^21), 3 KiB instead of 12
-    static constexpr int WB = (LOGL == 10 && PP == 8 && R0 == 1) ? 7 : 9;
-    __host__ __device__ static constexpr size_t lds_bytes(int levels) { return IMG_BYTES + ((size_t)L + ((size_t)levels << WB)) * 2 * sizeof(T) + 16; }
+    static constexpr int WB = (LOGL == 10 && R0 == 1) ? 7 : 9;
+    __host__ __device__ static constexpr size_t lds_bytes(int levels, bool plain = false) { return (plain ? IMG_BYTES_PLAIN : IMG_BYTES) + ((size_t)L + ((size_t)levels << WB)) * 2 * sizeof(T) + 16; }
     __host__ __device__ static constexpr int rad(int s) {
         if (s < NODD) return s == 0 ? RA : RB;
         s -= NODD;
@@ -154,7 +158,8 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     constexpr int NLD = ODD_DIRECT ? UB0 * RA : SEQC ? 8 : C * L / WG;   // loads per thread and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     U* img = reinterpret_cast<U*>(smem);
-    CX* wl = reinterpret_cast<CX*>(smem + G::IMG_BYTES);
+    constexpr size_t IMGB = (SEQC && !IINT && RMODE == 0) ? G::IMG_BYTES_PLAIN : G::IMG_BYTES;
+    CX* wl = reinterpret_cast<CX*>(smem + IMGB);
     CX* w3 = wl + L;
     const int tid = threadIdx.x, t = tid / PP, p = tid % PP;
 
@@ -252,7 +257,15 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     // first 170 workgroups to arrive took three tiles each and the rest none: 34 us per pass against 10 us for 256 tiles; and the start-up
     // burst of three atomics per workgroup on one address is off the critical path now.)
     const unsigned long long g0 = xctr ? gridDim.x / 8 : gridDim.x, lid = xctr ? blockIdx.x / 8 : blockIdx.x;
-    auto ranged = [&](unsigned long long local) -> unsigned long long { const unsigned long long g = xbase + local; return g < xend ? g : ngroups; };
+    // xmode bit 2 (round 6, with bit 1): the XCD's counter deals tile PAIRS round robin - local index l of XCD x is tile 16 (l / 2) + 2 x + l % 2 -
+    // instead of a contiguous eighth: the two column tiles that share every 128-byte line of their point rows (64-byte runs) are taken back to
+    // back by two workgroups of ONE XCD and meet in its L2, while all eight XCDs still sweep the batch together in order (the contiguous
+    // eighths of bit 1 alone cost the register-tiled passes 10-15 %: eight distant fronts in HBM)
+    const bool xpair = xctr && (D.xmode & 4u);
+    auto ranged = [&](unsigned long long local) -> unsigned long long {
+        if (xpair) { const unsigned long long g = 16ull * (local >> 1) + 2ull * (blockIdx.x % 8) + (local & 1ull); return g < ngroups ? g : ngroups; }
+        const unsigned long long g = xbase + local; return g < xend ? g : ngroups;
+    };
     unsigned pend = 0;
     const bool cstart = dyn && (D.xmode & 8u);       // (A/B, PFFFT_HIP_TILE_CSTART=1: the three start-up grabs of round 3 - 1-3 % slower at 1 GiB, N = 2^18 .. 393216)
     const unsigned long long goff = cstart ? 0 : 2 * g0;

@@ -15,7 +15,10 @@ template <typename T, int LOGL, int PP, int R0, int PFSEL, int PFSEL_B, int RAG>
 static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles, const TileDesc& D, int dir, hipStream_t st, Setup* s,
                           bool out_int, bool in_int, int pf_force) {
     typedef TileGeom<T, LOGL, PP, R0> G;
-    const size_t lds = G::lds_bytes(D.M > (1ull << (2 * G::WB)) ? 3 : 2);
+    const bool fw0 = dir == PFFFT_FORWARD;
+    const bool plain = D.seq_contig && !(in_int && !fw0);      // the column-pass kernels that keep an unpadded image (fft_tile.h IMG_BYTES_PLAIN)
+    if (D.M > (1ull << (3 * G::WB))) { g_last_error = "pffft_hip: four-step modulus beyond the tile's twiddle table"; return (int)hipErrorInvalidValue; }
+    const size_t lds = G::lds_bytes(D.M > (1ull << (2 * G::WB)) ? 3 : 2, plain);
     void (*k)(const cx<T>*, cx<T>*, unsigned long long, TileDesc, unsigned*);
     const bool fw = dir == PFFFT_FORWARD;
     if constexpr (PFSEL < 0) {
@@ -67,15 +70,19 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     // OFF for these kernels: their strides are whole or half lines, and measured (tools/r4_xmode.sh) the static map costs 0-4 %, the per-XCD
     // counters N = 2^20 0.20-0.23 -> 0.17-0.19 (one in-order sweep over the whole batch is what HBM rewards there); they pay only on the
     // strides of fft_tileg.h that are neither
-    static const int xmode_env = dev_env("PFFFT_HIP_TILE_XMODE", 0);
+    // Round 6, bit 4 (on): the column passes with 64-byte runs (PP = 4: two adjacent tiles share every 128-byte line) take their tiles from
+    // per-XCD counters that deal tile PAIRS round robin (fft_tile.h xpair) - both tiles of a line through one L2 while all XCDs sweep the batch
+    // together: N = 2^20 complex float 0.239 -> 0.245, double 0.250 -> 0.262, 2^19 +-1 % (tools/r6_quick.py, same box, alternating)
+    static const int xmode_env = dev_env("PFFFT_HIP_TILE_XMODE", 16);
     const bool dynm = !(ngroups <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
     // (bit 2: per-XCD counters for the column passes with 64-byte runs only - adjacent tiles share every line there)
-    const bool xctr = dynm && ((xmode_env & 2) || ((xmode_env & 4) && PP == 4 && D.seq_contig)) && grid % 8 == 0 && ngroups >= 64 && D.group <= 1;
+    const bool xpair = (xmode_env & 16) && PP == 4 && D.seq_contig;      // pairs of column tiles with 64-byte runs dealt per XCD (fft_tile.h)
+    const bool xctr = dynm && ((xmode_env & 2) || ((xmode_env & 4) && PP == 4 && D.seq_contig) || xpair) && grid % 8 == 0 && ngroups >= 64 && D.group <= 1;
     // (per-XCD counters: nine words = five {next, done} pairs of the ring, which is allocated with that much room past its end)
     unsigned* ctr = !dynm ? nullptr : take_counters(s, st, xctr ? 5 : 1);
     TileDesc D2 = D;
     static const int cstart_env = dev_env("PFFFT_HIP_TILE_CSTART", 0);   // A/B: start-up grabs from the counter
-    D2.xmode = (xctr ? 2u : 0u) | ((!dynm && (xmode_env & 1) && D.group <= 1) ? 1u : 0u) | (cstart_env ? 8u : 0u);
+    D2.xmode = (xctr ? 2u : 0u) | ((xctr && xpair) ? 4u : 0u) | ((!dynm && (xmode_env & 1) && D.group <= 1) ? 1u : 0u) | (cstart_env ? 8u : 0u);
     if (D2.xmode & 1u) grid = (grid + 7) / 8 * 8;      // (the static map is a bijection on a grid of whole eights; the surplus workgroups retire at once)
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D2, ctr);
     PF_CHECK(hipGetLastError());
