@@ -637,6 +637,122 @@ def fake_main(args, world, rank):
         dist.destroy_process_group()
 
 
+def single_process_main(args):
+    """--single-process: ONE host process (one rank, one thread) drives --gpus N devices through pffft[d]_hip_transform_batch_multi with
+    ONE shared setup (round 6: a setup keeps its device state per device, include/pffft_hip.h) - the C-level way to shard a batch over a
+    node, no torch.distributed, no RCCL: the path has no collective.  Same contract: W untimed + K timed
+    steps, a step = one _multi call (every device transforms its shard of the config's per-GPU batch, weak scaling), the timed region
+    bracketed by a synchronisation of ALL devices on both sides, value = whole-job transforms per second.  PFFFT_BENCH_SHARE_GPU=1 (harness
+    test on a 1-GPU box, never a reportable number): the parts share the visible devices round robin."""
+    import ctypes as C
+    import time
+    import torch
+    import pffft_amd as pa
+    from pffft_amd.sharding import global_uniform_np
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.config not in ("c2", "c3", "c5") or args.scaling != "weak":
+        raise SystemExit("bench.py --single-process: c2 / c3 / c5, weak scaling")
+    share = os.environ.get("PFFFT_BENCH_SHARE_GPU") == "1"
+    nvis = torch.cuda.device_count()
+    if nvis < args.gpus and not share:
+        raise SystemExit(f"bench.py --single-process: --gpus {args.gpus} but {nvis} device(s) visible")
+    cfg = CONFIGS[args.config]
+    seed = {"c2": 2, "c3": 3, "c5": 5}[args.config]
+    dt = _np_dtype(cfg["dtype"])
+    tdt = torch.float64 if cfg["dtype"] == "f64" else torch.float32
+    batch = 1 << (args.batch_log2 if args.batch_log2 is not None else cfg["batch_log2"])
+    setup = pa.Setup(cfg["N"], cfg["tr"], dt)
+    vs = setup.vec_scalars
+    P = args.gpus
+    devs = [p % nvis for p in range(P)]
+    xs, ys, sts = [], [], []
+    for p, d in enumerate(devs):
+        torch.cuda.set_device(d)
+        dev = torch.device("cuda", d)
+        xs.append(make_input(torch, dev, batch, vs, tdt, seed, p * batch))     # part p holds global vectors [p batch, (p + 1) batch)
+        ys.append(torch.empty_like(xs[-1]))
+        sts.append(torch.cuda.Stream(device=dev))
+    torch.cuda.set_device(devs[0])
+    L = pa.lib()
+    multi = L.pffftd_hip_transform_batch_multi if cfg["dtype"] == "f64" else L.pffft_hip_transform_batch_multi
+    multi.restype = C.c_int
+    a_dev = (C.c_int * P)(*devs)
+    a_set = (C.c_void_p * P)(*([setup.handle] * P))
+    a_in = (C.c_void_p * P)(*[t.data_ptr() for t in xs])
+    a_out = (C.c_void_p * P)(*[t.data_ptr() for t in ys])
+    a_b = (C.c_size_t * P)(*([batch] * P))
+    a_st = (C.c_void_p * P)(*[q.cuda_stream for q in sts])
+
+    def step():
+        rc = multi(P, a_dev, a_set, a_in, a_out, a_b, pa.FORWARD, 0, a_st)
+        if rc:
+            raise SystemExit("pffft_hip_transform_batch_multi failed: " + pa.last_error())
+
+    def sync_all():
+        for d in sorted(set(devs)):
+            torch.cuda.synchronize(d)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ev = []
+    for p, d in enumerate(devs):                                   # per-device kernel time: HIP events on the part's own stream
+        torch.cuda.set_device(d)
+        ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+        ev[-1][0].record(sts[p])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    for p, d in enumerate(devs):
+        torch.cuda.set_device(d)
+        ev[p][1].record(sts[p])
+    sync_all()
+    el = time.perf_counter() - t0
+    torch.cuda.set_device(devs[0])
+    per_dev_ms = [a.elapsed_time(b) / args.steps for a, b in ev]
+    tps = P * batch * args.steps / el
+    # parity of the first and the last part against the reference, inputs rebuilt on the host from their GLOBAL indices
+    parity = None
+    try:
+        from oracle import ref as oref
+        if oref.available():
+            rs = oref.get().setup(cfg["N"], cfg["tr"], dt)
+            worst, cnt = 0.0, 0
+            for p in sorted({0, P - 1}):
+                idx = sample_indices(batch, 512)
+                xin = np.stack([global_uniform_np((p * batch + i) * vs, vs, seed, dt) for i in idx])
+                want = rs.batch(xin, oref.FORWARD, False)
+                got = ys[p][torch.tensor(idx, device=ys[p].device)].cpu().numpy()
+                worst = max(worst, float((np.abs(got.astype(np.float64) - want).max(axis=1) / np.abs(want).max(axis=1)).max()))
+                cnt += len(idx)
+            parity = {"max_rel_err": worst, "transforms_checked": cnt}
+            rs.close()
+    except Exception as e:
+        parity = f"unchecked: {e}"
+    seen = pa.setup_devices(setup)
+    out = {
+        "metric": "M transforms/s, batched N=%d %s-%s forward FFT (pffft_transform semantics)" % (
+            cfg["N"], "complex" if cfg["tr"] else "real", "float" if cfg["dtype"] == "f32" else "double"),
+        "value": round(tps / 1e6, 3), "unit": "M transforms/s", "n_gpus": P, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": cfg["dtype"],
+        "data": "synthetic: counter hash of (seed, global element index), uniform [-1, 1)"
+                + (" (HARNESS TEST: parts share GPUs, not a reportable number)" if share else ""),
+        "gflops": round(tps * cfg["flops"] / 1e9, 1),
+        "config": {"workload": f"{cfg['name']}, batch=2^{int(np.log2(batch))} per GPU, out of place, device-resident, internal-layout spectrum",
+                   "kernel": pa.kernel_name(setup), "batch_per_gpu": batch,
+                   "sharding": "batch-split over the devices of ONE process: pffft_hip_transform_batch_multi, one shared setup, one stream per "
+                               "device, no collective"},
+        "single_process": True, "devices_seen": len(seen), "setup_devices": seen,
+        "ms_per_step_fastest_device": round(min(per_dev_ms), 4), "ms_per_step_slowest_device": round(max(per_dev_ms), 4),
+        "roofline": roofline(batch * cfg["bytes"], max(per_dev_ms) * 1e-3, None),
+        "parity_vs_reference": parity, "source_hash": source_hash(),
+    }
+    print(json.dumps(out), flush=True)
+    setup.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -650,10 +766,14 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline line only: skip the other configs / side rates")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process drives all --gpus devices through pffft_hip_transform_batch_multi with one shared setup")
     args = ap.parse_args()
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.single_process:
+        return single_process_main(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

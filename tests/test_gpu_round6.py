@@ -409,3 +409,26 @@ def test_graph_replay_equals_direct_call_on_lds_resident_routes(ref):
     rs = ref.setup(1024, pa.COMPLEX, np.float32)
     assert relerr(w_t[:4].cpu().numpy(), rs.batch(x[:4].cpu().numpy(), pa.FORWARD, False)) <= 1e-5
     rs.close(); s.close(); fc.close()
+
+
+# ------------------------------------------------------------------ bench.py --single-process (one process, N devices, one setup)
+@pytest.mark.parametrize("cfg", ["c2", "c5"])
+def test_bench_single_process_path(cfg):
+    """bench.py --gpus N --single-process: one rank drives N devices through pffft_hip_transform_batch_multi with ONE setup - the JSON line
+    of the contract with `devices_seen`; on a 1-GPU box N = 1 for real and N = 2 as the harness test where the parts share the device
+    (PFFFT_BENCH_SHARE_GPU=1), on a multi-GPU box every visible device."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    nd = pa.device_count()
+    for gpus, share in ((nd, False), (2, True)):
+        env = dict(os.environ)
+        if share:
+            env["PFFFT_BENCH_SHARE_GPU"] = "1"
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--single-process", "--config", cfg,
+                            "--steps", "3", "--warmup", "1", "--batch-log2", "12"], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == gpus and line["single_process"] and line["steps"] == 3
+        assert line["devices_seen"] == (min(gpus, nd) if not share else min(2, nd))
+        assert line["parity_vs_reference"]["max_rel_err"] <= (1e-5 if cfg == "c2" else 1e-12)
+        assert line["value"] > 0 and line["roofline"]["frac"] > 0
