@@ -225,23 +225,37 @@ def source_hash():
 
 
 def roofline(alg_bytes_per_launch, kernel_s, traffic_key=None):
-    """`traffic` cannot be measured inside this run (PMC counters need rocprofv3 around the process): it is the figure of
-    the last `rocprofv3 --pmc` capture of the same command (tools/profile_r03.sh -> profiles/pmc_traffic.json), and
-    `traffic_source` says so, with the source hash of the build it was captured on and whether that is this build."""
+    """`traffic` cannot be measured inside this run (PMC counters need rocprofv3 around the process): it is the figure of a
+    `rocprofv3 --pmc` capture of the same workload (tools/profile_round.sh -> tools/pmc_round.py -> profiles/pmc_traffic.json) - replayed ONLY
+    when that capture was taken on these very kernel sources (source hash) and is less than 24 h old; otherwise `traffic` is null and
+    `traffic_source` says why (a replay that can drift from the build is not a measurement)."""
     ach = alg_bytes_per_launch / kernel_s
     out = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
            "frac": round(ach / HBM_PEAK, 4), "traffic": None, "kernel_ms": round(kernel_s * 1e3, 4),
            "algorithmic_bytes_per_launch": int(alg_bytes_per_launch)}
     if traffic_key:
         try:
+            import datetime
             rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             v = rec.get(traffic_key)
-            if v is not None:
-                cap = rec.get("source_hash")
+            cap, when = rec.get("source_hash"), rec.get("captured", "")
+            age_h = None
+            try:
+                t0 = datetime.datetime.strptime(when, "%Y-%m-%dT%H:%MZ").replace(tzinfo=datetime.timezone.utc)
+                age_h = (datetime.datetime.now(datetime.timezone.utc) - t0).total_seconds() / 3600.0
+            except Exception:
+                pass
+            same = cap == source_hash()
+            fresh = age_h is not None and -6.0 <= age_h <= 24.0      # (clock skew between the capturing and the running box)
+            if v is not None and same and fresh:
                 out["traffic"] = int(round(v))
-                out["traffic_source"] = ("replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                         f"captured {rec.get('captured', '?')} on source hash {cap}); not measured in this run; "
-                                         f"this build: {source_hash()} ({'same build' if cap == source_hash() else 'DIFFERENT build'})")
+                out["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes, 2 x FETCH_SIZE + "
+                                         f"WRITE_SIZE, MI355X_MICROARCH.md HBM section) captured {when} ({age_h:.1f} h ago) on source hash {cap} = this build; "
+                                         "not measured inside this run")
+            elif v is not None:
+                out["traffic_source"] = (f"null: the capture in profiles/pmc_traffic.json ({when}, source hash {cap}) is "
+                                         + ("of another build" if not same else "older than 24 h") + f" (this build: {source_hash()}); "
+                                         "re-capture with tools/profile_round.sh + tools/pmc_round.py")
         except Exception:
             pass
     return out
@@ -379,7 +393,7 @@ def sizes_table(torch, pa, dev, timer, R=None):
                 for d in (pa.FORWARD, pa.BACKWARD):
                     for o in (True, False):
                         # best of two runs of 10 + 20 launches: single runs of the small-vector kernels scatter by 0.05-0.08 from one
-                        # run to the next on the same build (tools/r4_ab.py), which read as regressions that were not there
+                        # run to the next on the same build (r4_ab.py (earlier-round tool, git history)), which read as regressions that were not there
                         # (a best-of-two figure is not comparable with the single runs of earlier rounds - the mean of the two
                         #  runs is summed up beside it, `mean_of_two_runs` in the summary)
                         t2 = [timer(lambda: s.transform_batch(x, y, d, ordered=o), 20, warm=10) for _ in range(2)]

@@ -67,7 +67,7 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     const unsigned long long oneshot_env = (unsigned long long)env().oneshot;
     if (want_dyn && oneshot_env && ngroups <= oneshot_env * grid) grid = ngroups;
     // XCD-aware tile order (TileDesc::xmode, round 4): PFFFT_HIP_TILE_XMODE = 0 off, 1 static map only, 2 per-XCD counters only, 3 both (A/B).
-    // OFF for these kernels: their strides are whole or half lines, and measured (tools/r4_xmode.sh) the static map costs 0-4 %, the per-XCD
+    // OFF for these kernels: their strides are whole or half lines, and measured (r4_xmode.sh (earlier-round tool, git history)) the static map costs 0-4 %, the per-XCD
     // counters N = 2^20 0.20-0.23 -> 0.17-0.19 (one in-order sweep over the whole batch is what HBM rewards there); they pay only on the
     // strides of fft_tileg.h that are neither
     // Round 6, bit 4 (on): the column passes with 64-byte runs (PP = 4: two adjacent tiles share every 128-byte line) take their tiles from

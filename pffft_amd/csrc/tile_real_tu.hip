@@ -26,7 +26,7 @@ static int rtile_pass(const cx<T>* in, cx<T>* out, unsigned long long ntiles, co
     // pass B (RMODE 2) takes its tiles from one work counter PER XCD, each over a contiguous eighth of the tiles (TileDesc::xmode bit 1): the
     // partner-bin runs of a row tile are off by one element against the 128-byte lines, every line is shared with the neighbour tile, and
     // neighbours then meet in one L2 - double N = 2^17 .. 2^20 0.226 / 0.303 / 0.273 / 0.220 -> 0.285 / 0.339 / 0.315 / 0.261, float 2^18 /
-    // 2^19 0.216 / 0.227 -> 0.242 / 0.246 (tools/r4_rfft_x.py; dropping the streaming hint of those stores: no change).
+    // 2^19 0.216 / 0.227 -> 0.242 / 0.246 (r4_rfft_x.py (earlier-round tool, git history); dropping the streaming hint of those stores: no change).
     // PFFFT_HIP_RFFT_X=0: one counter (A/B)
     static const int x_env = dev_env("PFFFT_HIP_RFFT_X", 2);
     const bool dynm = !(ntiles <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
@@ -64,11 +64,11 @@ static bool rtile_split(long long N, int* l1, int* l2) {
 // adopted: true -> only the lengths where the two sweeps pay for BOTH layouts of the forward transform.  pffft_transform_ordered ==
 // pffft_zreorder(pffft_transform) holds bit for bit, so the unordered transform takes the same two sweeps and then the one-sweep
 // permutation big_block_kernel<5> - against tile passes + pair-and-layout sweep of the three-sweep route.  MI355X, 1 GiB per launch,
-// fraction of 8 TB/s, two sweeps ordered / unordered against three (tools/r4_rfft_x.py): float 2^16 0.232 / 0.192 against 0.250 / 0.247,
+// fraction of 8 TB/s, two sweeps ordered / unordered against three (r4_rfft_x.py (earlier-round tool, git history)): float 2^16 0.232 / 0.192 against 0.250 / 0.247,
 // 2^17 0.254 / 0.198 : 0.238 / 0.243, 2^18 0.243 / 0.187 : 0.237 / 0.234, 2^19 0.234 / 0.189 : 0.253 / 0.249, 2^20 0.230 / 0.186 : 0.214 / 0.225;
 // double 2^16 0.223 / 0.182 : 0.247 / 0.246, 2^17 0.288 / 0.220 : 0.245 / 0.247, 2^18 0.342 / 0.253 : 0.239 / 0.256, 2^19 0.318 / 0.233 :
 // 0.248 / 0.263, 2^20 0.262 / 0.201 : 0.237 / 0.241.  The Hermitian partner bins N - k of a row tile sit off by one element against the
-// 128-byte grid; those partial-line stores (0.5 GiB in ~200 us with one work counter, tools/r4_real_prof.py) ate most of the saved sweep
+// 128-byte grid; those partial-line stores (0.5 GiB in ~200 us with one work counter, r4_real_prof.py (earlier-round tool, git history)) ate most of the saved sweep
 // until the row tiles were taken per XCD
 bool tile_rfft_has_plan(long long N, bool is_double, bool adopted) {
     int l1, l2;

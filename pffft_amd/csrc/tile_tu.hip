@@ -123,7 +123,7 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
 // Two-pass plan of a size with factors 3 and / or 5: n = L1 L2, L = R0 2^b with R0 in {1, 3, 5, 9, 15, 25, 27, 45} and a tile
 // length that is instantiated: power of two 64 .. 512, odd-stage lengths 48 .. 768 (tile_host.h: mr_min_logl / mr_max_logl; image
 // <= 110 KiB).  Which length is the column pass and which the row pass is decided by the measured cost of each (us per GiB of
-// vectors, float and double alike within 10 %, tools/tile_len_times.py on MI355X): column tiles 105-125, but 165-180 from L = 640
+// vectors, float and double alike within 10 %, tile_len_times.py (earlier-round tool, git history) on MI355X): column tiles 105-125, but 165-180 from L = 640
 // (ten and more wavefronts per workgroup: 168 registers); row tiles 97-127, 125-140 from L = 576.  Three streaming passes cost
 // ~285 (five ~480 where the row length of that route is itself beyond LDS): plans above that are refused.  Tile lengths with two
 // odd stages (25, 27, 45): columns 118-128 (L = 720: 176-192), rows 102-138 (L = 720: 165-169).  false: no plan - the three streaming passes of fft_big.h.
@@ -133,7 +133,7 @@ static int g_wide_cost = dev_env("PFFFT_HIP_TILE_WIDECOST", 340);   // A/B: 0 = 
 static const int g_gen_cost = env().tile_plans;   // PFFFT_HIP_TILE_PLANS=0: no run-time plans (fft_tileg.h) - those sizes take the streaming passes
 // `stride`: the element stride between the points of the pass's strided side - the column count of a column pass (loads and stores), the
 // row count (outer) of a row pass (stores).  Costs in the unit of the table above (~ us per 0.5 GiB of float vectors / 2.1), round 4,
-// N = 10800 / 11664 / 250000 / 600000 on forced plans (tools/r4_gen_force.sh):
+// N = 10800 / 11664 / 250000 / 600000 on forced plans (r4_gen_force.sh (earlier-round tool, git history)):
 //   run-time plans (fft_tileg.h): rows 230 us where the stride is whole 128-byte lines, 250-275 on half lines, 250-290 else (L > 432: 280-310);
 //   columns 285-318 on half lines, 320-340 else, 414 for L = 60 (L > 432: 330-365);
 //   register-tiled kernels on strides that are not half lines (float, the other length = 2, 4, 6 mod 8): 475-550 for either pass
@@ -141,7 +141,7 @@ static int tile_cost(const TileLen& t, bool columns, unsigned long long stride, 
     const long long L = t.len();
     const unsigned long long line = is_double ? 8 : 16;
     if (t.gen) {
-        // (+ 10: a plan that ties with a register-tiled one on this model measured 1-9 % slower - N = 144000 .. 307200, tools/r4_gen_scan.sh changed)
+        // (+ 10: a plan that ties with a register-tiled one on this model measured 1-9 % slower - N = 144000 .. 307200, r4_gen_scan.sh (earlier-round tool, git history) changed)
         const int dbl = (is_double ? 8 : 0) + 10;         // (double: 233-324 / 292-390 on the same plans)
         if (columns) return (L > 432 ? 165 : stride % (line / 2) == 0 ? 143 : 158) + (L < 80 ? 40 : 0) + dbl;
         return (L > 432 ? 140 : stride % line == 0 ? 110 : stride % (line / 2) == 0 ? 125 : 132) + (L < 80 ? 20 : 0) + dbl;
@@ -245,7 +245,7 @@ static bool tile_pair_legal(long long n, bool is_double, const TileLen& ta, cons
     // (double: the register-tiled kernels are built without the ragged last tile - the OTHER length must be a multiple of 8)
     if (is_double && ((!ta.gen && tb.len() % 8) || (!tb.gen && ta.len() % 8))) return false;
     // (a length with a register-tiled kernel runs on the run-time plan only where the strided 128-byte runs of that kernel would not be
-    //  half lines - 475-550 us per pass against 250-330, tools/r4_gen_force.sh: N = 12000 = 100 x 120, 21600 = 108 x 200 ...)
+    //  half lines - 475-550 us per pass against 250-330, r4_gen_force.sh (earlier-round tool, git history): N = 12000 = 100 x 120, 21600 = 108 x 200 ...)
     const unsigned long long half = is_double ? 4 : 8;
     if ((ta.alt && tb.len() % half == 0) || (tb.alt && ta.len() % half == 0)) return false;
     return true;
@@ -311,7 +311,7 @@ static bool tile_plan_search(long long n, bool is_double, int mode, TileLen& a, 
                 const int c = tile_pair_cost(is_double, ta, tb);
                 // (float, not deep: a plan with a run-time length that carries the internal layout is taken up to 340 - the sizes with 2^4 / 2^5
                 //  and a large odd part, whose streaming route cannot read the internal layout in its column pass (R odd): four combinations
-                //  0.23 / 0.24 / 0.25 / 0.18 -> 0.21 / 0.24 / 0.24 / 0.24, tools/r4_gen_scan.sh wide; double: the run-time passes are 5-17 % behind)
+                //  0.23 / 0.24 / 0.25 / 0.18 -> 0.21 / 0.24 / 0.24 / 0.24, r4_gen_scan.sh (earlier-round tool, git history) wide; double: the run-time passes are 5-17 % behind)
                 const bool wide = mode == 0 && !is_double && (ta.gen || tb.gen) && ta.len() % 4 == 0 && tb.len() % 4 == 0;
                 if (c < best) { best = c; found = true; a = ta; b = tb; }
                 else if (wide && c < wide_best) { wide_best = c; wa = ta; wb = tb; have_wide = true; }

@@ -11,7 +11,7 @@ dev = "cuda"
 
 
 def timed(fn, reps=10, warm=None):
-    # the first ~15 launches of a kernel climb to the steady rate (tools/c3_ramp.py): warm up ~30 ms before timing
+    # the first ~15 launches of a kernel climb to the steady rate (c3_ramp.py (earlier-round tool, git history)): warm up ~30 ms before timing
     for _ in range(warm if warm is not None else max(3, 2 * reps)):
         fn()
     torch.cuda.synchronize()

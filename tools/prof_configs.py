@@ -5,7 +5,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pffft_amd as pa
-reps = 40   # the first ~15 launches of a kernel climb to the steady rate (tools/c3_ramp.py); pmc_r02.py averages the last ones
+reps = 40   # the first ~15 launches of a kernel climb to the steady rate (c3_ramp.py (earlier-round tool, git history)); pmc_r02.py averages the last ones
 def fft(N, tr, dtype, B, ordered=False):
     s = pa.Setup(N, tr, dtype)
     tdt = torch.float64 if dtype == np.float64 else torch.float32
@@ -26,7 +26,7 @@ for _ in range(reps + 1):
 torch.cuda.synchronize()
 xb = torch.empty(256, 1 << 20, device="cuda").uniform_(-1, 1); yb = torch.empty_like(xb)
 for _ in range(reps + 1):
-    fc.apply_batch(xb, True, out=yb)                          # the same split kernel on 256 signals of 2^20 (tools/pmc_r04.py: second half of its dispatches)
+    fc.apply_batch(xb, True, out=yb)                          # the same block kernel on 256 signals of 2^20 (tools/pmc_round.py: second half of its dispatches)
 torch.cuda.synchronize()
 xs = xb[0].contiguous(); ys = torch.empty_like(xs)
 for _ in range(4 * reps):

@@ -1,10 +1,13 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): kernel trace of the default bench line + PMC passes over the dominant kernel of every
-# BASELINE config (tools/prof_configs.py).  FETCH_SIZE and WRITE_SIZE in SEPARATE passes, no trace domains besides
-# --kernel-trace next to --pmc (MI355X_MICROARCH.md §HBM, gpurun rules).  tools/pmc_r05.py condenses into profiles/.
+# Run on the GPU box (through gpurun):   bash tools/profile_round.sh <round>      e.g. 06
+# kernel trace of the default bench line + PMC passes over the dominant kernel of every BASELINE config (tools/prof_configs.py).
+# FETCH_SIZE and WRITE_SIZE in SEPARATE passes, no trace domains besides --kernel-trace next to --pmc (MI355X_MICROARCH.md §HBM, gpurun
+# rules).  Then, here:  python tools/pmc_round.py <round>  condenses gpurun_out/prof_r<round> into profiles/r<round>_* and
+# profiles/pmc_traffic.json (source hash + capture time: bench.py replays `traffic` only from a capture of the SAME sources, < 24 h old).
 set -u
+R=${1:?round, e.g. 06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_r05
+OUT=$ROOT/gpurun_out/prof_r$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $ROOT

@@ -1,8 +1,9 @@
 #!/bin/bash
-# round 5: steady scans of every legal size (tools/size_scan.py ... steady), beyond LDS and LDS-resident, both precisions -> gpurun_out/r5_scans/
+# steady scans of every legal size (tools/size_scan.py ... steady), beyond LDS and LDS-resident, both precisions -> gpurun_out/scans/
+#     bash tools/scans.sh [all|beyond|resident]     then copy the four files to profiles/r<round>_scan_*.txt
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r5_scans
+OUT=$ROOT/gpurun_out/scans
 mkdir -p $OUT
 cd $ROOT
 what=${1:-all}
