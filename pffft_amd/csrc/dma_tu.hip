@@ -137,8 +137,8 @@ static int fir32(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int
     if (rc) return rc;
     if (!*hp_cache) {
         void* hp = nullptr;
-        PF_CHECK(hipMalloc(&hp, sizeof(float) * 2 * (size_t)Fir32::n));
-        hipLaunchKernelGGL(fir32_coef_kernel, dim3(1), dim3(Fir32::WG), 0, nullptr, (const cx<float>*)d_Hc, (vec4<float>*)hp);
+        PF_CHECK(hipMalloc(&hp, sizeof(float) * 4 * (size_t)Fir32::n));
+        hipLaunchKernelGGL(fir32_coef_kernel, dim3(1), dim3(Fir32::WG), 0, nullptr, (const cx<float>*)d_Hc, (const cx<float>*)ps->d_twr, (vec4<float>*)hp);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) { (void)hipFree(hp); return fail(e, "fir32_coef_kernel"); }

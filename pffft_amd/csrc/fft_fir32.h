@@ -12,10 +12,9 @@
 //   backward  radix 16 -> exchange -> radix 32 -> exchange -> radix 16 -> 16-byte stores of the block's first `numOut` samples
 // FOUR exchanges per block (256 KiB of stores + 256 KiB of loads), TWO workgroups per CU (two barrier domains on four wavefronts
 // each, 256 VGPRs per lane).  What made this organisation spill in rounds 2 and 4 (868 B of scratch per lane) and how it fits now:
-//   * the filter spectrum of a thread's 32 bins is NOT resident (64 VGPRs): it is read per block from a thread-major copy of the
-//     table (fir32_coef_kernel: 16 coalesced 16-byte loads per thread, L2 hits) right before the last forward stage and is dead after
-//     the product;
-//   * the 16 pair-pass twiddles W_N^(t + d n/16) are one base W_N^t times the constants W_32^d (30 VGPRs);
+//   * nothing of the filter is resident: pair pass, product and pair pass are folded into Z'[k] = A_k Z[k] + B_k conj Z[n - k] with per-bin
+//     coefficients read per block from a thread-major table (fir32_coef_kernel: 32 coalesced 16-byte loads per thread, L2 hits) around
+//     the last forward stage - 8 packed operations per pair of bins instead of 20, no pair-pass twiddles at all;
 //   * thread 0 (both of its butterflies are self-mirrored) used to evaluate a second pairing and select (3 x 64 live registers):
 //     now lane 0 permutes its 24 affected registers through 192 bytes of LDS so that the regular pairing applies to it too,
 //     and back after the second pair pass; only slot 15 (bins 0 and n/2) keeps a select;
@@ -41,28 +40,46 @@ struct Fir32 {
         if (t == 0) return bin0(perm(i));
         return i < 16 ? t + i * NB : (NB - t) + (i - 16) * NB;
     }
-    // W_32^d, rounded from double
-    static constexpr float W32[16][2] = {
-        {1.0f, -0.0f}, {0.9807852506637573f, -0.19509032368659973f}, {0.9238795042037964f, -0.3826834261417389f},
-        {0.8314695954322815f, -0.5555702447891235f}, {0.7071067690849304f, -0.7071067690849304f}, {0.5555702447891235f, -0.8314695954322815f},
-        {0.3826834261417389f, -0.9238795042037964f}, {0.19509032368659973f, -0.9807852506637573f}, {0.0f, -1.0f},
-        {-0.19509032368659973f, -0.9807852506637573f}, {-0.3826834261417389f, -0.9238795042037964f}, {-0.5555702447891235f, -0.8314695954322815f},
-        {-0.7071067690849304f, -0.7071067690849304f}, {-0.8314695954322815f, -0.5555702447891235f}, {-0.9238795042037964f, -0.3826834261417389f},
-        {-0.9807852506637573f, -0.19509032368659973f}};
 };
 
-// Thread-major copy of the filter spectrum (canonical half-complex spectrum x 1 / Nfft, bin 0 = (DC, Nyquist)), once per filter like
-// the reference's own transform of the filter (src/pffastconv.c:108): HP[(c WG + t) ] = (H[bin(t, 2c)], H[bin(t, 2c + 1)]).
-__global__ void __launch_bounds__(Fir32::WG) fir32_coef_kernel(const cx<float>* __restrict__ Hc, vec4<float>* __restrict__ HP) {
+// Folded per-bin coefficients, once per filter like the reference's own transform of the filter (src/pffastconv.c:108): real finalize,
+// x Hf / Nfft and real preprocess of a mirror pair collapse into   Z'[k] = A_k Z[k] + B_k conj Z[n - k]   (derivation: fft_fir.h
+// fastconv_part_kernel; the split kernels use the same form; bin 0 = (DC, Nyquist) and bin n/2 are their own mirrors) - 8 packed
+// operations per pair of bins where pair pass + two products + pair pass took 20.  Thread-major: AB[(2 d + h) WG + t] = (A, B) of the bin
+// in slot d (h = 0) / slot 31 - d (h = 1) of thread t: 32 coalesced 16-byte loads per thread and block, L2 hits.
+__global__ void __launch_bounds__(Fir32::WG) fir32_coef_kernel(const cx<float>* __restrict__ Hc, const cx<float>* __restrict__ twr,
+                                                               vec4<float>* __restrict__ AB) {
+    typedef float T;
+    typedef cx<T> CX;
+    constexpr int n = Fir32::n;
     const int t = threadIdx.x;
-    for (int c = 0; c < 16; ++c) {
-        // x 1/2: the real finalize X[k] = ((A + conj B) -+ i W (A - conj B)) / 2 leaves its factor here (not for thread 0's self-mirrored
-        // bins 0 and n/2, slots 15 and 16, which take no such step)
-        const float ha = (t == 0 && 2 * c == 16) ? 1.f : 0.5f, hb = (t == 0 && 2 * c + 1 == 15) ? 1.f : 0.5f;
-        const cx<float> a = Hc[Fir32::bin(t, 2 * c)] * ha, b = Hc[Fir32::bin(t, 2 * c + 1)] * hb;
+    for (int i = 0; i < 32; ++i) {
+        const int slot = (i & 1) ? 31 - (i >> 1) : (i >> 1);
+        const int k = Fir32::bin(t, slot);
+        const int km = (n - k) & (n - 1);
+        const CX w = k <= n / 2 ? twr[k] : conj(twr[n - k]) * (T)-1;
+        const CX Hk = Hc[k], Hm = Hc[km];
+        const CX iw = mk<T>(-w.y, w.x), iwc = mk<T>(w.y, w.x);   // i w, i conj(w)
+        const CX al = mk<T>(0.5f * (1.f - iw.x), -0.5f * iw.y), be = mk<T>(0.5f * (1.f + iw.x), 0.5f * iw.y);
+        const CX ga = mk<T>(1.f + iwc.x, iwc.y), de = mk<T>(1.f - iwc.x, -iwc.y);
+        const CX gH = cmul(ga, Hk), dHm = cmul(de, conj(Hm));
+        CX a = cmul(gH, al) + cmul(dHm, be), b = cmul(gH, be) + cmul(dHm, al);
+        if (k == 0) { a = mk<T>(Hk.x + Hk.y, 0.f); b = mk<T>(0.f, Hk.x - Hk.y); }
+        if (k == n / 2) { a = mk<T>(2.f * Hk.x, -2.f * Hk.y); b = mk<T>(0.f, 0.f); }
         vec4<float> o; o.x = a.x; o.y = a.y; o.z = b.x; o.w = b.y;
-        HP[c * Fir32::WG + t] = o;
+        AB[i * Fir32::WG + t] = o;
     }
+}
+
+// (b.y m.y + c.x, -b.x m.y + c.y): the second half of b conj(m) on top of an accumulator (cxmath.h pk_mul_yx_yy_n as a fused multiply-add)
+__device__ __forceinline__ vec2<float> pk_fma_yx_yy_n(vec2<float> b, vec2<float> m, vec2<float> c) {
+    vec2<float> r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(b), "v"(m), "v"(c));
+    return r;
+}
+// a z + b conj(m) in four packed operations
+__device__ __forceinline__ cx<float> fir32_fold(cx<float> a, cx<float> z, cx<float> b, cx<float> m) {
+    return pk_fma_xy_xx(b, m, pk_fma_yx_yy_n(b, m, pk_fma_xx_xy(a, z, pk_mul_yy_yx_n(a, z))));
 }
 
 // One 8-byte LDS read that the compiler cannot merge with its neighbour into ds_read2_b64: the pairs cost 8 LDS cycles per KiB where two
@@ -171,16 +188,6 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
     typename KB::Tw wb;
     KF::template load_tw_stage<1>(wf, t, twg);
     KB::template load_tw_stage<1>(wb, t, twg);
-    // W_N^k of slot d (N = 2 n): every thread but 0: k = t + d n/16, i.e. W_N^t W_32^d.  Thread 0 (permuted slots): d < 8: k = (2 d + 1) n/32,
-    // i.e. W_64 W_32^d; 8 <= d < 15: k = (d - 7) n/16, i.e. W_32^(-7) W_32^d (slot 15 is the self-mirrored pair, no twiddle): the same
-    // constants W_32^d on two bases, no select per slot
-    const CX pb = twrg[t];                                        // W_N^t (t <= n/2)
-    const CX pbase_lo = KF::sel(first, mk<T>(0.9951847195625305f, -0.0980171412229538f), pb);
-    const CX pbase_hi = KF::sel(first, mk<T>(0.19509032368659973f, 0.9807852506637573f), pb);
-    auto pair_tw = [&](int d) -> CX {
-        const CX c = mk<T>(Fir32::W32[d][0], Fir32::W32[d][1]);
-        return d == 0 ? pbase_lo : cmul(d < 8 ? pbase_lo : pbase_hi, c);
-    };
     if (dyn && t == 0) { s_next[0] = 0u; s_next[1] = 0u; }
     __syncthreads();
 
@@ -239,10 +246,10 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
         KF::template xwrite<1>(v, t, img); wg_sync_raw();
         xread1f(v); wg_sync_raw();
         PF_FSTAMP(4);
-        // the filter spectrum of this thread's bins: in flight during the last stage and the pair pass
-        F4 hh[16];
+        // the folded coefficients of this thread's first eight slot pairs: in flight during the last stage (the other eight follow below)
+        F4 ab[32];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) hh[c] = HP[c * WG + tl];
+        for (int c = 0; c < 16; ++c) ab[c] = HP[c * WG + tl];
         KF::template butterflies<2>(v, t, wf, twg);
         PF_FSTAMP(5);
         // ================= lane 0: its registers into the slot order of the regular pairing (through LDS: no selects, no registers)
@@ -257,36 +264,18 @@ fastconv_fused32_kernel(const float* __restrict__ x, float* __restrict__ y, cons
                 for (int i = 0; i < 24; ++i) v[i] = lds_ld(pscr + Fir32::perm(i));
             }
         }
-        // ================= packed spectrum -> X[k] (real finalize), x Hf / Nfft, X'[k] -> packed spectrum of the inverse (real preprocess):
+        // ================= Z'[k] = A_k Z[k] + B_k conj Z[n - k]: real finalize, x Hf / Nfft and real preprocess folded per bin (fir32_coef_kernel);
         //                   slot d holds bin k, slot 31 - d its mirror n - k
 #pragma unroll
+        for (int c = 16; c < 32; ++c) ab[c] = HP[c * WG + tl];
+#pragma unroll
         for (int d = 0; d < R; ++d) {
-            const CX w = pair_tw(d);
-            const CX A = v[d], B = v[31 - d];
-            // real finalize without its factor 1/2 (folded into HP): X[k] = S + D, X[n - k] = conj(S - D), S = A + conj B, D = -i W (A - conj B)
-            typename KF::Pair f;
-            {
-                const CX su = add_conj(A, B), m = cmul(sub_conj(A, B), w);
-                f.a = add_rot<FWD>(su, m);
-                f.b = conj(sub_rot<FWD>(su, m));
-            }
-            const F4 ha4 = hh[d >> 1], hb4 = hh[(31 - d) >> 1];
-            const CX ha = (d & 1) ? mk<T>(ha4.z, ha4.w) : mk<T>(ha4.x, ha4.y);
-            const CX hb = ((31 - d) & 1) ? mk<T>(hb4.z, hb4.w) : mk<T>(hb4.x, hb4.y);
-            CX xa = cmul(f.a, ha), xb = cmul(f.b, hb);
-            typename KB::Pair r = KB::pair1(xa, xb, w);
-            if (d == 15) {
-                // thread 0: slot 15 = bin 0 = (DC, Nyquist) packed in one complex (two real products, src/pffft_priv_impl.h:1680-1683),
-                // slot 16 = bin n/2 (its own mirror: X = conj Z, Z' = 2 conj X')
-                const CX x0 = mk<T>(A.x + A.y, A.x - A.y);
-                const CX p0 = mk<T>(x0.x * ha.x, x0.y * ha.y);
-                const CX z0 = mk<T>(p0.x + p0.y, p0.x - p0.y);
-                const CX xh = cmul(conj(B), hb);
-                const CX zh = mk<T>((T)2 * xh.x, (T)-2 * xh.y);
-                r.a = KF::sel(first, z0, r.a);
-                r.b = KF::sel(first, zh, r.b);
-            }
-            v[d] = r.a; v[31 - d] = r.b;
+            const CX zA = v[d], zB = v[31 - d];
+            const F4 ca = ab[2 * d], cb = ab[2 * d + 1];
+            // thread 0, slot 15: bin 0 = (DC, Nyquist) is its own mirror (slot 16 = bin n/2 has B = 0)
+            const CX mA = d == 15 ? KF::sel(first, zA, zB) : zB;
+            v[d] = fir32_fold(mk<T>(ca.x, ca.y), zA, mk<T>(ca.z, ca.w), mA);
+            v[31 - d] = fir32_fold(mk<T>(cb.x, cb.y), zB, mk<T>(cb.z, cb.w), zA);
         }
         PF_FSTAMP(6);
         if constexpr (PREF == 1) gather(gn, tl);

@@ -50,11 +50,11 @@ int main() {
     for (int k = 0; k < n; ++k) { H[k].x = 1.0f / Nfft; H[k].y = 0; }
     float *x, *y; cx<float> *dtw, *dtwr, *dH; unsigned* ctr; vec4<float>* HP;
     CK(hipMalloc(&x, L * nsig * 4)); CK(hipMalloc(&y, L * nsig * 4)); CK(hipMemset(x, 0, L * nsig * 4)); CK(hipMalloc(&ctr, 64));
-    CK(hipMalloc(&dtw, n * 8)); CK(hipMalloc(&dtwr, (n / 2 + 1) * 8)); CK(hipMalloc(&dH, n * 8)); CK(hipMalloc(&HP, n * 8));
+    CK(hipMalloc(&dtw, n * 8)); CK(hipMalloc(&dtwr, (n / 2 + 1) * 8)); CK(hipMalloc(&dH, n * 8)); CK(hipMalloc(&HP, n * 16));
     CK(hipMemcpy(dtw, tw.data(), n * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dtwr, twr.data(), (n / 2 + 1) * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dH, H.data(), n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(fir32_coef_kernel, dim3(1), dim3(Fir32::WG), 0, 0, dH, HP);
+    hipLaunchKernelGGL(fir32_coef_kernel, dim3(1), dim3(Fir32::WG), 0, 0, dH, dtwr, HP);
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("clock rate %d kHz, %d CUs\n", prop.clockRate, cus);
