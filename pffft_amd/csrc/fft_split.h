@@ -122,7 +122,7 @@ fastconv_split_kernel(const float* __restrict__ x, float* __restrict__ y, const 
     const unsigned xcd = blockIdx.x & 7u;
     const long long rest = nblk_all - 2ll * gridDim.x, xper = rest > 0 ? (rest + 7) / 8 : 0;
     const long long xbase = 2ll * gridDim.x + xcd * xper, xend = xbase + xper < nblk_all ? xbase + xper : nblk_all;
-    unsigned* cnext = ctr + (xmode ? xcd : 0u);
+    unsigned* cnext = dyn ? ctr + (xmode ? xcd : 0u) : nullptr;      // (formed only when there is a counter: no arithmetic on a null pointer)
     auto grabbed = [&](unsigned v) -> unsigned {
         if (!xmode) return 2u * gridDim.x + v;
         const long long gg = xbase + v;
