@@ -29,6 +29,7 @@
 // iteration only publishes the next work index.
 #pragma once
 #include "cxmath.h"
+#include "fft_tiled.h"   // lds_ld_c
 
 namespace pf {
 
@@ -135,6 +136,11 @@ __device__ __forceinline__ void c1024_part_a(const C1024V4 (&raw)[8], cx<float>*
     wave_lds_fence();
 }
 
+template <int Q> __device__ __forceinline__ void c1024_rd16(cx<float> (&m)[16], const cx<float>* rd) {
+    m[Q] = lds_ld_c<Q * 64>(rd);
+    if constexpr (Q + 1 < 16) c1024_rd16<Q + 1>(m, rd);
+}
+
 // part B: X1 read, S2, X2, S3, store
 template <int DIR, int OUT_INTERNAL>
 __device__ __forceinline__ void c1024_part_b(float* out, size_t t, cx<float>* wl, float* wf,
@@ -145,8 +151,7 @@ __device__ __forceinline__ void c1024_part_b(float* out, size_t t, cx<float>* wl
     C m[16];
     {
         const C* rd = wl + (L >> 3) * C1024_S1 + (L & 7);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) m[q] = rd[8 * q];
+        c1024_rd16<0>(m, rd);                                     // sixteen single ds_read_b64 (fft_tiled.h lds_ld_c: no ds_read2 pairing)
     }
     wave_lds_fence();
     // ---- S2: radix-16 over a, twiddle W128^(c * ka) = W1024^(8 c ka) ----
