@@ -87,6 +87,7 @@ template <typename T, int LOGL, int PP, int R0 = 1> struct TileGeom {
     // that image only - L = 1024 on 64-byte runs: 64 KiB + tables = 75 KiB instead of 100, L = 512 on 128-byte runs 76 instead of 84:
     // TWO workgroups per CU where one ran alone with nothing to overlap its barrier-separated phases
     static constexpr size_t IMG_BYTES_PLAIN = (size_t)L * PP * 16 + 256;
+    static constexpr bool SWZ = LOGL == 10 && PP == 4 && R0 == 1;         // XOR-swizzled unpadded image (tile_swz) for the plain passes of this geometry
     // + W_L^k (L entries) + `levels` x 2^WB entries of the four-step twiddle table.  WB = 9 (two levels reach M = 2^18, three
     // 2^27); the one tile that fills LDS - L = 1024 with 128-byte runs (PP = 8): 147 KiB of image - takes three levels of 2^7
     // (M <= 2^21), 3 KiB instead of 12
@@ -112,6 +113,14 @@ template <int WB, typename CX> __device__ __forceinline__ CX tile_w3(const CX* w
     CX f = cmul(w3[idx & MSK], w3[(1u << WB) + ((idx >> WB) & MSK)]);
     if (lv3) f = cmul(f, w3[(2u << WB) + (idx >> (2 * WB))]);
     return f;
+}
+
+// unit index of (point pt, unit p) in the swizzled image of four units per point: the unit's slot inside its 8-unit window (two points) is XORed
+// with bits 1..3 of the point index - slot bits 1:0 with bits 2:1, the point-parity bit with the parity of bits 1..3.  Eight lanes that hold the
+// same unit of eight consecutive even (or odd) points, two lanes on points t R + d and (t + 1) R + d (first stage, R = 2, 4, 8), two lanes on adjacent
+// points (later stages) and sixteen lanes on four consecutive points all fall into distinct 16-byte slots of the 32 / 64 banks
+__device__ __forceinline__ int tile_swz(int pt, int p) {
+    return ((pt << 2) | p) ^ (((((pt >> 1) ^ (pt >> 2) ^ (pt >> 3)) & 1) << 2) | ((pt >> 1) & 3));
 }
 
 // SEQC = 1: pass A (adjacent columns, four-step twiddle)   SEQC = 0: pass B (rows in, transposing store)
@@ -149,16 +158,24 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     // internal-layout input); a plain column pass touches the image only in whole unit rows - lanes (t, p), p fastest - and those are
     // conflict-free exactly WITHOUT it: ds_read_b128 of four consecutive rows at a pitch of 9 units costs 8 cycles against 4 (tools/lds_sim.py;
     // rocprofv3 had 0.56 conflict cycles per active cycle on pass A of N = 2^20).  The LDS size stays that of the padded image.
-    constexpr int PITCH = (SEQC && !IINT) ? PP : G::PITCH;
+    // SWZ (round 6): the L = 1024 tiles (64-byte runs, PP = 4) keep an UNPADDED image whose 16-byte units are XOR-swizzled by their point index
+    // (tile_swz): every access pattern of the kernel - the transposing write of a row pass (16-byte units now: a thread loads two adjacent points
+    // of every row), the stage reads and writes of every Ns, the copy-out - is conflict-free in tools/lds_sim.py, where the padded image (pitch
+    // 5 units) cost 2.33 x the ideal LDS cycles (rocprofv3: 0.567 conflict cycles per active cycle on pass B of N = 2^20), and the image is 64 KiB
+    // instead of 80: TWO workgroups per CU where the row pass ran alone
+    constexpr bool SWZ = G::SWZ && !OINT && !IINT && RMODE == 0;
+    constexpr int PITCH = (SWZ || (SEQC && !IINT)) ? PP : G::PITCH;
     // odd first stage on a pass-A tile (not from the internal layout): the loads ARE its operands, point j + q 2^LOGL of butterfly
     // j = t + TPT u (u < UB0, predicated on j < 2^LOGL)
     constexpr int RA = G::RA, RB = G::RB, NODD = G::NODD;
     constexpr int NB0 = L / RA, UB0 = (8 + RA - 1) / RA;
     constexpr bool ODD_DIRECT = R0 > 1 && SEQC && !IINT;
-    constexpr int NLD = ODD_DIRECT ? UB0 * RA : SEQC ? 8 : C * L / WG;   // loads per thread and tile
+    constexpr bool SWZ_ROWS2 = SWZ && !SEQC && S == 2;                    // row pass, float: 16-byte loads of two adjacent points per row
+    constexpr int NLD = ODD_DIRECT ? UB0 * RA : SEQC ? 8 : SWZ_ROWS2 ? C : C * L / WG;   // loads per thread and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     U* img = reinterpret_cast<U*>(smem);
-    constexpr size_t IMGB = (SEQC && !IINT && RMODE == 0) ? G::IMG_BYTES_PLAIN : G::IMG_BYTES;
+    constexpr size_t IMGB = (SWZ || (SEQC && !IINT && RMODE == 0)) ? G::IMG_BYTES_PLAIN : G::IMG_BYTES;
+    auto ua = [](int pt, int pu) -> int { if constexpr (SWZ) return tile_swz(pt, pu); else return pt * PITCH + pu; };
     CX* wl = reinterpret_cast<CX*>(smem + IMGB);
     CX* w3 = wl + L;
     const int tid = threadIdx.x, t = tid / PP, p = tid % PP;
@@ -203,7 +220,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     };
     // pass A: unit p of points t + TPT m straight into the stage-0 operand registers;
     // pass B: elements g = tid + i WG of the [sequence][point] tile (coalesced over the points of a row)
-    typedef typename std::conditional<SEQC != 0, U, CX>::type LD;
+    typedef typename std::conditional<SEQC != 0 || SWZ_ROWS2, U, CX>::type LD;
     constexpr int UPB_ = 2 * (int)sizeof(T), UPP_ = (C / 4) * UPB_;   // 16-byte units per block / per point row of the internal layout
     auto issue_loads = [&](const CX* src, LD (&r)[NLD], unsigned long long eb, int pv) {
         if constexpr (IINT) {
@@ -230,6 +247,11 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 for (int m = 0; m < 8; ++m)
                     r[m] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)(t + TPT * m) * D.ips + S * p));
             }
+        } else if constexpr (SWZ_ROWS2) {
+            static_assert(!SWZ_ROWS2 || 2 * WG == L, "two points per thread");
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                if (i < pv * S) r[i] = __builtin_nontemporal_load(reinterpret_cast<const U*>(src + (unsigned long long)i * D.iss + 2 * tid));
         } else {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
@@ -335,18 +357,33 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
             for (int m = 0; m < 8; ++m) v[m] = cur[m];
         } else if constexpr (SEQC) {
             // odd first stage: cur[] holds its operands
+        } else if constexpr (SWZ_ROWS2) {
+            // cur[seq] = points 2 tid, 2 tid + 1 of row seq: whole units (sequences 2u, 2u + 1) of those two points
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                U a, b;
+                a.x = cur[2 * u].x; a.y = cur[2 * u].y; a.z = cur[2 * u + 1].x; a.w = cur[2 * u + 1].y;
+                b.x = cur[2 * u].z; b.y = cur[2 * u].w; b.z = cur[2 * u + 1].z; b.w = cur[2 * u + 1].w;
+                img[ua(2 * tid, u)] = a;
+                img[ua(2 * tid + 1, u)] = b;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = img[ua(t + TPT * m, p)];
+            __syncthreads();
         } else {
             // C rows, contiguous over their points: transposed into the [point][sequence] image
             CX* imgc = reinterpret_cast<CX*>(img);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int g = tid + i * WG, seq = WG == L ? i : g / L, pt = WG == L ? tid : g % L;
-                imgc[pt * (PITCH * S) + seq] = cur[i];
+                if constexpr (SWZ) img[ua(pt, seq)] = *reinterpret_cast<const U*>(&cur[i]);      // (double: an element is a unit)
+                else imgc[pt * (PITCH * S) + seq] = cur[i];
             }
             __syncthreads();
             if constexpr (R0 == 1) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p];
+                for (int m = 0; m < 8; ++m) v[m] = img[ua(t + TPT * m, p)];
                 __syncthreads();
             }
         }
@@ -443,7 +480,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 static_assert(Ns * R <= L && L % (Ns * R) == 0, "stage shape");
                 __syncthreads();                     // every thread wrote its outputs of the stage before
 #pragma unroll
-                for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p];
+                for (int m = 0; m < 8; ++m) v[m] = img[ua(t + TPT * m, p)];
                 __syncthreads();                     // ... and read its operands: the image is free again
             }
             // Ns divides TPT (Ns R <= L, R <= 8): (t + TPT u) mod Ns = t mod Ns, (t + TPT u) div Ns = t div Ns + u TPT / Ns
@@ -493,7 +530,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                         static_assert(!OINT || (R == 8 && B == 1 && Ns == L / 8), "last stage shape");
                         img[(pbase + d * Ns) * PITCH + p + (d / 2) * G::QSKEW] = x;   // row j + d L/8 lies in quarter d / 2
                     } else {
-                        img[(pbase + d * Ns) * PITCH + p] = x;
+                        img[ua(pbase + d * Ns, p)] = x;
                     }
                 }
             }
@@ -624,7 +661,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int g = tid + i * WG, pt = g / PP, pu = g % PP;
-            if (pu < pv) __builtin_nontemporal_store(img[pt * PITCH + pu], reinterpret_cast<U*>(dst + (unsigned long long)pt * D.ops + S * pu));
+            if (pu < pv) __builtin_nontemporal_store(img[ua(pt, pu)], reinterpret_cast<U*>(dst + (unsigned long long)pt * D.ops + S * pu));
         }
         }
         // next tile: the group's next one, or the first of the next group (whose successor was published at this group's start)
