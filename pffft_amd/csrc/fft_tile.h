@@ -92,7 +92,12 @@ template <typename T, int LOGL, int PP, int R0 = 1> struct TileGeom {
     // 2^27); the one tile that fills LDS - L = 1024 with 128-byte runs (PP = 8): 147 KiB of image - takes three levels of 2^7
     // (M <= 2^21), 3 KiB instead of 12
     static constexpr int WB = (LOGL == 10 && R0 == 1) ? 7 : 9;
-    __host__ __device__ static constexpr size_t lds_bytes(int levels, bool plain = false) { return (plain ? IMG_BYTES_PLAIN : IMG_BYTES) + ((size_t)L + ((size_t)levels << WB)) * 2 * sizeof(T) + 16; }
+    // (the swizzled geometry in double keeps HALF the W_L table - W_L^(k + L/2) = -W_L^k: 8 KiB instead of 16, which is what lets two of its
+    //  workgroups share a CU's 160 KiB)
+    static constexpr bool HALFW = SWZ && sizeof(T) == 8;
+    __host__ __device__ static constexpr size_t lds_bytes(int levels, bool plain = false) {
+        return (plain ? IMG_BYTES_PLAIN : IMG_BYTES) + ((size_t)((plain && HALFW) ? L / 2 : L) + ((size_t)levels << WB)) * 2 * sizeof(T) + 16;
+    }
     __host__ __device__ static constexpr int rad(int s) {
         if (s < NODD) return s == 0 ? RA : RB;
         s -= NODD;
@@ -115,12 +120,15 @@ template <int WB, typename CX> __device__ __forceinline__ CX tile_w3(const CX* w
     return f;
 }
 
-// unit index of (point pt, unit p) in the swizzled image of four units per point: the unit's slot inside its 8-unit window (two points) is XORed
-// with bits 1..3 of the point index - slot bits 1:0 with bits 2:1, the point-parity bit with the parity of bits 1..3.  Eight lanes that hold the
-// same unit of eight consecutive even (or odd) points, two lanes on points t R + d and (t + 1) R + d (first stage, R = 2, 4, 8), two lanes on adjacent
-// points (later stages) and sixteen lanes on four consecutive points all fall into distinct 16-byte slots of the 32 / 64 banks
+// unit index of (point pt, unit p) in the swizzled image of four units per point (L = 1024): the unit's slot inside its 8-unit window (two
+// points) is XORed with a mask that is linear in bits 1, 2, 3, 8, 9 of the point index - masks 5, 2, 4, 5, 3, found by exhaustive search with
+// tools/lds_sim.py (tools/swz_search.py): every access pattern of the kernel, float and double, costs the ideal number of LDS cycles - the
+// transposing write of a row pass (eight lanes on the same unit of eight consecutive even / odd / plain points), the stage reads (sixteen lanes on
+// four points), the stage writes (two lanes on points 2 t + d and 2 t + 2 + d in the radix-2 first stage, on adjacent points later), the copy-out,
+// and the quarter gathers of the internal layout (points ptq + m L/4: bits 8, 9) in both directions
 __device__ __forceinline__ int tile_swz(int pt, int p) {
-    return ((pt << 2) | p) ^ (((((pt >> 1) ^ (pt >> 2) ^ (pt >> 3)) & 1) << 2) | ((pt >> 1) & 3));
+    const int b18 = ((pt >> 1) ^ (pt >> 8)) & 1;
+    return ((pt << 2) | p) ^ (b18 * 5) ^ ((pt >> 1) & 2) ^ ((pt >> 1) & 4) ^ (((pt >> 9) & 1) * 3);
 }
 
 // SEQC = 1: pass A (adjacent columns, four-step twiddle)   SEQC = 0: pass B (rows in, transposing store)
@@ -160,10 +168,10 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     // rocprofv3 had 0.56 conflict cycles per active cycle on pass A of N = 2^20).  The LDS size stays that of the padded image.
     // SWZ (round 6): the L = 1024 tiles (64-byte runs, PP = 4) keep an UNPADDED image whose 16-byte units are XOR-swizzled by their point index
     // (tile_swz): every access pattern of the kernel - the transposing write of a row pass (16-byte units now: a thread loads two adjacent points
-    // of every row), the stage reads and writes of every Ns, the copy-out - is conflict-free in tools/lds_sim.py, where the padded image (pitch
-    // 5 units) cost 2.33 x the ideal LDS cycles (rocprofv3: 0.567 conflict cycles per active cycle on pass B of N = 2^20), and the image is 64 KiB
+    // of every row), the stage reads and writes of every Ns, the copy-out, the gathers of the internal layout - is conflict-free in
+    // tools/lds_sim.py, where the padded image (pitch 5 units) cost 2.33 x the ideal LDS cycles (rocprofv3: 0.567 conflict cycles per active cycle on pass B of N = 2^20), and the image is 64 KiB
     // instead of 80: TWO workgroups per CU where the row pass ran alone
-    constexpr bool SWZ = G::SWZ && !OINT && !IINT && RMODE == 0;
+    constexpr bool SWZ = G::SWZ && RMODE == 0;
     constexpr int PITCH = (SWZ || (SEQC && !IINT)) ? PP : G::PITCH;
     // odd first stage on a pass-A tile (not from the internal layout): the loads ARE its operands, point j + q 2^LOGL of butterfly
     // j = t + TPT u (u < UB0, predicated on j < 2^LOGL)
@@ -177,10 +185,16 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     constexpr size_t IMGB = (SWZ || (SEQC && !IINT && RMODE == 0)) ? G::IMG_BYTES_PLAIN : G::IMG_BYTES;
     auto ua = [](int pt, int pu) -> int { if constexpr (SWZ) return tile_swz(pt, pu); else return pt * PITCH + pu; };
     CX* wl = reinterpret_cast<CX*>(smem + IMGB);
-    CX* w3 = wl + L;
+    constexpr bool HALFW = SWZ && G::HALFW;
+    constexpr int WLN = HALFW ? L / 2 : L;
+    CX* w3 = wl + WLN;
+    auto wl_at = [&](int idx) -> CX {
+        if constexpr (HALFW) { const CX w = wl[idx & (L / 2 - 1)]; return (idx & (L / 2)) ? mk<T>(-w.x, -w.y) : w; }
+        else return wl[idx];
+    };
     const int tid = threadIdx.x, t = tid / PP, p = tid % PP;
 
-    for (int i = tid; i < L; i += WG) wl[i] = tile_unit_root<T>((double)i / (double)L);
+    for (int i = tid; i < WLN; i += WG) wl[i] = tile_unit_root<T>((double)i / (double)L);
     constexpr int WB = G::WB;
     const bool lv3 = D.M > (1ull << (2 * WB));
     if (SEQC) {
@@ -331,25 +345,26 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
             for (int i = 0; i < 8; ++i) {
                 const int g = tid + i * WG, ptq = g / UPP_, rr = g % UPP_, bb = rr / UPB_, m = (rr / (UPB_ / 4)) % 4, sub = rr % (UPB_ / 4);
                 U* dp = img + (ptq + m * (L / 4)) * PITCH + m * G::QSKEW + bb * (4 / S);   // quarter rows skewed: conflict-free
+                [[maybe_unused]] const int prow = ptq + m * (L / 4), pun = bb * (4 / S);
                 const U x = cur[i];
                 if constexpr (S == 2) {           // sub = part: even lane re0..3, odd lane im0..3 -> sequences (0, 1) / (2, 3)
                     const T s0 = dpp_xor1(sub ? x.x : x.z), s1 = dpp_xor1(sub ? x.y : x.w);
                     U o;
                     if (sub) { o.x = s0; o.y = x.z; o.z = s1; o.w = x.w; }
                     else { o.x = x.x; o.y = s0; o.z = x.y; o.w = s1; }
-                    dp[sub] = o;
+                    if constexpr (SWZ) img[ua(prow, pun + sub)] = o; else dp[sub] = o;
                 } else {                          // sub = 2 part + (l / 2): lanes (re01, re23, im01, im23) -> sequences 0, 2, 1, 3
                     const T sv = dpp_xor2(sub >> 1 ? x.x : x.y);
                     U o;
                     if (sub >> 1) { o.x = sv; o.y = x.y; }
                     else { o.x = x.x; o.y = sv; }
-                    dp[2 * (sub & 1) + (sub >> 1)] = o;
+                    if constexpr (SWZ) img[ua(prow, pun + 2 * (sub & 1) + (sub >> 1))] = o; else dp[2 * (sub & 1) + (sub >> 1)] = o;
                 }
             }
             __syncthreads();
             if constexpr (R0 == 1) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) v[m] = img[(t + TPT * m) * PITCH + p + (m / 2) * G::QSKEW];   // row t + m L/8 lies in quarter m / 2
+                for (int m = 0; m < 8; ++m) v[m] = SWZ ? img[ua(t + TPT * m, p)] : img[(t + TPT * m) * PITCH + p + (m / 2) * G::QSKEW];   // row t + m L/8 lies in quarter m / 2
                 __syncthreads();
             }
         } else if constexpr (SEQC && R0 == 1) {
@@ -448,7 +463,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
             const int tk = t % RA, tq = t / RA;
             CX w[RB];
 #pragma unroll
-            for (int q = 1; q < RB; ++q) w[q] = wl[(q * tk) * (L / (RA * RB))];
+            for (int q = 1; q < RB; ++q) w[q] = wl_at((q * tk) * (L / (RA * RB)));
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 const int j = t + TPT * u;
@@ -493,7 +508,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 if constexpr (s > 0) {
                     const int k = tk;
 #pragma unroll
-                    for (int q = 1; q < R; ++q) w[q] = wl[(q * k) * (L / (Ns * R))];
+                    for (int q = 1; q < R; ++q) w[q] = wl_at((q * k) * (L / (Ns * R)));
                 }
                 CX o[S][R];
 #pragma unroll
@@ -528,7 +543,8 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                     for (int sq = 0; sq < S; ++sq) TU::set(x, sq, o[sq][d]);
                     if constexpr (OINT && s == NS - 1 && NS > 1) {
                         static_assert(!OINT || (R == 8 && B == 1 && Ns == L / 8), "last stage shape");
-                        img[(pbase + d * Ns) * PITCH + p + (d / 2) * G::QSKEW] = x;   // row j + d L/8 lies in quarter d / 2
+                        if constexpr (SWZ) img[ua(pbase + d * Ns, p)] = x;
+                        else img[(pbase + d * Ns) * PITCH + p + (d / 2) * G::QSKEW] = x;   // row j + d L/8 lies in quarter d / 2
                     } else {
                         img[ua(pbase + d * Ns, p)] = x;
                     }
@@ -647,11 +663,12 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 U* dp = reinterpret_cast<U*>(dst + 4 * (ebase + (unsigned long long)ptq * D.ops + 4 * bb)) + r % UPB;
                 U o;
                 if constexpr (S == 2) {           // sub = part p: (re or im) of the four sequences of the group
-                    const U u0 = sp[0], u1 = sp[1];
+                    const U u0 = SWZ ? img[ua(ptq + m * (L / 4), bb * UPS)] : sp[0], u1 = SWZ ? img[ua(ptq + m * (L / 4), bb * UPS + 1)] : sp[1];
                     if (sub) { o.x = u0.y; o.y = u0.w; o.z = u1.y; o.w = u1.w; }
                     else { o.x = u0.x; o.y = u0.z; o.z = u1.x; o.w = u1.z; }
                 } else {                          // sub = 2 p + (l / 2): part p of sequences 2 (l/2), 2 (l/2) + 1
-                    const U u0 = sp[2 * (sub & 1)], u1 = sp[2 * (sub & 1) + 1];
+                    const U u0 = SWZ ? img[ua(ptq + m * (L / 4), bb * UPS + 2 * (sub & 1))] : sp[2 * (sub & 1)];
+                    const U u1 = SWZ ? img[ua(ptq + m * (L / 4), bb * UPS + 2 * (sub & 1) + 1)] : sp[2 * (sub & 1) + 1];
                     if (sub >> 1) { o.x = u0.y; o.y = u1.y; }
                     else { o.x = u0.x; o.y = u1.x; }
                 }

@@ -16,9 +16,9 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
                           bool out_int, bool in_int, int pf_force) {
     typedef TileGeom<T, LOGL, PP, R0> G;
     const bool fw0 = dir == PFFFT_FORWARD;
-    // the kernels that keep an unpadded image (fft_tile.h IMG_BYTES_PLAIN): column passes off the canonical layout, and - round 6 - the row passes
-    // of the swizzled L = 1024 geometry that store the canonical layout
-    const bool plain = D.seq_contig ? !(in_int && !fw0) : (G::SWZ && !(out_int && fw0));
+    // the kernels that keep an unpadded image (fft_tile.h IMG_BYTES_PLAIN): column passes off the canonical layout, and - round 6 - every pass
+    // of the swizzled L = 1024 geometry
+    const bool plain = G::SWZ || (D.seq_contig && !(in_int && !fw0));
     if (D.M > (1ull << (3 * G::WB))) { g_last_error = "pffft_hip: four-step modulus beyond the tile's twiddle table"; return (int)hipErrorInvalidValue; }
     const size_t lds = G::lds_bytes(D.M > (1ull << (2 * G::WB)) ? 3 : 2, plain);
     void (*k)(const cx<T>*, cx<T>*, unsigned long long, TileDesc, unsigned*);
