@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpffft_hip.so")
-SOURCES = ["pffft_hip.hip", "dma_tu.hip", "conv_tu.hip", "tile_tu.hip", "tile_real_tu.hip", "tileg_tu.hip"] + [f"tile_mr{r}_tu.hip" for r in (3, 5, 9, 15, 25, 27, 45)] + [f"stock_ct_{t}_{h}_gen.hip" for t in ("f32c", "f32r", "f64c", "f64r") for h in "ab"]
+SOURCES = ["pffft_hip.hip", "dma_tu.hip", "conv_tu.hip", "tile_tu.hip", "tile_real_tu.hip", "tileg_tu.hip", "one_tu.hip"] + [f"one_k{f}_tu.hip" for f in (0, 2, 4, 5, 8, 10, 12, 13)] + [f"tile_mr{r}_tu.hip" for r in (3, 5, 9, 15, 25, 27, 45)] + [f"stock_ct_{t}_{h}_gen.hip" for t in ("f32c", "f32r", "f64c", "f64r") for h in "ab"]
 OBJDIR = os.path.join(HERE, "..", "build", "obj")
 # the PFDSP mixers are their own library, like the reference's PFDSP target (CMakeLists.txt:206)
 DSP_LIB = os.path.join(HERE, "libpfdsp_hip.so")

@@ -1,0 +1,357 @@
+// One HBM pass for the vectors that fill LDS ONCE but not twice (round 6): mixed-radix n with 80 KiB < vector <= 144 KiB - complex float
+// n = 10240 ... 18432, double 5120 ... 9216, and the real transforms on those cores - which the two-image Stockham kernels of fft_stock.h
+// cannot hold and which until now ran the two / three tile passes beyond LDS (0.27-0.38 of the roofline, real 0.17-0.25).
+//
+// Reference: the same functions as fft_stock.h - the radix passes and their drivers (src/pffft_priv_impl.h:122-901, cfftf1_ps :1004-1048,
+// rfftf1_ps / rfftb1_ps :809-901), real finalize / preprocess (:1330-1462), the reorder of pffft_zreorder (:1158-1193) - as ONE sweep.
+//
+// Shape: one 512-thread workgroup per vector and CU, ONE image in LDS, every exchange IN PLACE:
+//   * Stockham autosort in 2-4 stages of radix 3 ... 32 (cxmath.h dftR; the plan is data: StockStage of fft_stock.h, paddings from the
+//     same bank model), a stage's butterflies dealt round robin to the threads; a thread reads ALL its operands, the workgroup meets at a
+//     barrier, then it writes its results - the image a stage writes may be padded differently from the one it read;
+//   * canonical complex input goes from HBM straight into the first stage's operand registers, canonical complex output from the last
+//     stage's results straight to HBM (8 / 16-byte accesses, consecutive lanes on consecutive points);
+//   * the pffft-internal layout enters / leaves through the natural image: item i = (block b, quarter q) is eight scalars at offset 8 i of
+//     the layout (two dense 16 / 32-byte accesses per lane) and four bins of the natural image (bin_of, fft_generic.h);
+//   * real transforms: the pair pass runs on the natural image in place (bins k and n - k belong to one work item) or, where the
+//     canonical half-complex spectrum is the input / output, between HBM and the image;
+//   * backward = conj o forward o conj (one set of stage bodies); base twiddles W_(Ns R)^jm from a compact table in LDS, powers recomputed;
+//   * vectors are pulled in order from a work counter, the first one of a workgroup static.
+#pragma once
+#include "fft_stock.h"
+
+namespace pf {
+
+constexpr int ONE_WG = 512;
+template <typename T> constexpr int one_nmax() { return sizeof(T) == 4 ? 18432 : 9216; }
+// trips of a stage of radix R: butterflies per thread (compile-time bound, the run-time count is predicated): as many as keep a thread's
+// operands within 48 (float) / 24 (double) complex registers - the planner only uses a radix where n / R butterflies fit (one_build)
+__host__ __device__ constexpr int one_trips_of(bool is_double, int R) { return (is_double ? 24 : 48) / R < 1 ? 1 : (is_double ? 24 : 48) / R; }
+template <typename T, int R> constexpr int one_trips() { return one_trips_of(sizeof(T) == 8, R); }
+
+template <typename T> struct OneLds { size_t tab = 0, twr = 0, next = 0, total = 0; };
+template <typename T> __host__ __device__ constexpr OneLds<T> one_lds(const StockPlan& p, bool real) {
+    OneLds<T> l{};
+    size_t o = (size_t)p.img * sizeof(cx<T>);
+    l.tab = o; o += (size_t)(p.ctab + 1) * sizeof(cx<T>);
+    l.twr = o; if (real) o += ((size_t)64 + p.n / 128 + 2) * sizeof(cx<T>);
+    l.next = o; o += 16;
+    l.total = o;
+    return l;
+}
+
+template <typename T> struct OneCtx {
+    cx<T>* img;            // the image
+    const cx<T>* tab;      // compact base twiddles
+    const cx<T>* gsrc;     // canonical complex input vector (first stage from HBM)
+    cx<T>* gdst;           // canonical complex output vector (last stage to HBM)
+    int tid;
+    bool cj_in, cj_out;
+};
+
+// operand q of a stage times W^(q jm), W = p1 (the schemes of fft_stock.h sk_stage: powers at most five products deep)
+template <typename T, int R> __device__ __forceinline__ void one_twiddle(cx<T> (&v)[R], cx<T> p1) {
+    typedef cx<T> CX;
+    if constexpr (R > 16) {
+        const CX w2 = cmul(p1, p1), w3 = cmul(w2, p1), w4 = cmul(w2, w2);
+        CX blk = w4;
+#pragma unroll
+        for (int q = 1; q < R; ++q) {
+            const int aa = q >> 2, b = q & 3;
+            const CX wb = b == 1 ? p1 : (b == 2 ? w2 : w3);
+            CX t;
+            if (aa == 0) t = wb;
+            else t = b == 0 ? blk : cmul(blk, wb);
+            v[q] = cmul(v[q], t);
+            if (aa >= 1 && b == 3) blk = cmul(blk, w4);
+        }
+    } else {
+        CX p[R < 4 ? 4 : R];
+        p[1] = p1;
+        p[2] = cmul(p[1], p[1]);
+        if constexpr (R > 3) p[3] = cmul(p[2], p[1]);
+        if constexpr (R > 4) p[4] = cmul(p[2], p[2]);
+        if constexpr (R > 5) p[5] = cmul(p[4], p[1]);
+        if constexpr (R > 6) p[6] = cmul(p[3], p[3]);
+        if constexpr (R > 7) p[7] = cmul(p[4], p[3]);
+        if constexpr (R > 8) p[8] = cmul(p[4], p[4]);
+        if constexpr (R > 9) p[9] = cmul(p[8], p[1]);
+        if constexpr (R > 10) p[10] = cmul(p[5], p[5]);
+        if constexpr (R > 11) p[11] = cmul(p[8], p[3]);
+        if constexpr (R > 12) p[12] = cmul(p[6], p[6]);
+        if constexpr (R > 13) p[13] = cmul(p[8], p[5]);
+        if constexpr (R > 14) p[14] = cmul(p[7], p[7]);
+        if constexpr (R > 15) p[15] = cmul(p[8], p[7]);
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[q] = cmul(v[q], p[q]);
+    }
+}
+
+// One stage, in place.  SRC / DST: 0 = HBM (the canonical complex vector), 1 = the LDS image.
+//   operand q of butterfly j: logical point j + q nb of the image the previous stage wrote (blocks of Ns points padded by rpad);
+//   result d goes to logical point (j div Ns) Ns R + (j mod Ns) + d Ns of this stage's image (blocks of Ns R points padded to wblk).
+// Barriers: between the reads and the writes of an LDS -> LDS stage; before the writes of an HBM -> LDS stage (the previous vector's last
+// readers); after every stage that wrote the image.
+template <typename T, int R, int SRC, int DST>
+__device__ __forceinline__ void one_stage(const StockStage& st, const OneCtx<T>& c) {
+    typedef cx<T> CX;
+    constexpr int K = one_trips<T, R>();
+    CX v[K][R];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int j = c.tid + k * ONE_WG;
+        if (j < st.nb) {
+            if constexpr (SRC == 1) {
+                const int jd = st.Ns > 1 ? udiv(j, st.m_Ns) : j;
+                const CX* p = c.img + j + jd * st.rpad;
+#pragma unroll
+                for (int q = 0; q < R; ++q) v[k][q] = p[q * st.rstride];
+            } else {
+                const CX* p = c.gsrc + j;
+#pragma unroll
+                for (int q = 0; q < R; ++q) v[k][q] = __builtin_nontemporal_load(p + q * st.nb);
+            }
+        }
+    }
+    if constexpr (DST == 1) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int j = c.tid + k * ONE_WG;
+        if (j < st.nb) {
+            int jd = j, jm = 0;
+            if (st.Ns > 1) { jd = udiv(j, st.m_Ns); jm = j - jd * st.Ns; }
+            if (c.cj_in) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) v[k][q].y = -v[k][q].y;
+            }
+            if (st.Ns > 1) one_twiddle<T, R>(v[k], c.tab[st.tw_off + jm]);
+            dftR<R, FWD>(v[k]);
+            if constexpr (DST == 1) {
+                CX* p = c.img + jd * st.wblk + jm;
+#pragma unroll
+                for (int d = 0; d < R; ++d) p[d * st.Ns] = v[k][d];
+            } else {   // last stage: Ns = nb, result d is bin j + d nb
+                CX* p = c.gdst + j;
+                if (c.cj_out) {
+#pragma unroll
+                    for (int d = 0; d < R; ++d) v[k][d].y = -v[k][d].y;
+                }
+#pragma unroll
+                for (int d = 0; d < R; ++d) __builtin_nontemporal_store(v[k][d], p + d * st.nb);
+            }
+        }
+    }
+    if constexpr (DST == 1) __syncthreads();
+}
+
+template <typename T, int SRC, int DST>
+__device__ __forceinline__ void one_run(const StockStage& st, const OneCtx<T>& c) {
+    switch (st.R) {
+        case 3: one_stage<T, 3, SRC, DST>(st, c); break;
+        case 4: one_stage<T, 4, SRC, DST>(st, c); break;
+        case 5: one_stage<T, 5, SRC, DST>(st, c); break;
+        case 6: one_stage<T, 6, SRC, DST>(st, c); break;
+        case 8: one_stage<T, 8, SRC, DST>(st, c); break;
+        case 9: one_stage<T, 9, SRC, DST>(st, c); break;
+        case 10: one_stage<T, 10, SRC, DST>(st, c); break;
+        case 12: one_stage<T, 12, SRC, DST>(st, c); break;
+        case 15: one_stage<T, 15, SRC, DST>(st, c); break;
+        case 16: one_stage<T, 16, SRC, DST>(st, c); break;
+        default:
+            if constexpr (sizeof(T) == 4) {
+                switch (st.R) {
+                    case 24: one_stage<T, 24, SRC, DST>(st, c); break;
+                    case 25: one_stage<T, 25, SRC, DST>(st, c); break;
+                    case 27: one_stage<T, 27, SRC, DST>(st, c); break;
+                    case 32: one_stage<T, 32, SRC, DST>(st, c); break;
+                    default: break;
+                }
+            }
+            break;
+    }
+}
+
+// flags: bit 0 input in the internal layout (backward), bit 1 output in the internal layout (forward), bit 2 backward, bit 3 real
+template <typename T, int FLAGS>
+__global__ void __launch_bounds__(ONE_WG, 1)
+fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, StockPlan p, const cx<T>* __restrict__ twc,
+               const cx<T>* __restrict__ twrg, unsigned* ctr) {
+    typedef cx<T> CX;
+    typedef vec4<T> V4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool in_int = FLAGS & 1, out_int = FLAGS & 2, bwd = FLAGS & 4, real = FLAGS & 8;
+    const OneLds<T> L = one_lds<T>(p, real);
+    CX* const img = reinterpret_cast<CX*>(smem_raw);
+    CX* const tab = reinterpret_cast<CX*>(smem_raw + L.tab);
+    CX* const lds0 = img;                                            // sk_twr addresses the pair-pass tables from the start of LDS
+    const int twr_off = (int)(L.twr / sizeof(CX));
+    unsigned* s_next = reinterpret_cast<unsigned*>(smem_raw + L.next);
+    const int tid = threadIdx.x, n = p.n, ns = p.ns, half = n >> 1, per = half + 1, items4 = n >> 2;
+    const size_t vs = real ? (size_t)2 * n : (size_t)2 * n;         // scalars per vector: N = 2n (real) / 2N (complex)
+    for (int i = tid; i < p.ctab; i += ONE_WG) tab[i] = twc[i];
+    if constexpr (real) sk_twr_fill<T>(lds0, twr_off, 2, twrg, n, tid, ONE_WG);
+    constexpr bool first_from_g = !in_int && !(real && bwd);
+    constexpr bool last_to_g = !out_int && !(real && !bwd);
+    constexpr int NI = (one_nmax<T>() / 4 + ONE_WG - 1) / ONE_WG;      // layout items per thread
+    constexpr int NP = (one_nmax<T>() / 2 + 1 + ONE_WG - 1) / ONE_WG;  // pair items per thread
+    __syncthreads();
+
+    // half-complex bins k, n - k -> the CONJUGATE of the packed spectrum (the stages then run a forward transform and the store conjugates):
+    // Z'[k] = S + D, Z'[n-k] = conj(S - D), S = A + B, D = i conj(W_N^k) (A - B), A = X[k], B = conj X[n-k]   (fft_stock.h, real backward)
+    auto pair_bwd = [&](int k, CX A, CX Bn, CX& Pk, CX& Pm) {
+        if (k == 0) { Pk = mk<T>(A.x + A.y, -(A.x - A.y)); Pm = Pk; }
+        else if (k == half) { Pk = mk<T>((T)2 * A.x, (T)2 * A.y); Pm = Pk; }
+        else {
+            const CX wk = sk_twr<T>(lds0, twr_off, 2, twrg, k);
+            const CX S = add_conj(A, Bn), Dm = cmulc(sub_conj(A, Bn), wk);
+            Pk = conj(add_rot<BWD>(S, Dm));
+            Pm = sub_rot<BWD>(S, Dm);
+        }
+    };
+    // packed spectrum Z -> half-complex X: X[k] = S + D, X[n-k] = conj(S - D), S = (A+B)/2, D = -(i/2) W_N^k (A-B), A = Z[k], B = conj Z[n-k]
+    auto pair_fwd = [&](int k, CX A, CX Bn, CX& Xa, CX& Xb) {
+        if (k == 0) { Xa = mk<T>(A.x + A.y, A.x - A.y); Xb = Xa; }        // (DC, Nyquist): include/pffft/pffft.h:144-152
+        else if (k == half) { Xa = conj(A); Xb = Xa; }
+        else {
+            const CX wk = sk_twr<T>(lds0, twr_off, 2, twrg, k);
+            const CX S = add_conj(A, Bn) * (T)0.5, Dm = cmul(sub_conj(A, Bn) * (T)0.5, wk);
+            Xa = add_rot<FWD>(S, Dm);
+            Xb = conj(sub_rot<FWD>(S, Dm));
+        }
+    };
+
+    size_t cur = blockIdx.x;
+    for (unsigned it = 0; cur < batch; ++it) {
+        if (ctr && tid == 0) s_next[it & 1] = atomicAdd(ctr, 1u);      // read by everyone at the end of this iteration, barriers in between
+        const T* gin = in + cur * vs;
+        T* gout = out + cur * vs;
+        OneCtx<T> c;
+        c.img = img; c.tab = tab; c.tid = tid;
+        c.gsrc = reinterpret_cast<const CX*>(gin); c.gdst = reinterpret_cast<CX*>(gout);
+        c.cj_in = false; c.cj_out = false;
+
+        // ---------------------------------------------------------------- input phases that fill the natural image
+        if constexpr (in_int) {
+            // the internal layout: item i = (b, q) holds parts re / im of four bins; complex backward: conjugated on the way in
+            V4 re[NI], im[NI];
+#pragma unroll
+            for (int r = 0; r < NI; ++r) {
+                const int i = tid + r * ONE_WG;
+                if (i < items4) {
+                    re[r] = __builtin_nontemporal_load(reinterpret_cast<const V4*>(gin + 8 * (size_t)i));
+                    im[r] = __builtin_nontemporal_load(reinterpret_cast<const V4*>(gin + 8 * (size_t)i + 4));
+                }
+            }
+            __syncthreads();                                           // the previous vector's last readers of the image
+            int tid_w = tid;
+            asm volatile("" : "+v"(tid_w));                            // (the bins are derived after the barrier: hoisted above it they cost 100 registers)
+#pragma unroll
+            for (int r = 0; r < NI; ++r) {
+                const int i = tid_w + r * ONE_WG;
+                if (i < items4) {
+                    const T sg = real ? (T)1 : (T)-1;
+                    img[bin_of(2 * i, 0, n, real)] = mk<T>(re[r].x, sg * im[r].x);
+                    img[bin_of(2 * i, 1, n, real)] = mk<T>(re[r].y, sg * im[r].y);
+                    img[bin_of(2 * i, 2, n, real)] = mk<T>(re[r].z, sg * im[r].z);
+                    img[bin_of(2 * i, 3, n, real)] = mk<T>(re[r].w, sg * im[r].w);
+                }
+            }
+            __syncthreads();
+            if constexpr (real) {                                                // pair pass in place: bins k and n - k belong to one item
+#pragma unroll 1
+                for (int k = tid; k < per; k += ONE_WG) {
+                    const CX A = img[k], Bn = (k != 0 && k != half) ? img[n - k] : A;
+                    CX Pk, Pm;
+                    pair_bwd(k, A, Bn, Pk, Pm);
+                    img[k] = Pk;
+                    if (k != 0 && k != half) img[n - k] = Pm;
+                }
+                __syncthreads();
+            }
+        } else if constexpr (real && bwd) {
+            // canonical half-complex input: X[k] and X[n - k] straight from HBM (ascending / descending runs)
+            const CX* gx = reinterpret_cast<const CX*>(gin);
+            CX pa[NP], pb[NP];
+#pragma unroll
+            for (int r = 0; r < NP; ++r) {
+                const int k = tid + r * ONE_WG;
+                if (k < per) {
+                    pa[r] = __builtin_nontemporal_load(gx + k);
+                    pb[r] = __builtin_nontemporal_load(gx + (k ? n - k : 0));
+                }
+            }
+            __syncthreads();
+            int tid_w = tid;
+            asm volatile("" : "+v"(tid_w));
+#pragma unroll
+            for (int r = 0; r < NP; ++r) {
+                const int k = tid_w + r * ONE_WG;
+                if (k < per) {
+                    CX Pk, Pm;
+                    pair_bwd(k, pa[r], pb[r], Pk, Pm);
+                    img[k] = Pk;
+                    if (k != 0 && k != half) img[n - k] = Pm;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---------------------------------------------------------------- stages (one call site per kind of stage)
+#pragma unroll 1
+        for (int si = 0; si < ns; ++si) {
+            const StockStage st = p.st[si];
+            const bool fromg = si == 0 && first_from_g, tog = si == ns - 1 && last_to_g;
+            c.cj_in = si == 0 && bwd && !real && first_from_g;   // (internal-layout input was conjugated by its deposit, real backward by the pair pass)
+            c.cj_out = tog && bwd;
+            if (first_from_g && fromg) { if constexpr (first_from_g) one_run<T, 0, 1>(st, c); }
+            else if (last_to_g && tog) { if constexpr (last_to_g) one_run<T, 1, 0>(st, c); }
+            else one_run<T, 1, 1>(st, c);
+        }
+
+        // ---------------------------------------------------------------- output phases that read the natural image
+        if constexpr (real && !bwd) {
+            if constexpr (!out_int) {
+                CX* gx = reinterpret_cast<CX*>(gout);
+#pragma unroll 1
+                for (int k = tid; k < per; k += ONE_WG) {
+                    const CX A = img[k], Bn = (k != 0 && k != half) ? img[n - k] : A;
+                    CX Xa, Xb;
+                    pair_fwd(k, A, Bn, Xa, Xb);
+                    __builtin_nontemporal_store(Xa, gx + k);
+                    if (k != 0 && k != half) __builtin_nontemporal_store(Xb, gx + (n - k));
+                }
+            } else {
+#pragma unroll 1
+                for (int k = tid; k < per; k += ONE_WG) {
+                    const CX A = img[k], Bn = (k != 0 && k != half) ? img[n - k] : A;
+                    CX Xa, Xb;
+                    pair_fwd(k, A, Bn, Xa, Xb);
+                    img[k] = Xa;
+                    if (k != 0 && k != half) img[n - k] = Xb;
+                }
+                __syncthreads();
+            }
+        }
+        if constexpr (out_int) {
+#pragma unroll 1
+            for (int i = tid; i < items4; i += ONE_WG) {
+                const CX x0 = img[bin_of(2 * i, 0, n, real)], x1 = img[bin_of(2 * i, 1, n, real)];
+                const CX x2 = img[bin_of(2 * i, 2, n, real)], x3 = img[bin_of(2 * i, 3, n, real)];
+                V4 re, im;
+                re.x = x0.x; re.y = x1.x; re.z = x2.x; re.w = x3.x;
+                im.x = x0.y; im.y = x1.y; im.z = x2.y; im.w = x3.y;
+                __builtin_nontemporal_store(re, reinterpret_cast<V4*>(gout + 8 * (size_t)i));
+                __builtin_nontemporal_store(im, reinterpret_cast<V4*>(gout + 8 * (size_t)i + 4));
+            }
+        }
+        const size_t nx = ctr ? (size_t)gridDim.x + s_next[it & 1] : cur + gridDim.x;
+        cur = nx;
+    }
+    if (ctr && tid == 0) {
+        __threadfence();
+        const unsigned dn = atomicAdd(&ctr[1], 1u);
+        if (dn == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }
+    }
+}
+
+}  // namespace pf

@@ -66,6 +66,9 @@ struct Setup {
     StockPlan sk[2], skw[2];          // workgroup-phase plans; wave-local plans (small n)
     int sk_threads = 0, skw_threads = 0;
     bool sk_ok = false, skw_ok = false;
+    // single-image plan (fft_one.h, round 6): the sizes that fill LDS once but not twice - [0] forward, [1] backward
+    StockPlan one[2];
+    bool one_ok = false;
     // device state (lazy: creating a setup never touches the GPU)
     std::mutex mu;        // guards the lazy device initialisation
     std::mutex stage_mu;  // guards the staging buffers of the legacy host-pointer entries
@@ -139,6 +142,12 @@ int launch_fir32(Setup* ps, const float* d_Hc, const float* d_x, float* d_y, int
 int launch_tile_rfft(Setup* s, const void* in, void* work, void* out, size_t batch, long long N, int dir, hipStream_t st);
 bool tile_rfft_has_plan(long long N, bool is_double, bool adopted = true);   // adopted: only where it measured faster
 size_t tile_rfft_work_elems(long long N, bool is_double);
+
+// one_tu.hip: the single-image kernel (fft_one.h) - one HBM pass for the vectors between 80 and 144 KiB that have no two-image Stockham plan
+bool one_build(int n, bool is_double, bool real, StockPlan out[2], size_t lds_max);
+size_t one_lds_bytes(const StockPlan& p, bool is_double, bool real);
+int launch_one(Setup* s, const void* in, void* out, size_t batch, int dir, int ordered, hipStream_t st);
+const void* one_kernel_ptr(bool is_double, int flags);
 
 // conv_tu.hip: forward -> x H (one filter spectrum, internal layout) -> backward in ONE kernel (fft_conv.h); -1: no fused kernel
 int launch_conv_fused(Setup* s, const void* in, const void* H, void* out, size_t batch, double scaling, int accumulate, hipStream_t st);

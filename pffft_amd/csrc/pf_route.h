@@ -65,6 +65,7 @@ enum AbValue : int {
     AB_CONV_COMPOSED = 120,     // pffft_hip_convolve_batch as the three batched entries
     AB_RFFT_THREE = 121,        // real transforms beyond LDS: always complex core + pair sweep
     AB_RFFT_TWO = 122,          // real transforms beyond LDS: two sweeps wherever the length splits
+    AB_NO_ONE_IMAGE = 123,      // the sizes of the single-image kernel (fft_one.h) on the tile / streaming passes they ran on before round 6
     AB_FAKE_DEVICE = 130,       // the calling thread counts as being on ANOTHER device than its current one (key + 64): exercises the per-device
                                 // replicas of a shared setup on a box with one GPU (tests/test_gpu_round6.py)
 };
@@ -76,7 +77,7 @@ struct AbSel {
 AbSel ab();   // the calling thread's selector
 
 // ------------------------------------------------------------------------------------------------ routes
-enum Family : uint8_t { FAM_NONE = 0, FAM_TINY, FAM_C1024, FAM_TILED, FAM_STOCK, FAM_BIG };
+enum Family : uint8_t { FAM_NONE = 0, FAM_TINY, FAM_C1024, FAM_TILED, FAM_STOCK, FAM_BIG, FAM_ONE };
 const char* family_name(Family f);
 
 // launch rule of an LDS-resident kernel

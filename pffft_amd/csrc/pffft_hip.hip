@@ -280,6 +280,9 @@ static Setup* new_setup(int N, int transform, int is_double) {
     // every other size that fits: mixed-radix Stockham kernel (fft_stock.h); the in-place kernel of
     // fft_generic.h keeps the sizes whose two images exceed LDS
     if (s->kernel == K_BIG) s->sk_ok = s->skw_ok = false;
+    // ... of those, the vectors that fill LDS once (80-144 KiB): ONE pass on the single-image kernel (fft_one.h, round 6); the plan above stays
+    // as the route of the helpers (zreorder, zconvolve) and of AB_NO_ONE_IMAGE
+    if (s->kernel == K_BIG) s->one_ok = one_build(s->n, is_double != 0, transform == PFFFT_REAL, s->one, LDS_MAX);
     if (s->kernel == K_GENERIC && !PF_HAS_VARIANTS && !sub_is_fast(s)) {
         // product build: only compile-time Stockham plans exist.  A size without one (none today) must not yield a setup whose
         // every transform fails: refuse it here, where the reference reports unsupported sizes too (NULL, src/pffft_priv_impl.h:1105-1109)
@@ -423,6 +426,32 @@ static int ensure_device(Setup* s) {
             }
             PF_CHECK(hipMalloc(&s->d_bigtw[i], sizeof(cx<T>) * m));
             PF_CHECK(hipMemcpy(s->d_bigtw[i], tw.data(), sizeof(cx<T>) * m, hipMemcpyHostToDevice));
+        }
+        if (s->one_ok) {   // single-image kernel: compact base twiddles per direction, W_N^k of the pair pass
+            const long double PI2 = 2.0L * 3.14159265358979323846264338327950288L;
+            for (int d = 0; d < 2; ++d) {
+                const StockPlan& sp = s->one[d];
+                std::vector<cx<T>> tc(sp.ctab + 1);
+                for (int st = 1; st < sp.ns; ++st) {
+                    const StockStage& g = sp.st[st];
+                    for (int jm = 0; jm < g.Ns; ++jm) {   // W_{Ns R}^jm
+                        const long double a = -PI2 * (long double)jm / (long double)(g.Ns * g.R);
+                        tc[g.tw_off + jm].x = (T)cosl(a); tc[g.tw_off + jm].y = (T)sinl(a);
+                    }
+                }
+                PF_CHECK(hipMalloc(&s->d_twc[d], sizeof(cx<T>) * tc.size()));
+                PF_CHECK(hipMemcpy(s->d_twc[d], tc.data(), sizeof(cx<T>) * tc.size(), hipMemcpyHostToDevice));
+            }
+            if (s->transform == PFFFT_REAL) {
+                const int m = s->n / 2 + 1;
+                std::vector<cx<T>> twr(m);
+                for (int k = 0; k < m; ++k) {
+                    const long double a = -PI2 * (long double)k / (long double)(2 * s->n);
+                    twr[k].x = (T)cosl(a); twr[k].y = (T)sinl(a);
+                }
+                PF_CHECK(hipMalloc(&s->d_twr, sizeof(cx<T>) * m));
+                PF_CHECK(hipMemcpy(s->d_twr, twr.data(), sizeof(cx<T>) * m, hipMemcpyHostToDevice));
+            }
         }
         s->dev_ready = true;
         return 0;
@@ -1160,6 +1189,7 @@ static Route plan_route(const Setup* s, int dir, int ordered, const AbSel& sel) 
             return r;
         }
     }
+    if (s->kernel == K_BIG && s->one_ok && !sel.is(AB_NO_ONE_IMAGE)) { r.fam = FAM_ONE; r.rule = LR_INORDER; return r; }
     if (s->kernel == K_BIG) { r.fam = FAM_BIG; r.rule = LR_INORDER; plan_big(s, dir, ordered, sel, r.big); return r; }
     if ((s->sk_ok || s->skw_ok) && plan_stock<T>(s, dir, ordered, sel, r)) { r.fam = FAM_STOCK; return r; }
     r.fam = FAM_NONE;   // (every legal size is routed above: new_setup sends whatever has no Stockham plan to the streaming passes, K_BIG)
@@ -1216,6 +1246,7 @@ static int transform_batch(Setup* s, const T* in, T* out, size_t batch, int dir,
         }
         case FAM_STOCK: return launch_stock<T>(s, *r, in, out, batch, dir, st);
         case FAM_BIG: return launch_big<T>(s, *r, in, out, batch, dir, ordered, st);
+        case FAM_ONE: return launch_one(s, in, out, batch, dir, ordered ? 1 : 0, st);
         default: break;
     }
     g_last_error = "pffft_hip: no kernel for this size";
@@ -1232,6 +1263,7 @@ const char* family_name(Family f) {
         case FAM_TILED: return "tiled";
         case FAM_STOCK: return "stockham";
         case FAM_BIG: return "fourstep";
+        case FAM_ONE: return "oneimage";
         default: return "none";
     }
 }
@@ -1275,6 +1307,13 @@ static int describe_route(const Setup* s, const Route& r, char* buf, size_t len)
             return snprintf(buf, len, "fourstep: %s; pre %d%s fuse_in %d col_in %d fuse_out %d post %d%s pair_after %d; %d sweeps", core, b.pre,
                             b.pre_separate ? "(separate)" : "", (int)b.fuse_in, (int)b.col_in, (int)b.fuse_out, b.post, b.post_separate ? "(separate)" : "",
                             (int)b.pair_after, b.sweeps);
+        }
+        case FAM_ONE: {
+            const StockPlan& sp = s->one[0];
+            char rad[48] = "";
+            for (int i = 0; i < sp.ns; ++i) snprintf(rad + strlen(rad), sizeof rad - strlen(rad), i ? " x %d" : "%d", sp.st[i].R);
+            return snprintf(buf, len, "oneimage: one %d-thread workgroup per vector, stages %s in place, lds %zu %s; 1 sweep", sp.C, rad,
+                            one_lds_bytes(sp, s->is_double != 0, s->transform == PFFFT_REAL), launch_rule_name(r.rule));
         }
         default: return snprintf(buf, len, "none");
     }
