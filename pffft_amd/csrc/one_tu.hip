@@ -27,6 +27,7 @@ bool one_build(int n, bool is_double, bool real, StockPlan out[2], size_t lds_ma
     const int last = best.back(); best.pop_back();
     for (int x : best) r.push_back(x);
     r.push_back(last);
+    if (r.front() < 8 || r.back() < 8) return false;     // (the stages next to the layout image exist for radices from 8: fft_one.h one_run)
     for (int dir = 0; dir < 2; ++dir) {
         StockPlan& p = out[dir];
         memset(&p, 0, sizeof p);
