@@ -334,6 +334,15 @@ def test_describe_matches_the_routing_restated_here():
                         assert kind == want, (dt, tr, N, ln)
                         if kind == "tiled":
                             assert "in-order oneshot<=" + ("16" if (not dbl and n == 4096 and tr == pa.COMPLEX) else "4") in body, ln
+                    elif n * (16 if dbl else 8) <= 147456:
+                        # round 6: the vectors that fill LDS once but not twice (80 000 B < vector <= 144 KiB) take ONE pass on the single-image
+                        # kernel (fft_one.h) in all four combinations; the size's family stays "fourstep" (its helpers run those passes)
+                        assert kind == "oneimage" and "1 sweep" in body and "in-order" in body, (dt, tr, N, ln)
+                        rad = [int(v) for v in body.split("stages ")[1].split(" in place")[0].split(" x ")]
+                        prod = 1
+                        for v in rad:
+                            prod *= v
+                        assert prod == n and 2 <= len(rad) <= 4 and rad[0] >= 8 and rad[-1] >= 8, (dt, tr, N, ln)
                     else:
                         assert kind == "fourstep", (dt, tr, N, ln)
                         two_sweep = tr == pa.REAL and dbl and N in (1 << 18, 1 << 19) and fwd
@@ -356,7 +365,7 @@ def test_describe_matches_the_routing_restated_here():
                         if tr == pa.COMPLEX and ordered:
                             assert "pre -1" in body and "post -1" in body and any(f" {k} sweeps" in body for k in (2, 3, 5)), ln
                 s.close()
-    assert seen.get("tiled", 0) > 60 and seen.get("stockham", 0) > 800 and seen.get("fourstep", 0) > 2000 and seen.get("tiny", 0) >= 8, seen
+    assert seen.get("tiled", 0) > 60 and seen.get("stockham", 0) > 800 and seen.get("fourstep", 0) > 1900 and seen.get("tiny", 0) >= 8 and seen.get("oneimage", 0) == 4 * 62, seen
     # an invalid handle
     import ctypes as C
     buf = C.create_string_buffer(64)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import pffft_amd as pa
+from conftest import legal_sizes, relerr
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -432,3 +433,84 @@ def test_bench_single_process_path(cfg):
         assert line["devices_seen"] == (min(gpus, nd) if not share else min(2, nd))
         assert line["parity_vs_reference"]["max_rel_err"] <= (1e-5 if cfg == "c2" else 1e-12)
         assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+# ------------------------------------------------------------------ the single-image kernel (fft_one.h): one pass for the vectors that fill LDS once
+def _oneimage_sizes(tr, dt):
+    esz = 8 if dt == "f32" else 16
+    out = []
+    for N in legal_sizes(tr, 0, 1 << 16):
+        n = N if tr == pa.COMPLEX else N // 2
+        if 80000 < n * esz <= 147456 and n & (n - 1):
+            out.append(N)
+    return out
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("tr", [pa.COMPLEX, pa.REAL])
+def test_oneimage_every_size_against_reference_and_the_tile_passes(ref, dt, tr):
+    """Every size of the single-image kernel, four direction x layout combinations: against the reference's transform (oracle/_ref) at the
+    flat bars, against the two / three tile passes the sizes ran on until round 6 (variant 123: an independent route to the same spectrum), in
+    place bit-identical to out of place, ordered bit-identical to zreorder(unordered) - on batches that are ragged against the 256 resident
+    workgroups (1, 257 and 600 vectors: the static first vector, the in-order counter, its reset between launches)."""
+    dtype, tdt, tol = (np.float32, torch.float32, 1e-5) if dt == "f32" else (np.float64, torch.float64, 1e-12)
+    sizes = _oneimage_sizes(tr, dt)
+    assert len(sizes) == (17 if dt == "f32" else 14), sizes
+    rng = np.random.default_rng(606)
+    for N in sizes:
+        s = pa.Setup(N, tr, dtype)
+        assert "oneimage" in pa.describe(s) and pa.kernel_name(s) == "fourstep"
+        rs = ref.setup(N, tr, dtype)
+        for batch in ((1, 257) if N != sizes[-1] else (1, 257, 600)):
+            x = torch.from_numpy(rng.uniform(-1, 1, (batch, s.vec_scalars)).astype(dtype)).cuda()
+            pick = sorted({0, batch - 1, batch // 2})
+            xh = x[pick].cpu().numpy()
+            for d in (pa.FORWARD, pa.BACKWARD):
+                res = {}
+                for o in (True, False):
+                    got = s.transform_batch(x, None, d, o)
+                    want = rs.batch(xh, d, o)
+                    e = relerr(got[pick].cpu().numpy(), want)
+                    lim = tol if (dt == "f32" or all(N % q for q in (3, 5))) else 2e-7     # (the reference's double build: DESIGN.md §4)
+                    assert e <= lim, (dt, tr, N, batch, d, o, e)
+                    pa.set_variant(123)
+                    try:
+                        old = s.transform_batch(x, None, d, o)
+                    finally:
+                        pa.set_variant(0)
+                    assert relerr(got[pick].cpu().numpy(), old[pick].cpu().numpy()) <= 4 * tol, (dt, tr, N, batch, d, o)
+                    y = x.clone()
+                    s.transform_batch(y, y, d, o)
+                    assert torch.equal(y, got), (dt, tr, N, batch, d, o, "in place")
+                    res[o] = got
+                if d == pa.FORWARD:
+                    assert torch.equal(s.zreorder_batch(res[False], None, pa.FORWARD), res[True]), (dt, tr, N, batch, "zreorder(unordered) != ordered")
+        s.close(); rs.close()
+
+
+def test_oneimage_streams_graph_and_roundtrip():
+    """The single-image kernel on ten streams at once (one work counter per launch), replayed from a HIP graph, and forward -> backward = N x."""
+    N, tr = 12000, pa.COMPLEX
+    s = pa.Setup(N, tr, np.float32)
+    x = torch.rand(700, 2 * N, device="cuda") * 2 - 1
+    want = s.transform_batch(x, None, pa.FORWARD, False)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(10)]
+    outs = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            outs.append(s.transform_batch(x, None, pa.FORWARD, False))
+    torch.cuda.synchronize()
+    for y in outs:
+        assert torch.equal(y, want)
+    st = torch.cuda.Stream(); g = torch.cuda.CUDAGraph()
+    y = torch.empty_like(x)
+    with torch.cuda.stream(st):
+        s.transform_batch(x, y, pa.FORWARD, False); torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=st):
+            s.transform_batch(x, y, pa.FORWARD, False)
+    y.zero_(); g.replay(); g.replay(); torch.cuda.synchronize()
+    assert torch.equal(y, want)
+    back = s.transform_batch(want, None, pa.BACKWARD, False)
+    assert float((back / N - x).abs().max()) <= 2e-5
+    s.close()
