@@ -137,9 +137,9 @@ __device__ __forceinline__ void one_stage(const StockStage& st, const OneCtx<T>&
                 }
                 __builtin_amdgcn_sched_barrier(0);   // (one trip's index arithmetic at a time: interleaved across trips it spills)
             } else {
-                const CX* p = c.gsrc + j;
+                // (uniform base + 32-bit element offset: one address register per load instead of a 64-bit pair)
 #pragma unroll
-                for (int q = 0; q < R; ++q) v[k][q] = __builtin_nontemporal_load(p + q * st.nb);
+                for (int q = 0; q < R; ++q) v[k][q] = __builtin_nontemporal_load(c.gsrc + (unsigned)(j + q * st.nb));
             }
         }
     }
@@ -175,13 +175,12 @@ __device__ __forceinline__ void one_stage(const StockStage& st, const OneCtx<T>&
                 }
                 __builtin_amdgcn_sched_barrier(0);
             } else {   // last stage: Ns = nb, result d is bin j + d nb
-                CX* p = c.gdst + j;
                 if (c.cj_out) {
 #pragma unroll
                     for (int d = 0; d < R; ++d) v[k][d].y = -v[k][d].y;
                 }
 #pragma unroll
-                for (int d = 0; d < R; ++d) __builtin_nontemporal_store(v[k][d], p + d * st.nb);
+                for (int d = 0; d < R; ++d) __builtin_nontemporal_store(v[k][d], c.gdst + (unsigned)(j + d * st.nb));
             }
         }
     }
@@ -279,7 +278,7 @@ fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, Stoc
         asm volatile("" : "+v"(tix));
         const T* gin = in + cur * vs;
         T* gout = out + cur * vs;
-        constexpr bool TOUCH = real && bwd;
+        constexpr bool TOUCH = (real && bwd) || (in_int && sizeof(T) == 8);
         [[maybe_unused]] int touched = 0;
         constexpr int NT = (int)(((size_t)one_nmax<T>() * sizeof(CX) / 128 + ONE_WG - 1) / ONE_WG);   // 128-byte lines per thread
         OneCtx<T> c;
@@ -387,6 +386,7 @@ fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, Stoc
             const bool first = si == 0, last = si == ns - 1;
             c.cj_in = first && bwd && !real;          // complex backward: conj o forward o conj (real backward: the pair pass conjugates)
             c.cj_out = last && bwd;
+            if constexpr (TOUCH) if (last) asm volatile("" ::"v"(touched));   // (consumed BEFORE the last stage: behind its stores the wait would cover them too)
             if (first && SRC0 != 1) { if constexpr (SRC0 != 1) one_run<T, SRC0, 1>(st, c); }
             else if (last && DSTL != 1) { if constexpr (DSTL != 1) one_run<T, 1, DSTL>(st, c); }
             else one_run<T, 1, 1>(st, c);
@@ -394,9 +394,10 @@ fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, Stoc
                 // One image leaves no room to hold the next vector, and a stage's operands leave no registers: its lines are TOUCHED instead - one
                 // 4-byte load per 128-byte line, issued behind the first stage's barriers (everyone knows the next vector by then), consumed at
                 // the end of the iteration - so that they travel from HBM to L2 / the Infinity Cache while the stages run and the next
-                // iteration's loads find them there.  Measured per flow (same box, alternating): real backward 0.33-0.39 -> 0.38-0.49; every flow whose
-                // first stage loads from HBM itself, and the complex backward one from the layout, -2 ... -10 %: real backward only
-                const size_t nxv = ctr ? (size_t)gridDim.x + s_next[it & 1] : cur + gridDim.x;
+                // iteration's loads find them there.  Measured per flow (same box, alternating): real backward 0.33-0.39 -> 0.38-0.49, double complex
+                // backward from the layout 0.37 -> 0.43; every flow whose first stage loads from HBM itself -3 ... -8 % (wherever the value is
+                // consumed), the float complex backward one from the layout -14 %: those stay untouched
+                const size_t nxv = ctr ? (size_t)gridDim.x + (unsigned)__builtin_amdgcn_readfirstlane((int)s_next[it & 1]) : cur + gridDim.x;
                 if (nxv < batch) {
                     const char* pn = reinterpret_cast<const char*>(in + nxv * vs);
                     const unsigned vbytes = (unsigned)(vs * sizeof(T));
@@ -408,7 +409,6 @@ fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, Stoc
                 }
             }
         }
-        if constexpr (TOUCH) asm volatile("" ::"v"(touched));
 
         // ---------------------------------------------------------------- output phases
         if constexpr (real && !bwd) {
@@ -480,7 +480,8 @@ fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, Stoc
                 if ((int)cc < nchk) __builtin_nontemporal_store(img16[one_lchunk<T>((int)cc)], g16 + cc);
             }
         }
-        const size_t nx = ctr ? (size_t)gridDim.x + s_next[it & 1] : cur + gridDim.x;
+        // (read back as a wave-uniform value: the vector's base pointers then live in scalar registers)
+        const size_t nx = ctr ? (size_t)gridDim.x + (unsigned)__builtin_amdgcn_readfirstlane((int)s_next[it & 1]) : cur + gridDim.x;
         cur = nx;
     }
     if (ctr && tid == 0) {
