@@ -48,6 +48,9 @@ CASES = [
     ("big20_B", "tile_fft_kernel<float, 10, 4, 0, 0", 2 * (1 << 30), "N=2^20 cplx f32, pass B"),
     ("gen600k_A", "tileg_kernel<float, 1024, 0, 1", 2 * 223 * 600000 * 8, "N=600000 cplx f32 = 750 x 800, column pass on a run-time plan (fft_tileg.h, round 4)"),
     ("gen600k_B", "tileg_kernel<float, 1024, 0, 0", 2 * 223 * 600000 * 8, "N=600000 cplx f32, row pass on a run-time plan"),
+    ("one12000", "fft_one_kernel<float, 0>", 2 * 11184 * 12000 * 8, "N=12000 cplx f32 forward ordered: single-image kernel 32 x 15 x 25 in place (fft_one.h, round 6), 1 GiB of vectors"),
+    ("one24000r", "fft_one_kernel<float, 10>", 2 * 11184 * 24000 * 4, "real N=24000 f32 forward unordered on the single-image kernel: stages, pair pass in place, gather into the internal layout"),
+    ("one9216d", "fft_one_kernel<double, 2>", 2 * 7281 * 9216 * 16, "N=9216 cplx f64 forward unordered on the single-image kernel: 12 x 8 x 8 x 12, last stage into the layout image"),
     ("c2_once12", "fft_c1024_f32_once_kernel<0, 0, 1, 4>", (1 << 12) * 16384, "N=1024 cplx f32 fwd, batch 2^12: one transform per wavefront in dispatch order (round 5)", 1024),
     ("c2_once14", "fft_c1024_f32_once_kernel<0, 0, 1, 4>", (1 << 14) * 16384, "N=1024 cplx f32 fwd, batch 2^14: one transform per wavefront in dispatch order (round 5)", 4096),
 ]

@@ -53,5 +53,8 @@ fft(1 << 20, pa.COMPLEX, np.float32, 128, ordered=True)
 fft(1 << 18, pa.REAL, np.float32, 1024, ordered=False)        # round 3: pair pass + internal layout as one block-kernel sweep
 fft(4000, pa.COMPLEX, np.float32, 1 << 15, ordered=False)     # a mixed-radix Stockham plan (workgroup kernel)
 fft(600000, pa.COMPLEX, np.float32, 223, ordered=True)        # round 4: 750 x 800 on the run-time tile passes (fft_tileg.h), 1 GiB of vectors
+fft(12000, pa.COMPLEX, np.float32, 11184, ordered=True)       # round 6: the single-image kernel (fft_one.h), 1 GiB of vectors, 32 x 15 x 25 in place
+fft(24000, pa.REAL, np.float32, 11184, ordered=False)         # ... real forward into the internal layout: pair pass in place + gather
+fft(9216, pa.COMPLEX, np.float64, 7281, ordered=False)        # ... double, four stages, last one into the layout image
 fft(1024, pa.COMPLEX, np.float32, 1 << 12)                    # round 5: the short-launch kernel of the headline size (one transform per wavefront)
 fft(1024, pa.COMPLEX, np.float32, 1 << 14)

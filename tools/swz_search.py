@@ -4,10 +4,12 @@ kernel, float and double, is priced with tools/lds_sim.py and only masks at the 
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from lds_sim import cycles, ideal
 import numpy as np, itertools
-L=1024; PP=4; TPT=128; WG=512
-base={1:0b0101,2:0b0110,3:0b0100}
+LOGL=int(sys.argv[1]) if len(sys.argv)>1 else 10
+L=1<<LOGL; PP=4; TPT=L//8; WG=TPT*PP
+RAD=([1<<(LOGL%3)] if LOGL%3 else [])+[8]*(LOGL//3)
+QB=(LOGL-2,LOGL-1)      # the bits of the point index that tell the quarters apart
 def mk(m8,m9):
-    masks=dict(base); masks[8]=m8; masks[9]=m9
+    masks={}; masks[QB[0]]=m8; masks[QB[1]]=m9
     def ua(pt,u):
         x=(pt<<2)|u
         for b,mv in masks.items():
@@ -22,10 +24,10 @@ def pat_cost(kind, fn):
 def patterns(ua,S):
     out={}
     # P2 reads
-    out['read']=pat_cost('r128', lambda tid: ua(tid//4+128*3, tid%4))
+    out['read']=pat_cost('r128', lambda tid: ua(tid//4+TPT*3, tid%4))
     # stage writes
     Ns=1
-    for s,R in enumerate([2,8,8,8]):
+    for s,R in enumerate(RAD):
         for d in range(R):
             def f(tid,d=d,Ns=Ns,R=R):
                 t=tid//4; p=tid%4; tk=t%Ns; tq=t//Ns
@@ -40,24 +42,24 @@ def patterns(ua,S):
         for k in (0,1):
             def f(tid,k=k):
                 g=tid+WG*1; ptq=g//16; r=g%16; bb=r//8; m=(r//2)%4
-                return ua(ptq+256*m, 2*bb+k)
+                return ua(ptq+(L//4)*m, 2*bb+k)
             out[f'oint{k}']=pat_cost('r128', f)
         def f(tid):
             g=tid+WG*1; ptq=g//16; r=g%16; bb=r//8; m=(r//2)%4; sub=r%2
-            return ua(ptq+256*m, 2*bb+sub)
+            return ua(ptq+(L//4)*m, 2*bb+sub)
         out['iint']=pat_cost('w128', f)
     else:
         for i in range(2):
             for sq in range(4):
-                out[f'tw{i}{sq}']=pat_cost('w128', lambda tid: ua(tid+512*i, sq))
+                out[f'tw{i}{sq}']=pat_cost('w128', lambda tid: ua(tid+WG*i, sq))
         for k in (0,1):
             def f(tid,k=k):
                 g=tid+WG*1; ptq=g//16; r=g%16; m=(r//4)%4; sub=r%4
-                return ua(ptq+256*m, 2*(sub&1)+k)
+                return ua(ptq+(L//4)*m, 2*(sub&1)+k)
             out[f'oint{k}']=pat_cost('r128', f)
         def f(tid):
             g=tid+WG*1; ptq=g//16; r=g%16; m=(r//4)%4; sub=r%4
-            return ua(ptq+256*m, 2*(sub&1)+(sub>>1))
+            return ua(ptq+(L//4)*m, 2*(sub&1)+(sub>>1))
         out['iint']=pat_cost('w128', f)
     return out
 def mk2(masks):
@@ -87,7 +89,7 @@ found=[]
 for (m1,m2,m3) in res:
     for m8 in range(16):
         for m9 in range(16):
-            masks={1:m1,2:m2,3:m3,8:m8,9:m9}
+            masks={1:m1,2:m2,3:m3,QB[0]:m8,QB[1]:m9}
             ua=mk2(masks)
             seen=set(ua(pt,u) for pt in range(L) for u in range(4))
             if len(seen)!=4*L or max(seen)>=4*L: continue
@@ -98,4 +100,5 @@ for (m1,m2,m3) in res:
     if len(found)>4000: break
 found.sort(key=lambda x:(x[0],x[1]))
 for f in found[:10]: print(f)
-print([f[2] for f in found if f[0]==1.0 and f[2][:3]==(5,2,4)][:20])
+print([f[2] for f in found if f[0]==1.0][:20])
+print("masks below 8 only:", [f[2] for f in found if f[0]==1.0 and max(f[2])<8][:10])
