@@ -364,9 +364,11 @@ template <int R, int DIR, typename V> __device__ __forceinline__ void dftR(V (&a
     else if constexpr (R == 12) dft_pfa<4, 3, DIR>(a);
     else if constexpr (R == 15) dft_pfa<3, 5, DIR>(a);
     else if constexpr (R == 16) dft16<DIR>(a);
+    else if constexpr (R == 20) dft_pfa<4, 5, DIR>(a);
     else if constexpr (R == 24) dft_pfa<8, 3, DIR>(a);
     else if constexpr (R == 25) dft_ct<5, 5, DIR>(a);
     else if constexpr (R == 27) dft_ct<3, 9, DIR>(a);
+    else if constexpr (R == 30) dft_pfa<6, 5, DIR>(a);
     else if constexpr (R == 32) dft32<DIR>(a);
 }
 

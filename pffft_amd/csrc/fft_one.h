@@ -28,8 +28,18 @@ constexpr int ONE_WG = 512;
 template <typename T> constexpr int one_nmax() { return sizeof(T) == 4 ? 18432 : 9216; }
 // trips of a stage of radix R: butterflies per thread (compile-time bound, the run-time count is predicated): as many as keep a thread's
 // operands within 48 (float) / 24 (double) complex registers - the planner only uses a radix where n / R butterflies fit (one_build)
-__host__ __device__ constexpr int one_trips_of(bool is_double, int R) { return (is_double ? 24 : 48) / R < 1 ? 1 : (is_double ? 24 : 48) / R; }
-template <typename T, int R> constexpr int one_trips() { return one_trips_of(sizeof(T) == 8, R); }
+// (float, radices 24 ... 32 as a MIDDLE stage - image to image: 32-bit LDS addresses, no 64-bit pair per HBM access - take TWO trips: that
+//  gives n = 14400 ... 18432 three-stage plans, 24 x 25 x 24 ... 24 x 32 x 24; every other (radix, position) keeps the 48 / 24 budget - a wider
+//  one for all of them spilled 50-350 B per lane in the kernels with a pair pass)
+// NARROW: the one kernel without them - the float complex backward transform from the internal layout, whose layout-image first stage (two scalar
+// picks and their index arithmetic per operand) is the kernel closest to its 256 registers: with the two-trip instantiations next to it its
+// three-stage sizes lost 13 % (n = 12000: 0.46 -> 0.40); it keeps a plan of its own (one_tu.hip: Setup::one[2])
+__host__ __device__ constexpr int one_trips_of(bool is_double, int R, bool middle = false, bool narrow = false) {
+    const int budget = is_double ? 24 : 48;
+    if (!is_double && middle && !narrow && R >= 24) return 2;
+    return budget / R < 1 ? 1 : budget / R;
+}
+template <typename T, int R, int SRC, int DST, bool NARROW> constexpr int one_trips() { return one_trips_of(sizeof(T) == 8, R, SRC == 1 && DST == 1, NARROW); }
 
 template <typename T> struct OneLds { size_t tab = 0, twr = 0, next = 0, total = 0; };
 template <typename T> __host__ __device__ constexpr OneLds<T> one_lds(const StockPlan& p, bool real) {
@@ -111,10 +121,10 @@ template <typename T, int R> __device__ __forceinline__ void one_twiddle(cx<T> (
 //   result d goes to logical point (j div Ns) Ns R + (j mod Ns) + d Ns of this stage's image (blocks of Ns R points padded to wblk).
 // Barriers: between the reads and the writes of an LDS -> LDS stage; before the writes of an HBM -> LDS stage (the previous vector's last
 // readers); after every stage that wrote the image.
-template <typename T, int R, int SRC, int DST>
+template <typename T, int R, int SRC, int DST, bool NARROW>
 __device__ __forceinline__ void one_stage(const StockStage& st, const OneCtx<T>& c) {
     typedef cx<T> CX;
-    constexpr int K = one_trips<T, R>();
+    constexpr int K = one_trips<T, R, SRC, DST, NARROW>();
     CX v[K][R];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -189,26 +199,28 @@ __device__ __forceinline__ void one_stage(const StockStage& st, const OneCtx<T>&
 
 // (the stages next to the layout image are the first / last one of a plan: radices from 8 - one_build; the small radices there, twelve and
 //  more trips of index arithmetic, were the kernels' only spills)
-template <typename T, int SRC, int DST>
+template <typename T, int SRC, int DST, bool NARROW>
 __device__ __forceinline__ void one_run(const StockStage& st, const OneCtx<T>& c) {
     switch (st.R) {
-        case 3: if constexpr (SRC != 2 && DST != 2) one_stage<T, 3, SRC, DST>(st, c); break;
-        case 4: if constexpr (SRC != 2 && DST != 2) one_stage<T, 4, SRC, DST>(st, c); break;
-        case 5: if constexpr (SRC != 2 && DST != 2) one_stage<T, 5, SRC, DST>(st, c); break;
-        case 6: if constexpr (SRC != 2 && DST != 2) one_stage<T, 6, SRC, DST>(st, c); break;
-        case 8: one_stage<T, 8, SRC, DST>(st, c); break;
-        case 9: one_stage<T, 9, SRC, DST>(st, c); break;
-        case 10: one_stage<T, 10, SRC, DST>(st, c); break;
-        case 12: one_stage<T, 12, SRC, DST>(st, c); break;
-        case 15: one_stage<T, 15, SRC, DST>(st, c); break;
-        case 16: one_stage<T, 16, SRC, DST>(st, c); break;
+        case 3: if constexpr (SRC != 2 && DST != 2) one_stage<T, 3, SRC, DST, NARROW>(st, c); break;
+        case 4: if constexpr (SRC != 2 && DST != 2) one_stage<T, 4, SRC, DST, NARROW>(st, c); break;
+        case 5: if constexpr (SRC != 2 && DST != 2) one_stage<T, 5, SRC, DST, NARROW>(st, c); break;
+        case 6: if constexpr (SRC != 2 && DST != 2) one_stage<T, 6, SRC, DST, NARROW>(st, c); break;
+        case 8: one_stage<T, 8, SRC, DST, NARROW>(st, c); break;
+        case 9: one_stage<T, 9, SRC, DST, NARROW>(st, c); break;
+        case 10: one_stage<T, 10, SRC, DST, NARROW>(st, c); break;
+        case 12: one_stage<T, 12, SRC, DST, NARROW>(st, c); break;
+        case 15: one_stage<T, 15, SRC, DST, NARROW>(st, c); break;
+        case 16: one_stage<T, 16, SRC, DST, NARROW>(st, c); break;
         default:
             if constexpr (sizeof(T) == 4) {
                 switch (st.R) {
-                    case 24: one_stage<T, 24, SRC, DST>(st, c); break;
-                    case 25: one_stage<T, 25, SRC, DST>(st, c); break;
-                    case 27: one_stage<T, 27, SRC, DST>(st, c); break;
-                    case 32: one_stage<T, 32, SRC, DST>(st, c); break;
+                    case 20: if constexpr (SRC == 1 && DST == 1) one_stage<T, 20, SRC, DST, NARROW>(st, c); break;   // (20, 30: middle stages only - one_build)
+                    case 24: one_stage<T, 24, SRC, DST, NARROW>(st, c); break;
+                    case 25: one_stage<T, 25, SRC, DST, NARROW>(st, c); break;
+                    case 27: one_stage<T, 27, SRC, DST, NARROW>(st, c); break;
+                    case 30: if constexpr (SRC == 1 && DST == 1) one_stage<T, 30, SRC, DST, NARROW>(st, c); break;
+                    case 32: one_stage<T, 32, SRC, DST, NARROW>(st, c); break;
                     default: break;
                 }
             }
@@ -290,8 +302,9 @@ fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, Stoc
         constexpr bool RIN_NAT = in_int && real;                       // real backward, internal layout in: straight into the NATURAL image
         constexpr bool ROUT_NAT = out_int && real && sizeof(T) == 4;   // real forward, internal layout out, float: gathered from the natural image
         if constexpr (RIN_NAT) {
-            // (measured against the layout image + pair pass across a barrier, which holds every pair of a thread in registers: 0.27-0.35 of the
-            //  roofline against 0.15-0.19) item i = (block b, quarter q) is eight scalars at offset 8 i of the layout - two dense 16 / 32-byte loads per
+            // (real: measured against the layout image + pair pass across a barrier, which holds every pair of a thread in registers: 0.27-0.35 of the
+            //  roofline against 0.15-0.19; float complex through the same deposit: 0.39-0.44 flat against 0.46-0.53 through
+            //  the layout image for n <= 13824 and 0.29-0.39 above: not adopted) item i = (block b, quarter q) is eight scalars at offset 8 i of the layout - two dense 16 / 32-byte loads per
             //  lane - and four bins of the natural image (bin_of, fft_generic.h); the pair pass then runs in place: bins k and n - k belong to one item
             typedef vec4<T> V4;
             constexpr int NI = (one_nmax<T>() / 4 + ONE_WG - 1) / ONE_WG;
@@ -312,22 +325,25 @@ fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, Stoc
             for (int r = 0; r < NI; ++r) {
                 const int i = tid_c + r * ONE_WG;
                 if (i < items4) {
-                    img[bin_of(2 * i, 0, n, 1)] = mk<T>(re[r].x, im[r].x);
-                    img[bin_of(2 * i, 1, n, 1)] = mk<T>(re[r].y, im[r].y);
-                    img[bin_of(2 * i, 2, n, 1)] = mk<T>(re[r].z, im[r].z);
-                    img[bin_of(2 * i, 3, n, 1)] = mk<T>(re[r].w, im[r].w);
+                    const T sg = real ? (T)1 : (T)-1;                  // (complex backward: conjugated on the way in)
+                    img[bin_of(2 * i, 0, n, real)] = mk<T>(re[r].x, sg * im[r].x);
+                    img[bin_of(2 * i, 1, n, real)] = mk<T>(re[r].y, sg * im[r].y);
+                    img[bin_of(2 * i, 2, n, real)] = mk<T>(re[r].z, sg * im[r].z);
+                    img[bin_of(2 * i, 3, n, real)] = mk<T>(re[r].w, sg * im[r].w);
                 }
             }
             __syncthreads();
+            if constexpr (real) {
 #pragma unroll 2
-            for (int k = tid_c; k < per; k += ONE_WG) {
-                const CX A = img[k], Bn = (k != 0 && k != half) ? img[n - k] : A;
-                CX Pk, Pm;
-                pair_bwd(k, A, Bn, Pk, Pm);
-                img[k] = Pk;
-                if (k != 0 && k != half) img[n - k] = Pm;
+                for (int k = tid_c; k < per; k += ONE_WG) {
+                    const CX A = img[k], Bn = (k != 0 && k != half) ? img[n - k] : A;
+                    CX Pk, Pm;
+                    pair_bwd(k, A, Bn, Pk, Pm);
+                    img[k] = Pk;
+                    if (k != 0 && k != half) img[n - k] = Pm;
+                }
+                __syncthreads();
             }
-            __syncthreads();
         } else if constexpr (in_int) {
             // the vector arrives in the internal layout: linear 16-byte chunks into the layout image
             const chunk16* g16 = reinterpret_cast<const chunk16*>(gin);
@@ -378,7 +394,8 @@ fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, Stoc
         }
 
         // ---------------------------------------------------------------- stages (one call site per kind of stage)
-        constexpr int SRC0 = first_from_g ? 0 : (in_int && !real) ? 2 : 1;   // (real: the pair pass left the natural image)
+        constexpr bool NARROW = (FLAGS & 15) == 5 && sizeof(T) == 4;
+        constexpr int SRC0 = first_from_g ? 0 : (in_int && !RIN_NAT) ? 2 : 1;   // (real: the pair pass left the natural image)
         constexpr int DSTL = last_to_g ? 0 : (out_int && !real) ? 2 : 1;
 #pragma unroll 1
         for (int si = 0; si < ns; ++si) {
@@ -387,9 +404,9 @@ fft_one_kernel(const T* __restrict__ in, T* __restrict__ out, size_t batch, Stoc
             c.cj_in = first && bwd && !real;          // complex backward: conj o forward o conj (real backward: the pair pass conjugates)
             c.cj_out = last && bwd;
             if constexpr (TOUCH) if (last) asm volatile("" ::"v"(touched));   // (consumed BEFORE the last stage: behind its stores the wait would cover them too)
-            if (first && SRC0 != 1) { if constexpr (SRC0 != 1) one_run<T, SRC0, 1>(st, c); }
-            else if (last && DSTL != 1) { if constexpr (DSTL != 1) one_run<T, 1, DSTL>(st, c); }
-            else one_run<T, 1, 1>(st, c);
+            if (first && SRC0 != 1) { if constexpr (SRC0 != 1) one_run<T, SRC0, 1, NARROW>(st, c); }
+            else if (last && DSTL != 1) { if constexpr (DSTL != 1) one_run<T, 1, DSTL, NARROW>(st, c); }
+            else one_run<T, 1, 1, NARROW>(st, c);
             if constexpr (TOUCH) if (first) {
                 // One image leaves no room to hold the next vector, and a stage's operands leave no registers: its lines are TOUCHED instead - one
                 // 4-byte load per 128-byte line, issued behind the first stage's barriers (everyone knows the next vector by then), consumed at

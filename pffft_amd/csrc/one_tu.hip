@@ -8,25 +8,48 @@ namespace pf {
 
 // Plan of the single-image kernel for n complex points: 2-4 stages from the radices dftR has, the stage next to HBM on either side large,
 // paddings from the bank model of stock_plan.h.  false: not a size for this kernel (it fits two images, or not even one, or has no plan).
-bool one_build(int n, bool is_double, bool real, StockPlan out[2], size_t lds_max) {
+bool one_build(int n, bool is_double, bool real, StockPlan out[2], size_t lds_max, bool narrow) {
     const int esz = is_double ? 16 : 8;
     const int nmax = is_double ? one_nmax<double>() : one_nmax<float>();
     if (n > nmax || n < 2048 || n % 16) return false;
     static const std::vector<int> setf = {32, 27, 25, 24, 16, 15, 12, 10, 9, 8, 6, 5, 4, 3};
     static const std::vector<int> setd = {16, 15, 12, 10, 9, 8, 6, 5, 4, 3};
-    // a radix is usable where its n / R butterflies fit the trips the kernel is compiled for
-    std::vector<int> set, cur, best;
-    for (int R : (is_double ? setd : setf))
-        if (n % R == 0 && n / R <= one_trips_of(is_double, R) * ONE_WG) set.push_back(R);
-    sk_search(n, 0, set, cur, best);
-    if (best.size() < 2 || best.size() > (size_t)SK_MAX_STAGES) return false;
-    // order: largest radix first (the stage that reads HBM), second largest last (the one that writes it), the rest ascending in between
-    std::sort(best.begin(), best.end());
+    // a radix is usable in a position where its n / R butterflies fit the trips the kernel is compiled for there (fft_one.h one_trips_of: the
+    // first and last stage hold 48 / 24 complex operands per thread, a middle one 64 / 32); the stages next to the layout image exist for
+    // radices from 8 (one_run).  Three stages where a triple fits (smallest radix sum; float: radices 20 and 30 join), else the fewest stages
+    // from the radices that fit anywhere.
+    auto fits = [&](int R, bool middle) { return n % R == 0 && n / R <= one_trips_of(is_double, R, middle) * ONE_WG; };
     std::vector<int> r;
-    r.push_back(best.back()); best.pop_back();
-    const int last = best.back(); best.pop_back();
-    for (int x : best) r.push_back(x);
-    r.push_back(last);
+    {
+        std::vector<int> set, cur, best;
+        for (int R : (is_double ? setd : setf)) if (fits(R, false)) set.push_back(R);
+        sk_search(n, 0, set, cur, best);
+        if (!narrow && (best.size() > 3 || best.size() < 2)) {
+            // no plan within three stages on the end-stage budgets: a triple whose MIDDLE radix takes two trips (n = 14400 = 24 x 25 x 24 ... 18432 =
+            // 24 x 32 x 24, float; four-stage plans measured 0.39-0.48 of the roofline where three-stage ones run 0.52-0.57)
+            static const std::vector<int> tri_f = {32, 30, 27, 25, 24, 20, 16, 15, 12, 10, 9, 8};
+            static const std::vector<int> tri_d = {16, 15, 12, 10, 9, 8};
+            const std::vector<int>& S = is_double ? tri_d : tri_f;
+            int best_sum = 1 << 30;
+            for (int f : S) for (int m : S) {
+                if (n % (f * m)) continue;
+                const int l = n / (f * m);
+                if (std::find(S.begin(), S.end(), l) == S.end()) continue;
+                if (!fits(f, false) || !fits(m, true) || !fits(l, false)) continue;
+                if (f == 20 || f == 30 || l == 20 || l == 30) continue;          // (radices 20 and 30 exist as middle stages only)
+                if (f + m + l < best_sum && f >= l) { best_sum = f + m + l; r = {f, m, l}; }   // (the larger end radix first: it reads HBM)
+            }
+        }
+        if (r.empty()) {
+            if (best.size() < 2 || best.size() > (size_t)SK_MAX_STAGES) return false;
+            // order: largest radix first (the stage that reads HBM), second largest last (the one that writes it), the rest ascending in between
+            std::sort(best.begin(), best.end());
+            r.push_back(best.back()); best.pop_back();
+            const int last = best.back(); best.pop_back();
+            for (int x : best) r.push_back(x);
+            r.push_back(last);
+        }
+    }
     if (r.front() < 8 || r.back() < 8) return false;     // (the stages next to the layout image exist for radices from 8: fft_one.h one_run)
     for (int dir = 0; dir < 2; ++dir) {
         StockPlan& p = out[dir];
@@ -96,8 +119,9 @@ template <typename T> static OneFn<T> one_kernel(int flags) {
 template <typename T>
 static int launch_one_t(Setup* s, const T* in, T* out, size_t batch, int dir, int ordered, hipStream_t st) {
     const bool bwd = dir == PFFFT_BACKWARD, real = s->transform == PFFFT_REAL;
-    const StockPlan& p = s->one[bwd ? 1 : 0];
     const int flags = (real ? 8 : 0) | (bwd ? 4 : 0) | (!ordered ? (bwd ? 1 : 2) : 0);
+    const int pi = (flags == 5 && sizeof(T) == 4) ? 2 : bwd ? 1 : 0;      // (the float complex backward transform from the layout: a plan of its own)
+    const StockPlan& p = s->one[pi];
     const size_t lds = one_lds<T>(p, real).total;
     auto k = one_kernel<T>(flags);
     int rc = allow_big_lds(k, lds);
@@ -106,7 +130,7 @@ static int launch_one_t(Setup* s, const T* in, T* out, size_t batch, int dir, in
     if (grid > batch) grid = batch;
     // in order from the counter (one grab per 80-144 KiB vector); a launch that the resident workgroups cover in one go needs none
     unsigned* ctr = (batch > grid && batch < 0xfffffff0ull) ? take_counters(s, st, 1) : nullptr;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(ONE_WG), lds, st, in, out, batch, p, (const cx<T>*)s->d_twc[bwd ? 1 : 0],
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(ONE_WG), lds, st, in, out, batch, p, (const cx<T>*)(pi == 2 ? s->d_one_tw2 : s->d_twc[pi]),
                        (const cx<T>*)s->d_twr, ctr);
     PF_CHECK(hipGetLastError());
     return 0;

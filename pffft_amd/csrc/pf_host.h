@@ -67,8 +67,9 @@ struct Setup {
     int sk_threads = 0, skw_threads = 0;
     bool sk_ok = false, skw_ok = false;
     // single-image plan (fft_one.h, round 6): the sizes that fill LDS once but not twice - [0] forward, [1] backward
-    StockPlan one[2];
+    StockPlan one[3];          // [2]: the float complex backward transform from the internal layout (fft_one.h NARROW: no two-trip middle stages)
     bool one_ok = false;
+    void* d_one_tw2 = nullptr; // compact twiddles of one[2]
     // device state (lazy: creating a setup never touches the GPU)
     std::mutex mu;        // guards the lazy device initialisation
     std::mutex stage_mu;  // guards the staging buffers of the legacy host-pointer entries
@@ -144,7 +145,7 @@ bool tile_rfft_has_plan(long long N, bool is_double, bool adopted = true);   // 
 size_t tile_rfft_work_elems(long long N, bool is_double);
 
 // one_tu.hip: the single-image kernel (fft_one.h) - one HBM pass for the vectors between 80 and 144 KiB that have no two-image Stockham plan
-bool one_build(int n, bool is_double, bool real, StockPlan out[2], size_t lds_max);
+bool one_build(int n, bool is_double, bool real, StockPlan out[2], size_t lds_max, bool narrow = false);
 size_t one_lds_bytes(const StockPlan& p, bool is_double, bool real);
 int launch_one(Setup* s, const void* in, void* out, size_t batch, int dir, int ordered, hipStream_t st);
 const void* one_kernel_ptr(bool is_double, int flags);

@@ -282,7 +282,14 @@ static Setup* new_setup(int N, int transform, int is_double) {
     if (s->kernel == K_BIG) s->sk_ok = s->skw_ok = false;
     // ... of those, the vectors that fill LDS once (80-144 KiB): ONE pass on the single-image kernel (fft_one.h, round 6); the plan above stays
     // as the route of the helpers (zreorder, zconvolve) and of AB_NO_ONE_IMAGE
-    if (s->kernel == K_BIG) s->one_ok = one_build(s->n, is_double != 0, transform == PFFFT_REAL, s->one, LDS_MAX);
+    if (s->kernel == K_BIG) {
+        s->one_ok = one_build(s->n, is_double != 0, transform == PFFFT_REAL, s->one, LDS_MAX);
+        if (s->one_ok) {
+            StockPlan narrow[2];
+            if (one_build(s->n, is_double != 0, transform == PFFFT_REAL, narrow, LDS_MAX, true)) s->one[2] = narrow[1];
+            else s->one_ok = false;
+        }
+    }
     if (s->kernel == K_GENERIC && !PF_HAS_VARIANTS && !sub_is_fast(s)) {
         // product build: only compile-time Stockham plans exist.  A size without one (none today) must not yield a setup whose
         // every transform fails: refuse it here, where the reference reports unsupported sizes too (NULL, src/pffft_priv_impl.h:1105-1109)
@@ -308,6 +315,7 @@ static void destroy_setup(Setup* s) {
         if (s->d_tw) (void)hipFree(s->d_tw);
         if (s->d_twr) (void)hipFree(s->d_twr);
         for (void* q : s->d_twc) if (q) (void)hipFree(q);
+        if (s->d_one_tw2) (void)hipFree(s->d_one_tw2);
     }
     if (s->d_ctr) (void)hipFree(s->d_ctr);
     if (s->sub) destroy_setup(s->sub);
@@ -429,7 +437,7 @@ static int ensure_device(Setup* s) {
         }
         if (s->one_ok) {   // single-image kernel: compact base twiddles per direction, W_N^k of the pair pass
             const long double PI2 = 2.0L * 3.14159265358979323846264338327950288L;
-            for (int d = 0; d < 2; ++d) {
+            for (int d = 0; d < 3; ++d) {
                 const StockPlan& sp = s->one[d];
                 std::vector<cx<T>> tc(sp.ctab + 1);
                 for (int st = 1; st < sp.ns; ++st) {
@@ -439,8 +447,9 @@ static int ensure_device(Setup* s) {
                         tc[g.tw_off + jm].x = (T)cosl(a); tc[g.tw_off + jm].y = (T)sinl(a);
                     }
                 }
-                PF_CHECK(hipMalloc(&s->d_twc[d], sizeof(cx<T>) * tc.size()));
-                PF_CHECK(hipMemcpy(s->d_twc[d], tc.data(), sizeof(cx<T>) * tc.size(), hipMemcpyHostToDevice));
+                void** dst = d < 2 ? &s->d_twc[d] : &s->d_one_tw2;
+                PF_CHECK(hipMalloc(dst, sizeof(cx<T>) * tc.size()));
+                PF_CHECK(hipMemcpy(*dst, tc.data(), sizeof(cx<T>) * tc.size(), hipMemcpyHostToDevice));
             }
             if (s->transform == PFFFT_REAL) {
                 const int m = s->n / 2 + 1;
@@ -1309,7 +1318,8 @@ static int describe_route(const Setup* s, const Route& r, char* buf, size_t len)
                             (int)b.pair_after, b.sweeps);
         }
         case FAM_ONE: {
-            const StockPlan& sp = s->one[0];
+            const int pi = (&r == &s->route[1][0] && !s->is_double && s->transform == PFFFT_COMPLEX) ? 2 : (&r == &s->route[1][0] || &r == &s->route[1][1]) ? 1 : 0;
+            const StockPlan& sp = s->one[pi];
             char rad[48] = "";
             for (int i = 0; i < sp.ns; ++i) snprintf(rad + strlen(rad), sizeof rad - strlen(rad), i ? " x %d" : "%d", sp.st[i].R);
             return snprintf(buf, len, "oneimage: one %d-thread workgroup per vector, stages %s in place, lds %zu %s; 1 sweep", sp.C, rad,
@@ -1853,6 +1863,14 @@ PF_EXPORT int pffft_hip_route_occupancy(const void* setup, int dir, int ordered)
     int per_cu = 0;
     if (r.fam == pf::FAM_TILED) { if (pf::allow_big_lds_impl(r.tiled.fn, r.tiled.lds) || pf::cached_occupancy(r.tiled.fn, r.tiled.wg, r.tiled.lds, &per_cu)) return -1; }
     else if (r.fam == pf::FAM_STOCK && r.stock.fn) { if (pf::allow_big_lds_impl(r.stock.fn, r.stock.lds) || pf::cached_occupancy(r.stock.fn, r.stock.threads, r.stock.lds, &per_cu)) return -1; }
+    else if (r.fam == pf::FAM_ONE) {
+        const bool real = s->transform == PFFFT_REAL;
+        const int flags = (real ? 8 : 0) | (dir ? 4 : 0) | (!ordered ? (dir ? 1 : 2) : 0);
+        const void* fn = pf::one_kernel_ptr(s->is_double != 0, flags);
+        const int pi = (flags == 5 && !s->is_double) ? 2 : dir;
+        const size_t lds = pf::one_lds_bytes(s->one[pi], s->is_double != 0, real);
+        if (pf::allow_big_lds_impl(fn, lds) || pf::cached_occupancy(fn, s->one[pi].C, lds, &per_cu)) return -1;
+    }
     return per_cu;
 }
 PF_EXPORT int pffft_hip_describe(const void* setup, char* buf, size_t len) {
