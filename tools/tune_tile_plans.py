@@ -28,6 +28,17 @@ L.pffft_hip_tile_override.restype = C.c_int
 L.pffft_hip_tile_override.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
 
 
+
+def box_stamp():
+    """One comment line naming the box a measured table was taken on (device, CU count, ROCm / HIP version, date): the tables are relative A/B
+    figures of ONE box - boxes of the pool differ by +-1.5-3 % (Stockham family up to 6 %) - and say which."""
+    import datetime
+    import torch
+    p = torch.cuda.get_device_properties(0)
+    return (f"// Taken on: {p.name} ({getattr(p, 'gcnArchName', '?')}, {p.multi_processor_count} CUs), HIP {torch.version.hip}, "
+            f"{datetime.datetime.utcnow().strftime('%Y-%m-%d')}; relative A/B figures of one box.\n")
+
+
 def candidates(n, dbl):
     buf = (C.c_int * (5 * 64))()
     cnt = min(64, L.pffft_hip_tile_candidates(n, int(dbl), buf, 64))
@@ -148,7 +159,7 @@ def main():
         f.write("// GENERATED by tools/tune_tile_plans.py - tile plans beyond LDS that were measured to beat the choice of the cost model (tile_tu.hip tile_cost)\n"
                 "// on MI355X by >= 3 % of the mean over the four direction x layout combinations (or to lift a minimum below 0.20 by >= 10 %), "
                 f"{mib} MiB per launch.\n// {{n, is_double, L1, gen1, L2, gen2}}: columns L1 then rows L2, gen = the run-time kernel of fft_tileg.h; L1 = 0: no tile plan, the\n"
-                "// streaming passes of fft_big.h win.  Log of the run: profiles/r05_tile_plan_tuning.txt\n#pragma once\nnamespace pf {\n"
+                "// streaming passes of fft_big.h win.  Log of the run: profiles/r05_tile_plan_tuning.txt\n" + box_stamp() + "#pragma once\nnamespace pf {\n"
                 "struct TilePlanEnt { long long n; int is_double, l1, g1, l2, g2; };\nstatic const TilePlanEnt kTilePlans[] = {\n")
         for e in sorted(kept + table, key=lambda e: (e[1], e[0])):
             f.write("    {%d, %d, %d, %d, %d, %d},\n" % e)
