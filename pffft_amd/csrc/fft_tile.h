@@ -154,6 +154,11 @@ __device__ __forceinline__ int tile_swz(int pt, int p) {
 //   2 (pass B, forward): row transforms of length L = N2 of the rows k1 <= N1/2: X[k1 + N1 k2]; k2 < N2/2 goes straight to its bin, k2 >=
 //     N2/2 conjugated to bin N - k = (N1 - k1) + N1 (N2 - 1 - k2) (Hermitian symmetry: the rows k1 > N1/2 are never computed) - every
 //     tile stores to two places instead of needing its mirror tile; bin 0 carries (DC, Nyquist) (include/pffft/pffft.h:144-155)
+//   3 (round 6, the LAST pass of a real forward transform on the complex core n = N/2 - any tile length, 128-byte runs): row tiles whose ROW SET IS
+//     CLOSED UNDER THE MIRROR k1 -> N1 - k1 - tile a = rows [aH, aH + H) and (N1 - aH - H, N1 - aH], H = C/2; tile 0 takes row N1/2 in place of
+//     the second copy of row 0 - so that both bins of every pair (k, n - k) = (k1 + N1 k2, (N1 - k1) + N1 (L - 1 - k2)) lie in ONE image: the pair pass
+//     X[k] = S + D, X[n-k] = conj(S - D) runs in LDS, in place, and the tile stores the canonical half-complex spectrum itself - two runs of H
+//     adjacent k1 per point (64 bytes; the mirror run sits one element off the grid).  The pair sweep over HBM of the three-sweep route is gone.
 template <typename T, int LOGL, int PP, int DIR, int SEQC, int PF, int OINT = 0, int IINT = 0, int R0 = 1, int RAG = 0, int RMODE = 0>
 __global__ void __launch_bounds__((R0 << LOGL) / 8 * PP, PF ? 2 : 3)
 tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned long long ntiles, TileDesc D, unsigned* ctr) {
@@ -197,7 +202,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     for (int i = tid; i < WLN; i += WG) wl[i] = tile_unit_root<T>((double)i / (double)L);
     constexpr int WB = G::WB;
     const bool lv3 = D.M > (1ull << (2 * WB));
-    if (SEQC) {
+    if (SEQC || RMODE == 3) {
         const double invM = 1.0 / (double)D.M;
         for (int i = tid; i < ((lv3 ? 3 : 2) << WB); i += WG) {
             const int lvl = i >> WB, m = i & ((1 << WB) - 1);
@@ -234,6 +239,13 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     };
     // pass A: unit p of points t + TPT m straight into the stage-0 operand registers;
     // pass B: elements g = tid + i WG of the [sequence][point] tile (coalesced over the points of a row)
+    // RMODE 3: row of sequence seq of tile a (mirror-closed row sets, H = C / 2)
+    auto mirror_row = [&](unsigned a, int seq) -> unsigned {
+        constexpr int H = C / 2;
+        if (seq < H) return a * H + (unsigned)seq;
+        const unsigned r = D.rn1 - a * H - (unsigned)(C - 1 - seq);
+        return r == D.rn1 ? D.rn1 / 2 : r;
+    };
     typedef typename std::conditional<SEQC != 0 || SWZ_ROWS2, U, CX>::type LD;
     constexpr int UPB_ = 2 * (int)sizeof(T), UPP_ = (C / 4) * UPB_;   // 16-byte units per block / per point row of the internal layout
     auto issue_loads = [&](const CX* src, LD (&r)[NLD], unsigned long long eb, int pv) {
@@ -270,7 +282,8 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int g = tid + i * WG, seq = WG == L ? i : g / L, pt = WG == L ? tid : g % L;   // (128-byte runs: WG == L)
-                if (seq < pv * S) r[i] = __builtin_nontemporal_load(src + (unsigned long long)seq * D.iss + pt);
+                if constexpr (RMODE == 3) r[i] = __builtin_nontemporal_load(src + (unsigned long long)mirror_row((unsigned)eb, seq) * D.iss + pt);
+                else if (seq < pv * S) r[i] = __builtin_nontemporal_load(src + (unsigned long long)seq * D.iss + pt);
             }
         }
     };
@@ -588,6 +601,79 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
                 U* dp = reinterpret_cast<U*>(dst + (unsigned long long)k1 * N2 + 2ull * mc);
                 __builtin_nontemporal_store(o0, dp);
                 __builtin_nontemporal_store(o1, dp + 1);
+            }
+        } else if constexpr (RMODE == 3) {
+            static_assert(RMODE != 3 || (!SEQC && DIR == FWD && !OINT && !IINT && PP == 8 && !RAG && !SWZ), "real pair pass in the tile: forward row pass on 128-byte tiles");
+            constexpr int H = C / 2;
+            const unsigned a = (unsigned)ebase, N1 = D.rn1;
+            CX* imgc = reinterpret_cast<CX*>(img);
+            auto at = [&](int pt, int seq) -> CX& { return imgc[pt * (PITCH * S) + seq]; };
+            // packed spectrum Z -> half-complex X (fft_stock.h / fft_one.h): S = (A + conj B) / 2, D = -(i/2) W_N^k (A - conj B), A = Z[k], B = Z[n-k]
+            auto pairw = [&](CX wk, CX A, CX Bn, CX& Xa, CX& Xb) {
+                const CX Sm = add_conj(A, Bn) * (T)0.5, Dm = cmul(sub_conj(A, Bn) * (T)0.5, wk);
+                Xa = add_rot<FWD>(Sm, Dm);
+                Xb = conj(sub_rot<FWD>(Sm, Dm));
+            };
+            static_assert(RMODE != 3 || ((H * L) % WG == 0 && WG % H == 0), "pairs per thread, one sequence per thread");
+            // a thread keeps its sequence c = tid mod H and walks the points k2 = tid / H + i WG / H: W_N^k of bin k = k1 + N1 k2 from ONE table
+            // product and one multiplication by W_N^(N1 WG / H) per step (a table product per pair made this pass as slow as pass + pair sweep)
+            const int c = tid % H;
+            const unsigned k1 = a * H + (unsigned)c;
+            CX wk = tile_w3<WB>(w3, k1 + N1 * (unsigned)(tid / H), lv3);
+            const CX wstep = tile_w3<WB>(w3, N1 * (unsigned)(WG / H), lv3), whalf = tile_w3<WB>(w3, N1 / 2, lv3);
+#pragma unroll
+            for (int i = 0; i < H * L / WG; ++i) {
+                const int k2 = tid / H + i * (WG / H);
+                if (a == 0 && c == 0) {
+                    // row 0 pairs with itself, (0, k2) <-> (0, L - k2); bin 0 carries (DC, Nyquist) (include/pffft/pffft.h:144-152), bin n/2 is conj Z
+                    if (k2 == 0) { const CX Z = at(0, 0); at(0, 0) = mk<T>(Z.x + Z.y, Z.x - Z.y); }
+                    else if (2 * k2 < L) { CX Xa, Xb; pairw(wk, at(k2, 0), at(L - k2, 0), Xa, Xb); at(k2, 0) = Xa; at(L - k2, 0) = Xb; }
+                    else if (2 * k2 == L) at(k2, 0) = conj(at(k2, 0));
+                    // ... and so does row N1/2 (the last sequence of tile 0): (N1/2, k2) <-> (N1/2, L - 1 - k2), bin N1/2 + N1 k2
+                    if (2 * k2 < L) { CX Xa, Xb; pairw(cmul(wk, whalf), at(k2, C - 1), at(L - 1 - k2, C - 1), Xa, Xb); at(k2, C - 1) = Xa; at(L - 1 - k2, C - 1) = Xb; }
+                } else {
+                    const int ps = C - 1 - c;                          // the sequence that holds row N1 - k1
+                    CX Xa, Xb;
+                    pairw(wk, at(k2, c), at(L - 1 - k2, ps), Xa, Xb);
+                    at(k2, c) = Xa; at(L - 1 - k2, ps) = Xb;
+                }
+                wk = cmul(wk, wstep);
+            }
+            __syncthreads();
+            // bins k1 + N1 k2: per point two runs of H adjacent k1 (no streaming hint: the mirror run shares its lines with the neighbour tile's).
+            // Float: the first run as 16-byte units; the mirror run starts one element off the 16-byte grid - its inner pairs as units, the two end
+            // elements alone (eight-byte stores of all sixteen: 16 instead of 9 store instructions per thread)
+            if constexpr (S == 2) {
+                constexpr int IPP = 4 + 3 + 2;                          // items per point
+#pragma unroll
+                for (int i = 0; i < (IPP * L + WG - 1) / WG; ++i) {
+                    const int g = tid + i * WG;
+                    if (g < IPP * L) {
+                        const int pt = g / IPP, j = g % IPP;
+                        CX* row = dst + (unsigned long long)pt * N1;
+                        if (j < 4) {                                    // sequences 2j, 2j + 1 -> bins aH + 2j, + 1
+                            *reinterpret_cast<U*>(row + a * H + 2 * j) = img[pt * PITCH + j];
+                        } else if (j < 7) {                             // sequences 9 + 2 (j - 4), + 1 -> an aligned pair inside the mirror run
+                            const int sq = 9 + 2 * (j - 4);
+                            if (a == 0 && sq + 1 == C - 1) {            // (tile 0: the last sequence is row N1/2, not the run's end)
+                                row[mirror_row(a, sq)] = at(pt, sq);
+                            } else {
+                                U o; TU::set(o, 0, at(pt, sq)); TU::set(o, 1, at(pt, sq + 1));
+                                *reinterpret_cast<U*>(row + mirror_row(a, sq)) = o;
+                            }
+                        } else if (j == 7) {
+                            row[mirror_row(a, 8)] = at(pt, 8);
+                        } else {
+                            row[mirror_row(a, C - 1)] = at(pt, C - 1);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < C * L / WG; ++i) {
+                    const int g = tid + i * WG, pt = g / C, seq = g % C;
+                    dst[(unsigned long long)pt * N1 + mirror_row(a, seq)] = at(pt, seq);
+                }
             }
         } else if constexpr (RMODE == 2) {
             static_assert(RMODE != 2 || (!SEQC && DIR == FWD && R0 == 1 && !OINT && !IINT), "real Hermitian store: forward row pass");

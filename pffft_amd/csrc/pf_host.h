@@ -159,13 +159,15 @@ int launch_fir_split1(Setup* ps, const float* d_Hc, const float* d_x, float* d_y
                       hipStream_t st, const FcBatch& fb, void** ab_cache);
 
 // tile_tu.hip: power-of-two sizes beyond LDS in two / three passes (fft_tile.h); canonical complex, in -> out through `work`
-// (same size, distinct from both; in may equal out).  -1 when the size has no tile plan.  layout 1 (forward only): the
+// (same size, distinct from both; in may equal out).  -1 when the size has no tile plan.  layout 3 (round 6, forward only, the complex core
+// of a REAL transform): the last pass carries the pair pass and stores the canonical half-complex spectrum.  layout 1 (forward only): the
 // spectrum is stored in the pffft-internal layout by the last pass; layout 2 (backward only): it is read from that layout
 // by the first pass.
 // (n complex points; -1 = no tile plan for n.  tile_has_plan: the same answer without launching)
 // deep: the streaming route of this n would take five sweeps - three tile passes are allowed
 int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, long long n, int dir, hipStream_t st, int layout = 0, int mode = 0);
-bool tile_has_plan(long long n, bool is_double, int mode = 0);   // mode: 0 complex / three streaming sweeps, 1 five (deep), 2 real core / three
+bool tile_has_plan(long long n, bool is_double, int mode = 0);
+bool tile_real_rows_plan(long long n, bool is_double, int mode);   // layout 3 of launch_tile_fft: real forward, the pair pass inside the last (row) pass   // mode: 0 complex / three streaming sweeps, 1 five (deep), 2 real core / three
 int tile_plan_lengths(long long n, bool is_double, int mode, int lengths[3]);
 int tile_plan_candidates(long long n, bool is_double, int* out, int max);   // every legal pair {L1, gen1, L2, gen2, model cost}
 int tile_plan_override(long long n, bool is_double, int l1, int g1, int l2, int g2);   // the tuner's hook (tools/tune_tile_plans.py)

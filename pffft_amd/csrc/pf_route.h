@@ -118,6 +118,7 @@ struct BigPlan {             // n beyond LDS: the sweeps over HBM, in order
     bool fuse_in = false;        // the first tile pass reads the internal layout itself
     bool col_in = false;         // the column pass of the streaming route reads it
     bool fuse_out = false;       // the last pass (tile pass or transpose) stores the internal layout itself
+    bool rfuse = false;          // real forward (round 6): the last tile pass carries the pair pass (fft_tile.h RMODE 3) - no pair sweep
     int post = -1;               // block kernel AFTER the core: 0 complex canonical -> internal, 2 real pair pass + internal, 5 permutation
     bool pair_after = false;     // real forward ordered: in-place pair pass on the result
     bool post_separate = false;  // AB_BIG_SEPARATE_SWEEPS: pair pass + zreorder kernel

@@ -1034,6 +1034,19 @@ static void plan_big(const Setup* s, int dir, int ordered, const AbSel& sel, Big
         else if (!fwd && real) b.pre = 4;                // canonical half-complex spectrum -> packed spectrum
         b.pre_separate = b.pre >= 0 && !blk;
     }
+    // Adopted where it measured faster over BOTH layouts: double (ordered 0.24 -> 0.29-0.32, unordered 0.24-0.25 -> 0.21-0.23 through the permutation
+    // sweep: +8 % on the pair); float gains on 128-point rows (+6 %) and loses on longer ones (-2 ... -7 %): AB_RFFT_TWO runs it there.
+    if (tiled && real && fwd && blk && !sel.is(AB_RFFT_THREE) && (dbl || sel.is(AB_RFFT_TWO)) && tile_real_rows_plan(s->n, dbl, b.tmode)) {
+        // real forward on a two-pass plan whose row pass is a register-tiled one on 128-byte runs: the pair pass runs INSIDE that pass (mirror-
+        // closed row tiles, fft_tile.h RMODE 3) - two sweeps into the canonical spectrum instead of three.  Ordered and unordered take the same
+        // route (pffft_transform_ordered == pffft_zreorder(pffft_transform) bit for bit): the unordered spectrum through the one-sweep
+        // permutation big_block_kernel<5>, as on the two-sweep route above.  AB_RFFT_THREE: the complex core + pair sweep (the second route of the tests)
+        b.core = BIG_TILES;
+        b.rfuse = true;
+        b.post = ordered ? -1 : 5;
+        b.sweeps = tile_plan_lengths(s->n, dbl, b.tmode, b.lens) + (ordered ? 0 : 1);
+        return;
+    }
     if (tiled) {
         b.core = BIG_TILES;
         b.fuse_out = fwd && !ordered && !real && (tlay & 1) && fuse_ok;      // the last tile pass stores the internal layout
@@ -1103,7 +1116,7 @@ static int launch_big(Setup* s, const Route& r, const T* in, T* out, size_t batc
     cx<T>* dest = (b.post >= 0) ? bufA : (cx<T>*)out;
     switch (b.core) {
         case BIG_TILES:
-            rc = launch_tile_fft(s, cur, bufB, dest, batch, (long long)s->n, dir, st, b.fuse_out ? 1 : b.fuse_in ? 2 : 0, b.tmode);
+            rc = launch_tile_fft(s, cur, bufB, dest, batch, (long long)s->n, dir, st, b.rfuse ? 3 : b.fuse_out ? 1 : b.fuse_in ? 2 : 0, b.tmode);
             if (rc < 0) { g_last_error = "pffft_hip: the planned tile passes have no kernel"; return (int)hipErrorInvalidValue; }
             if (rc) return rc;
             break;
@@ -1308,7 +1321,7 @@ static int describe_route(const Setup* s, const Route& r, char* buf, size_t len)
                 case BIG_RFFT2: snprintf(core, sizeof core, "real two-sweep tiles"); break;
                 case BIG_TILES:
                     if (b.lens[2]) snprintf(core, sizeof core, "tiles %d x %d x %d (mode %d)", b.lens[0], b.lens[1], b.lens[2], b.tmode);
-                    else snprintf(core, sizeof core, "tiles %d x %d (mode %d)", b.lens[0], b.lens[1], b.tmode);
+                    else snprintf(core, sizeof core, "tiles %d x %d (mode %d)%s", b.lens[0], b.lens[1], b.tmode, b.rfuse ? " real-rows" : "");
                     break;
                 case BIG_STREAM: snprintf(core, sizeof core, "streaming %d x %d%s", b.lens[0], b.lens[1], (s->sub && s->sub->kernel == K_BIG) ? " (rows beyond LDS)" : ""); break;
                 default: snprintf(core, sizeof core, "strided %d x %d", b.lens[0], b.lens[1]); break;

@@ -39,6 +39,21 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
         else if (out_int && fw) k = tile_fft_kernel<T, LOGL, PP, FWD, 0, PFB, 1, 0, R0, RAG>;
         else k = fw ? tile_fft_kernel<T, LOGL, PP, FWD, 0, PFB, 0, 0, R0, RAG> : tile_fft_kernel<T, LOGL, PP, BWD, 0, PFB, 0, 0, R0, RAG>;
     }
+    // the last pass of a real forward transform: mirror-closed row tiles with the pair pass inside (fft_tile.h RMODE 3; TileDesc::rn1 set)
+    if (D.rn1 && !D.seq_contig) {
+        if constexpr (PP == 8 && RAG == 0) {
+            if (!fw || out_int || in_int) { g_last_error = "pffft_hip: the fused real row pass is a forward pass into the canonical spectrum"; return (int)hipErrorInvalidValue; }
+            if constexpr (PFSEL < 0) {
+                const bool pf = pf_force >= 0 ? pf_force != 0 : lds > 40 * 1024;
+                k = pf ? tile_fft_kernel<T, LOGL, PP, FWD, 0, 1, 0, 0, R0, 0, 3> : tile_fft_kernel<T, LOGL, PP, FWD, 0, 0, 0, 0, R0, 0, 3>;
+            } else {
+                k = tile_fft_kernel<T, LOGL, PP, FWD, 0, PFSEL_B, 0, 0, R0, 0, 3>;
+            }
+        } else {
+            g_last_error = "pffft_hip: no fused real row pass for this tile geometry";
+            return (int)hipErrorInvalidValue;
+        }
+    }
     int rc = allow_big_lds(k, lds);
     if (rc) return rc;
     int per_cu = 0;
@@ -79,12 +94,14 @@ static int tile_pass_impl(const cx<T>* in, cx<T>* out, unsigned long long ntiles
     const bool dynm = !(ngroups <= grid || !want_dyn || ntiles >= 0xfffffff0ull);
     // (bit 2: per-XCD counters for the column passes with 64-byte runs only - adjacent tiles share every line there)
     const bool xpair = (xmode_env & 16) && PP == 4 && D.seq_contig;      // pairs of column tiles with 64-byte runs dealt per XCD (fft_tile.h)
-    const bool xctr = dynm && ((xmode_env & 2) || ((xmode_env & 4) && PP == 4 && D.seq_contig) || xpair) && grid % 8 == 0 && ngroups >= 64 && D.group <= 1;
+    const bool xctr = dynm && ((xmode_env & 2) || ((xmode_env & 4) && PP == 4 && D.seq_contig) || xpair || (D.rn1 && !D.seq_contig)) && grid % 8 == 0 && ngroups >= 64 && D.group <= 1;
     // (per-XCD counters: nine words = five {next, done} pairs of the ring, which is allocated with that much room past its end)
     unsigned* ctr = !dynm ? nullptr : take_counters(s, st, xctr ? 5 : 1);
     TileDesc D2 = D;
     static const int cstart_env = dev_env("PFFFT_HIP_TILE_CSTART", 0);   // A/B: start-up grabs from the counter
-    D2.xmode = (xctr ? 2u : 0u) | ((xctr && xpair) ? 4u : 0u) | ((!dynm && (xmode_env & 1) && D.group <= 1) ? 1u : 0u) | (cstart_env ? 8u : 0u);
+    // (the fused real row pass: the mirror runs of neighbouring tiles share their lines - XCD-contiguous tiles, static map or per-XCD counters)
+    const bool rrows = D.rn1 && !D.seq_contig;
+    D2.xmode = (xctr ? 2u : 0u) | ((xctr && xpair) ? 4u : 0u) | ((!dynm && ((xmode_env & 1) || rrows) && D.group <= 1) ? 1u : 0u) | (cstart_env ? 8u : 0u);
     if (D2.xmode & 1u) grid = (grid + 7) / 8 * 8;      // (the static map is a bijection on a grid of whole eights; the surplus workgroups retire at once)
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(G::WG), lds, st, in, out, ntiles, D2, ctr);
     PF_CHECK(hipGetLastError());

@@ -120,6 +120,27 @@ static int pass_rows(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long n
     return tile_any<T>(tl, pp, in, out, ntiles, D, dir, st, s, out_int, false);
 }
 
+// the LAST pass of a real forward transform on its complex core n = N1 L: row tiles closed under k1 -> N1 - k1, pair pass in the tile, canonical
+// half-complex spectrum out (fft_tile.h RMODE 3)
+template <typename T>
+static int pass_rows_real(Setup* s, const cx<T>* in, cx<T>* out, unsigned long long nvec, TileLen tl, unsigned long long N1, hipStream_t st) {
+    const int C = 8 * TileUnit<T>::S;
+    const unsigned long long L = tl.len();
+    TileDesc D{};
+    D.TA = (unsigned)(N1 / C); D.TB = 1;
+    D.vstride = N1 * L; D.ovstride = N1 * L;
+    D.ips = 1; D.iss = L; D.ops = N1;
+    D.M = 2 * N1 * L;                       // W_N^k of the pair pass, N = 2 n, from the kernel's four-step table
+    D.seq_contig = 0; D.rn1 = (unsigned)N1;
+    return tile_any<T>(tl, 8, in, out, nvec * D.TA, D, PFFFT_FORWARD, st, s, false, false);
+}
+// can the last pass of n's two-pass plan be that one?  A register-tiled row length on 128-byte runs (not the L = 1024 geometry, not a run-time
+// plan), whole mirror-closed tiles of the column length
+template <typename T> static bool real_rows_ok(const TileLen& ta, const TileLen& tb) {
+    const unsigned long long C = 8 * TileUnit<T>::S;
+    return !tb.gen && pick_pp<T>(tb) == 8 && ta.len() % C == 0 && ta.len() >= 2 * C && (ta.len() * tb.len()) * 2 <= (1ull << 27);
+}
+
 // Two-pass plan of a size with factors 3 and / or 5: n = L1 L2, L = R0 2^b with R0 in {1, 3, 5, 9, 15, 25, 27, 45} and a tile
 // length that is instantiated: power of two 64 .. 512, odd-stage lengths 48 .. 768 (tile_host.h: mr_min_logl / mr_max_logl; image
 // <= 110 KiB).  Which length is the column pass and which the row pass is decided by the measured cost of each (us per GiB of
@@ -448,16 +469,19 @@ int tile_plan_lengths(long long n, bool is_double, int mode, int lengths[3]) {
 // out_int: forward transform straight into the internal layout (the last pass stores it: no reorder sweep)
 template <typename T>
 static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t batch, long long n, int dir, hipStream_t st, bool out_int, bool in_int,
-                    int mode) {
+                    int mode, bool real_rows = false) {
     const bool deep = mode == 1;
     int rc;
     if (n & (n - 1)) {
         TileLen a, b, c;
         if (ab().is(AB_BIG_NO_MR_TILES)) return -1;
         if (tile_plan(n, sizeof(T) == 8, mode, a, b)) {
+            if (real_rows && !real_rows_ok<T>(a, b)) return -1;
             if ((rc = pass_columns<T>(s, in, work, batch, a, b.len(), dir, st, in_int))) return rc;
+            if (real_rows) return pass_rows_real<T>(s, work, out, batch, b, a.len(), st);
             return pass_rows<T>(s, work, out, batch, b, a.len(), 1, dir, st, out_int);
         }
+        if (real_rows) return -1;
         if (!deep || n > (1ll << 27) || !tile_plan3(n, sizeof(T) == 8, a, b, c)) return -1;
         if ((rc = pass_columns<T>(s, in, work, batch, a, b.len() * c.len(), dir, st, in_int))) return rc;
         if ((rc = pass_columns<T>(s, work, work, batch * a.len(), b, c.len(), dir, st))) return rc;
@@ -472,9 +496,12 @@ static int tile_fft(Setup* s, const cx<T>* in, cx<T>* work, cx<T>* out, size_t b
         TileLen ta{1, logn / 2}, tb{1, logn - logn / 2};
         TileLen ma{1, 0}, mb{1, 0};
         if (measured_plan(n, sizeof(T) == 8, ma, mb) == 1) { ta = ma; tb = mb; }
+        if (real_rows && !real_rows_ok<T>(ta, tb)) return -1;
         if ((rc = pass_columns<T>(s, in, work, batch, ta, tb.len(), dir, st, in_int))) return rc;
+        if (real_rows) return pass_rows_real<T>(s, work, out, batch, tb, ta.len(), st);
         return pass_rows<T>(s, work, out, batch, tb, ta.len(), 1, dir, st, out_int);
     }
+    if (real_rows) return -1;
     const int l1 = logn / 3, rem = logn - l1, l2 = rem / 2, l3 = rem - l2;
     // n = L1 n', n' = L2 L3:  A over L1 (columns n'), then per row of length n': A over L2 (in place), B over L3 with the
     // scatter X[(k3 L2 + k2) L1 + k1]
@@ -520,10 +547,27 @@ int tile_plan_override(long long n, bool is_double, int l1, int g1, int l2, int 
 
 // layout: 1 = forward, spectrum out in the internal layout; 2 = backward, spectrum in from the internal layout
 int launch_tile_fft(Setup* s, const void* in, void* work, void* out, size_t batch, long long n, int dir, hipStream_t st, int layout, int mode) {
-    const bool out_int = layout == 1, in_int = layout == 2;
-    if ((out_int && dir != PFFFT_FORWARD) || (in_int && dir != PFFFT_BACKWARD)) return -1;
-    if (s->is_double) return tile_fft<double>(s, (const cx<double>*)in, (cx<double>*)work, (cx<double>*)out, batch, n, dir, st, out_int, in_int, mode);
-    return tile_fft<float>(s, (const cx<float>*)in, (cx<float>*)work, (cx<float>*)out, batch, n, dir, st, out_int, in_int, mode);
+    const bool out_int = layout == 1, in_int = layout == 2, real_rows = layout == 3;
+    if ((out_int && dir != PFFFT_FORWARD) || (in_int && dir != PFFFT_BACKWARD) || (real_rows && dir != PFFFT_FORWARD)) return -1;
+    if (s->is_double) return tile_fft<double>(s, (const cx<double>*)in, (cx<double>*)work, (cx<double>*)out, batch, n, dir, st, out_int, in_int, mode, real_rows);
+    return tile_fft<float>(s, (const cx<float>*)in, (cx<float>*)work, (cx<float>*)out, batch, n, dir, st, out_int, in_int, mode, real_rows);
+}
+
+// does the two-pass plan of the complex core n of a real transform end in a row pass that can carry the pair pass (layout 3)?
+bool tile_real_rows_plan(long long n, bool is_double, int mode) {
+    if (n <= 0) return false;
+    TileLen a{1, 0}, b{1, 0};
+    if ((n & (n - 1)) == 0) {
+        int logn = 0;
+        while ((1ll << logn) < n) ++logn;
+        if (logn < 12 || logn > 20) return false;
+        a = TileLen{1, logn / 2}; b = TileLen{1, logn - logn / 2};
+        TileLen ma{1, 0}, mb{1, 0};
+        if (measured_plan(n, is_double, ma, mb) == 1) { a = ma; b = mb; }
+    } else {
+        if (ab().is(AB_BIG_NO_MR_TILES) || !tile_plan(n, is_double, mode, a, b)) return false;
+    }
+    return is_double ? real_rows_ok<double>(a, b) : real_rows_ok<float>(a, b);
 }
 
 }  // namespace pf
