@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "cxmath.h"
+#include "fft_big.h"   // pair_root: the W_N^k of every real pair pass beyond LDS
 
 namespace pf {
 
@@ -202,7 +203,7 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
     for (int i = tid; i < WLN; i += WG) wl[i] = tile_unit_root<T>((double)i / (double)L);
     constexpr int WB = G::WB;
     const bool lv3 = D.M > (1ull << (2 * WB));
-    if (SEQC || RMODE == 3) {
+    if (SEQC) {
         const double invM = 1.0 / (double)D.M;
         for (int i = tid; i < ((lv3 ? 3 : 2) << WB); i += WG) {
             const int lvl = i >> WB, m = i & ((1 << WB) - 1);
@@ -609,35 +610,39 @@ tile_fft_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, unsigned 
             CX* imgc = reinterpret_cast<CX*>(img);
             auto at = [&](int pt, int seq) -> CX& { return imgc[pt * (PITCH * S) + seq]; };
             // packed spectrum Z -> half-complex X (fft_stock.h / fft_one.h): S = (A + conj B) / 2, D = -(i/2) W_N^k (A - conj B), A = Z[k], B = Z[n-k]
-            auto pairw = [&](CX wk, CX A, CX Bn, CX& Xa, CX& Xb) {
+            // The arithmetic of the pair sweeps of the three-sweep route, operation for operation (fft_big.h big_block_kernel / real_pair_kernel): the
+            // pair (k, n - k) is evaluated from its SMALLER index, W_N^k through the same exact-argument evaluation (pair_root) - so that this pass
+            // and complex core + pair sweep give the same bits, and the unordered transform may keep its own three sweeps (pair + internal layout in
+            // one): pffft_transform_ordered == pffft_zreorder(pffft_transform) bit for bit (benchmarks/bench_pffft.c:343-349) whichever route runs
+            const long long nn = (long long)N1 * L;
+            auto pairx = [&](unsigned k, CX& Zk, CX& Zm) {               // Zk = Z[k] -> X[k], Zm = Z[n - k] -> X[n - k]
+                const bool low = 2ull * k <= (unsigned long long)nn;
+                const long long ks = low ? (long long)k : nn - (long long)k;
+                const CX A = low ? Zk : Zm, Bn = low ? Zm : Zk;
+                const CX wk = pair_root<T>(ks, nn);
                 const CX Sm = add_conj(A, Bn) * (T)0.5, Dm = cmul(sub_conj(A, Bn) * (T)0.5, wk);
-                Xa = add_rot<FWD>(Sm, Dm);
-                Xb = conj(sub_rot<FWD>(Sm, Dm));
+                const CX Xa = add_rot<FWD>(Sm, Dm), Xb = conj(sub_rot<FWD>(Sm, Dm));
+                Zk = low ? Xa : Xb; Zm = low ? Xb : Xa;
             };
             static_assert(RMODE != 3 || ((H * L) % WG == 0 && WG % H == 0), "pairs per thread, one sequence per thread");
-            // a thread keeps its sequence c = tid mod H and walks the points k2 = tid / H + i WG / H: W_N^k of bin k = k1 + N1 k2 from ONE table
-            // product and one multiplication by W_N^(N1 WG / H) per step (a table product per pair made this pass as slow as pass + pair sweep)
             const int c = tid % H;
             const unsigned k1 = a * H + (unsigned)c;
-            CX wk = tile_w3<WB>(w3, k1 + N1 * (unsigned)(tid / H), lv3);
-            const CX wstep = tile_w3<WB>(w3, N1 * (unsigned)(WG / H), lv3), whalf = tile_w3<WB>(w3, N1 / 2, lv3);
 #pragma unroll
             for (int i = 0; i < H * L / WG; ++i) {
                 const int k2 = tid / H + i * (WG / H);
                 if (a == 0 && c == 0) {
                     // row 0 pairs with itself, (0, k2) <-> (0, L - k2); bin 0 carries (DC, Nyquist) (include/pffft/pffft.h:144-152), bin n/2 is conj Z
                     if (k2 == 0) { const CX Z = at(0, 0); at(0, 0) = mk<T>(Z.x + Z.y, Z.x - Z.y); }
-                    else if (2 * k2 < L) { CX Xa, Xb; pairw(wk, at(k2, 0), at(L - k2, 0), Xa, Xb); at(k2, 0) = Xa; at(L - k2, 0) = Xb; }
+                    else if (2 * k2 < L) { CX Zk = at(k2, 0), Zm = at(L - k2, 0); pairx(N1 * (unsigned)k2, Zk, Zm); at(k2, 0) = Zk; at(L - k2, 0) = Zm; }
                     else if (2 * k2 == L) at(k2, 0) = conj(at(k2, 0));
                     // ... and so does row N1/2 (the last sequence of tile 0): (N1/2, k2) <-> (N1/2, L - 1 - k2), bin N1/2 + N1 k2
-                    if (2 * k2 < L) { CX Xa, Xb; pairw(cmul(wk, whalf), at(k2, C - 1), at(L - 1 - k2, C - 1), Xa, Xb); at(k2, C - 1) = Xa; at(L - 1 - k2, C - 1) = Xb; }
+                    if (2 * k2 < L) { CX Zk = at(k2, C - 1), Zm = at(L - 1 - k2, C - 1); pairx(N1 / 2 + N1 * (unsigned)k2, Zk, Zm); at(k2, C - 1) = Zk; at(L - 1 - k2, C - 1) = Zm; }
                 } else {
                     const int ps = C - 1 - c;                          // the sequence that holds row N1 - k1
-                    CX Xa, Xb;
-                    pairw(wk, at(k2, c), at(L - 1 - k2, ps), Xa, Xb);
-                    at(k2, c) = Xa; at(L - 1 - k2, ps) = Xb;
+                    CX Zk = at(k2, c), Zm = at(L - 1 - k2, ps);
+                    pairx(k1 + N1 * (unsigned)k2, Zk, Zm);
+                    at(k2, c) = Zk; at(L - 1 - k2, ps) = Zm;
                 }
-                wk = cmul(wk, wstep);
             }
             __syncthreads();
             // bins k1 + N1 k2: per point two runs of H adjacent k1 (no streaming hint: the mirror run shares its lines with the neighbour tile's).

@@ -1034,17 +1034,16 @@ static void plan_big(const Setup* s, int dir, int ordered, const AbSel& sel, Big
         else if (!fwd && real) b.pre = 4;                // canonical half-complex spectrum -> packed spectrum
         b.pre_separate = b.pre >= 0 && !blk;
     }
-    // Adopted where it measured faster over BOTH layouts: double (ordered 0.24 -> 0.29-0.32, unordered 0.24-0.25 -> 0.21-0.23 through the permutation
-    // sweep: +8 % on the pair); float gains on 128-point rows (+6 %) and loses on longer ones (-2 ... -7 %): AB_RFFT_TWO runs it there.
-    if (tiled && real && fwd && blk && !sel.is(AB_RFFT_THREE) && (dbl || sel.is(AB_RFFT_TWO)) && tile_real_rows_plan(s->n, dbl, b.tmode)) {
-        // real forward on a two-pass plan whose row pass is a register-tiled one on 128-byte runs: the pair pass runs INSIDE that pass (mirror-
-        // closed row tiles, fft_tile.h RMODE 3) - two sweeps into the canonical spectrum instead of three.  Ordered and unordered take the same
-        // route (pffft_transform_ordered == pffft_zreorder(pffft_transform) bit for bit): the unordered spectrum through the one-sweep
-        // permutation big_block_kernel<5>, as on the two-sweep route above.  AB_RFFT_THREE: the complex core + pair sweep (the second route of the tests)
+    // real forward ORDERED on a two-pass plan whose row pass is a register-tiled one on 128-byte runs: the pair pass runs INSIDE that pass (mirror-
+    // closed row tiles, fft_tile.h RMODE 3) - two sweeps into the canonical spectrum instead of three.  Its arithmetic is the pair sweeps' operation
+    // for operation, so the unordered transform keeps its three sweeps (pair pass + internal layout in one) and pffft_transform_ordered ==
+    // pffft_zreorder(pffft_transform) still holds bit for bit.  Adopted in double (0.24-0.25 -> 0.28-0.32 of the roofline); in float the exact-
+    // argument W_N^k per pair (a double-precision division + sincospif) costs the small tiles more than the sweep saves - 128-point rows 0.25 ->
+    // 0.23, 512-point rows 0.25 -> 0.26 - and AB_RFFT_TWO runs it.  AB_RFFT_THREE: the complex core + pair sweep (the second route of the tests)
+    if (tiled && real && fwd && ordered && blk && !sel.is(AB_RFFT_THREE) && (dbl || sel.is(AB_RFFT_TWO)) && tile_real_rows_plan(s->n, dbl, b.tmode)) {
         b.core = BIG_TILES;
         b.rfuse = true;
-        b.post = ordered ? -1 : 5;
-        b.sweeps = tile_plan_lengths(s->n, dbl, b.tmode, b.lens) + (ordered ? 0 : 1);
+        b.sweeps = tile_plan_lengths(s->n, dbl, b.tmode, b.lens);
         return;
     }
     if (tiled) {

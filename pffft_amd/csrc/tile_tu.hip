@@ -130,7 +130,7 @@ static int pass_rows_real(Setup* s, const cx<T>* in, cx<T>* out, unsigned long l
     D.TA = (unsigned)(N1 / C); D.TB = 1;
     D.vstride = N1 * L; D.ovstride = N1 * L;
     D.ips = 1; D.iss = L; D.ops = N1;
-    D.M = 2 * N1 * L;                       // W_N^k of the pair pass, N = 2 n, from the kernel's four-step table
+    D.M = 0;
     D.seq_contig = 0; D.rn1 = (unsigned)N1;
     return tile_any<T>(tl, 8, in, out, nvec * D.TA, D, PFFFT_FORWARD, st, s, false, false);
 }

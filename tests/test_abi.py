@@ -345,9 +345,9 @@ def test_describe_matches_the_routing_restated_here():
                         assert prod == n and 2 <= len(rad) <= 4 and rad[0] >= 8 and rad[-1] >= 8, (dt, tr, N, ln)
                     else:
                         assert kind == "fourstep", (dt, tr, N, ln)
-                        if "real-rows" in body:       # round 6: the pair pass inside the last tile pass - real forward, double, two-pass plans
-                            assert tr == pa.REAL and dbl and fwd and "tiles " in body and (" 2 sweeps" in body if ordered else " 3 sweeps" in body), ln
-                            assert ("post 5" in body) == (not ordered) and "pair_after 0" in body, ln
+                        if "real-rows" in body:       # round 6: the pair pass inside the last tile pass - real forward ordered on two-pass plans
+                            assert tr == pa.REAL and fwd and ordered and "tiles " in body and " 2 sweeps" in body, ln
+                            assert "post -1" in body and "pair_after 0" in body, ln
                         two_sweep = tr == pa.REAL and dbl and N in (1 << 18, 1 << 19) and fwd
                         assert ("real two-sweep" in body) == two_sweep, (dt, tr, N, ln)
                         if "tiles " in body and not two_sweep:
